@@ -1,0 +1,73 @@
+/* oracle/fx8010_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * C interface of the scalar CPU restatement of the reference interpreter
+ * (easypx/FX8010-Emulator-Core, class Klangraum::FX8010).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the
+ * product (fx8010-emulator-core_amd/) never links, imports or calls it.
+ * See fx8010_oracle.c for the per-function reference citations.
+ */
+#ifndef FX8010_ORACLE_H
+#define FX8010_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fxo fxo_t;
+
+/* sticky "outside the parity domain" flags (reference behaviour is UB/crash there) */
+enum {
+    FXO_OOD_TRAM_READ_NEG = 1 << 0,  /* (rpos-p)%size went negative: reference reads before the array */
+    FXO_OOD_TRAM_WRITE_OOB = 1 << 1, /* wpos+p beyond the reference's array */
+    FXO_OOD_TRAM_SIZE0 = 1 << 2,     /* delay op with size 0: reference divides by zero */
+    FXO_OOD_LUT_TABLE = 1 << 3,      /* LOG/EXP table index outside 0..31 */
+    FXO_OOD_LUT_INDEX = 1 << 4,      /* LOG/EXP x outside [-1,1] */
+    FXO_OOD_PASS_CAP = 1 << 5,       /* SKIP kept jumping over END: reference loops forever */
+    FXO_OOD_PARSE = 1 << 6           /* loader input on which the reference throws (stoi/stof) */
+};
+
+fxo_t* fxo_create(int channels);
+void fxo_destroy(fxo_t*);
+int fxo_load_file(fxo_t*, const char* path); /* 1 = ok, 0 = failed (see error list) */
+int fxo_load_text(fxo_t*, const char* text); /* same, program text in memory */
+void fxo_process(fxo_t*, const float* in, float* out);               /* one sample */
+void fxo_process_block(fxo_t*, const float* in, float* out, int S);  /* [S][channels] */
+int fxo_set_register(fxo_t*, const char* key, float v);              /* 0 found, 1 not found */
+float fxo_get_register(fxo_t*, const char* key);                     /* 1.0f when not found */
+int64_t fxo_instruction_counter(fxo_t*);
+int fxo_ready(fxo_t*);
+int fxo_channels(fxo_t*);
+unsigned fxo_ood_flags(fxo_t*);
+void fxo_seed_noise(fxo_t*, int32_t x1, int32_t x2);
+
+int fxo_error_count(fxo_t*);
+const char* fxo_error_desc(fxo_t*, int i);
+int fxo_error_row(fxo_t*, int i);
+int fxo_control_count(fxo_t*);
+const char* fxo_control_at(fxo_t*, int i);
+int fxo_meta_get(fxo_t*, const char* key, char* buf, int buflen);
+
+/* decoded program model (FX8010.h:167-194) for cross-checking the product's front-end */
+int fxo_num_registers(fxo_t*);
+const char* fxo_register_name(fxo_t*, int i);
+int fxo_register_type(fxo_t*, int i);
+int fxo_register_ioindex(fxo_t*, int i);
+float fxo_register_value(fxo_t*, int i);
+int fxo_num_instructions(fxo_t*);
+void fxo_instruction(fxo_t*, int i, int out8[8]); /* opcode,R,A,X,Y,hasInput,hasOutput,hasNoise */
+int fxo_itram_size(fxo_t*);
+int fxo_xtram_size(fxo_t*);
+/* kind 0 = LOG, 1 = EXP; returns 64 doubles */
+const double* fxo_lut(fxo_t*, int kind, int exponent);
+
+/* CPU baseline helper ("port"): `threads` independent oracle objects, each `samples`
+ * process() calls; returns wall seconds, -1 on load failure. */
+double fxo_bench(const char* path, long samples, int threads, const float* in, int in_len,
+                 long long* instr_out, double* checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
