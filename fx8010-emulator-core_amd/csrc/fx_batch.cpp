@@ -1,0 +1,437 @@
+// fx_batch.cpp — device state management and launch orchestration for one batch of instances.
+//
+// Device-resident state (all instance-fastest so a wavefront touches contiguous 256-byte runs):
+//   state  [rows][nPad] u32   one row per reference register (index = reference register index),
+//                             then output latches, TRAM cursors, LFSR words, ood flags, counter
+//   itram  [wave][iSlots][64] f32   reference smallDelayBuffer, include/FX8010.h:210
+//   xtram  [wave][xSlots][64] f32   reference largeDelayBuffer, include/FX8010.h:211
+//   lut    [64][65] f64             LOG tables 0..31, EXP tables 32..63
+//   stream steady | last | row table
+// Registers the decoder classifies as uniform live only in hostValue_ (and as immediates in the
+// stream); their state rows are refreshed when they turn per-instance.
+#include "fx_batch.hpp"
+
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/fx8010_amd.h"
+
+namespace fx {
+
+namespace {
+const Luts& sharedLuts() {
+    static const Luts l;
+    return l;
+}
+constexpr size_t kScratchBytes = 1 << 16;
+inline uint32_t bitsOf(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+}  // namespace
+
+Batch::Batch(int64_t nInstances, int channels, int device) : prog_(channels) {
+    if (nInstances < 1) throw std::runtime_error("n_instances must be >= 1");
+    if (channels < 1 || channels > kMaxChannels) throw std::runtime_error("num_channels must be 1..4");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        throw std::runtime_error(std::string("no usable HIP device (hipGetDeviceCount: ") + hipGetErrorString(e) + "); this library has no CPU fallback");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= count) throw std::runtime_error("HIP device ordinal out of range");
+    device_ = device;
+    n_ = nInstances;
+    nPad_ = (nInstances + 63) / 64 * 64;
+    auto chk = [&](hipError_t r, const char* what) {
+        if (r != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(r));
+    };
+    chk(hipSetDevice(device_), "hipSetDevice");
+    chk(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    chk(hipEventCreate(&ev0_), "hipEventCreate");
+    chk(hipEventCreate(&ev1_), "hipEventCreate");
+    chk(hipMalloc(reinterpret_cast<void**>(&dLut_), sizeof(double) * 64 * 65), "hipMalloc lut");
+    chk(hipMalloc(reinterpret_cast<void**>(&dScratch_), kScratchBytes), "hipMalloc scratch");
+    const Luts& L = sharedLuts();
+    chk(hipMemcpy(dLut_, &L.log_[0][0], sizeof(double) * 32 * 65, hipMemcpyHostToDevice), "lut upload");
+    chk(hipMemcpy(dLut_ + 32 * 65, &L.exp_[0][0], sizeof(double) * 32 * 65, hipMemcpyHostToDevice), "lut upload");
+}
+
+Batch::~Batch() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    (void)hipFree(dState_);
+    (void)hipFree(dITram_);
+    (void)hipFree(dXTram_);
+    (void)hipFree(dLut_);
+    (void)hipFree(dStream_);
+    (void)hipFree(dScratch_);
+    (void)hipFree(dIn_);
+    (void)hipFree(dOut_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Batch::fail(int code, const std::string& what) {
+    lastError_ = what;
+    return code;
+}
+int Batch::hipFail(hipError_t e, const char* where) {
+    return fail(e == hipErrorOutOfMemory ? FX_E_MEMORY : FX_E_NODEVICE, std::string(where) + ": " + hipGetErrorString(e));
+}
+
+bool Batch::loadFile(const std::string& path) { return afterLoad(prog_.loadFile(path)) == 1; }
+bool Batch::loadText(const std::string& text) { return afterLoad(prog_.loadText(text)) == 1; }
+
+int Batch::afterLoad(bool ok) {
+    (void)hipSetDevice(device_);
+    // registers may have been created even when the load failed; keep host mirrors in step
+    const size_t old = hostValue_.size();
+    hostValue_.resize(prog_.regs.size());
+    forcedLane_.resize(prog_.regs.size(), 0);
+    for (size_t r = old; r < prog_.regs.size(); ++r) hostValue_[r] = prog_.regs[r].value;
+    lowDirty_ = true;
+    if (!ok) return 0;
+    loaded_ = true;
+    if (ensureState() != 0) return 0;
+    return 1;
+}
+
+int Batch::fillRows(const std::vector<uint32_t>& rows, const std::vector<uint32_t>& values) {
+    size_t done = 0;
+    const size_t chunk = kScratchBytes / 8;
+    while (done < rows.size()) {
+        const size_t k = std::min(chunk, rows.size() - done);
+        hipError_t e = hipMemcpyAsync(dScratch_, rows.data() + done, k * 4, hipMemcpyHostToDevice, stream_);
+        if (e == hipSuccess) e = hipMemcpyAsync(dScratch_ + chunk, values.data() + done, k * 4, hipMemcpyHostToDevice, stream_);
+        if (e == hipSuccess) e = launchFillRows(dState_, nPad_, dScratch_, dScratch_ + chunk, (int)k, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);  // host vectors are pageable and reused
+        if (e != hipSuccess) return hipFail(e, "fillRows");
+        done += k;
+    }
+    return 0;
+}
+
+// Allocate the state block, or grow it when a further loadFile() added registers
+// (the reference accumulates registers across loads, source/FX8010.cpp:777 ff.).
+int Batch::ensureState() {
+    const StateLayout want = makeLayout((int)prog_.regs.size(), prog_.numChannels);
+    if (dState_ && want.totalRows == stateRows_) return 0;
+    uint32_t* fresh = nullptr;
+    const size_t rowBytes = (size_t)nPad_ * 4;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), rowBytes * want.totalRows);
+    if (e != hipSuccess) return hipFail(e, "hipMalloc state");
+    std::vector<uint32_t> rows, values;
+    const uint32_t* old = dState_;
+    const StateLayout was = stateLayout_;
+    dState_ = fresh;
+    int firstNew = 0;
+    if (old) {
+        if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+        auto copyRow = [&](int dst, int src) {
+            return hipMemcpyAsync(fresh + (size_t)dst * nPad_, old + (size_t)src * nPad_, rowBytes, hipMemcpyDeviceToDevice, stream_);
+        };
+        for (int r = 0; r < was.nRegs && e == hipSuccess; ++r) e = copyRow(r, r);
+        const int specials = was.totalRows - was.outBase;
+        for (int k = 0; k < specials && e == hipSuccess; ++k) e = copyRow(want.outBase + k, was.outBase + k);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        (void)hipFree(const_cast<uint32_t*>(old));
+        if (e != hipSuccess) return hipFail(e, "state grow");
+        firstNew = was.nRegs;
+    } else {
+        // specials of a fresh batch: latches 0, cursors 0, reference LFSR seeds, flags 0, counter 0
+        for (int k = want.outBase; k < want.totalRows; ++k) { rows.push_back(k); values.push_back(0); }
+        values[want.noiseBase - want.outBase + 0] = 0x70f4f854u;  // g_x1, include/FX8010.h:290
+        values[want.noiseBase - want.outBase + 1] = 0xe1e9f0a7u;  // g_x2, include/FX8010.h:291
+    }
+    for (int r = firstNew; r < want.nRegs; ++r) { rows.push_back(r); values.push_back(bitsOf(hostValue_[r])); }
+    stateLayout_ = want;
+    stateRows_ = want.totalRows;
+    return fillRows(rows, values);
+}
+
+int Batch::ensureTram() {
+    auto grow = [&](float*& buf, int& have, int want) -> int {
+        if (want <= have) return 0;
+        const size_t waves = (size_t)(nPad_ / 64);
+        float* fresh = nullptr;
+        const size_t bytes = waves * (size_t)want * 256;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), bytes);
+        if (e != hipSuccess) return hipFail(e, "hipMalloc TRAM");
+        e = hipMemsetAsync(fresh, 0, bytes, stream_);  // the parity domain assumes zeroed delay memory
+        if (e == hipSuccess && buf && have > 0) {
+            if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+            e = hipMemcpy2DAsync(fresh, (size_t)want * 256, buf, (size_t)have * 256, (size_t)have * 256, waves, hipMemcpyDeviceToDevice, stream_);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        if (e != hipSuccess) { (void)hipFree(fresh); return hipFail(e, "TRAM init"); }
+        (void)hipFree(buf);
+        buf = fresh;
+        have = want;
+        return 0;
+    };
+    int rc = grow(dITram_, iSlotsAlloc_, low_.iSlots);
+    if (rc == 0) rc = grow(dXTram_, xSlotsAlloc_, low_.xSlots);
+    return rc;
+}
+
+bool Batch::laneResident(int reg) const {
+    if (reg < (int)forcedLane_.size() && forcedLane_[reg]) return true;
+    return !lowDirty_ ? low_.rowOfReg[reg] >= 0 : (reg < (int)low_.rowOfReg.size() && low_.rowOfReg[reg] >= 0);
+}
+
+int Batch::ensureLowered() {
+    if (!loaded_ || !prog_.ready) return fail(FX_E_NOTREADY, "no program loaded");
+    if (!lowDirty_) return 0;
+    std::vector<int> before = low_.rowOfReg;
+    Lowered fresh = lowerProgram(prog_, hostValue_, forcedLane_);
+    if (!fresh.error.empty()) return fail(FX_E_PROGRAM, fresh.error);
+    int rc = ensureState();
+    if (rc != 0) return rc;
+    // registers that were uniform and are per-instance from now on: seed their rows
+    std::vector<uint32_t> rows, values;
+    for (size_t r = 0; r < fresh.rowOfReg.size(); ++r) {
+        const bool was = r < before.size() && before[r] >= 0;
+        const bool forced = forcedLane_[r] != 0;  // already seeded when it was forced
+        if (fresh.rowOfReg[r] >= 0 && !was && !forced) { rows.push_back((uint32_t)r); values.push_back(bitsOf(hostValue_[r])); }
+    }
+    low_ = std::move(fresh);
+    if (!rows.empty() && (rc = fillRows(rows, values)) != 0) return rc;
+    if ((rc = ensureTram()) != 0) return rc;
+
+    // upload: steady | last | row table
+    const size_t nOps = low_.steady.size();
+    const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size();
+    if (words > streamCap_) {
+        if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+        (void)hipFree(dStream_);
+        dStream_ = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dStream_), words * 4 + 256);
+        if (e != hipSuccess) return hipFail(e, "hipMalloc stream");
+        streamCap_ = words;
+    }
+    std::vector<uint32_t> host(words);
+    std::memcpy(host.data(), low_.steady.data(), nOps * 32);
+    std::memcpy(host.data() + nOps * 8, low_.last.data(), nOps * 32);
+    size_t p = nOps * 16;
+    for (const RowCopy& rcp : low_.loadRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+    for (const RowCopy& rcp : low_.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still read the old stream
+    hipError_t e = hipMemcpy(dStream_, host.data(), words * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hipFail(e, "stream upload");
+    lowDirty_ = false;
+    return 0;
+}
+
+int Batch::setRegister(const std::string& key, float v) {
+    (void)hipSetDevice(device_);
+    const int r = prog_.findRegister(key);
+    if (r < 0) return 1;
+    hostValue_[r] = v;
+    const bool resident = laneResident(r);
+    forcedLane_[r] = 0;  // every instance holds the same value again
+    lowDirty_ = true;    // immediates (and possibly the classification) change
+    if (resident && dState_) {
+        if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+        int rc = fillRows({(uint32_t)r}, {bitsOf(v)});
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+int Batch::setRegisterAt(const std::string& key, int64_t inst, float v) {
+    (void)hipSetDevice(device_);
+    const int r = prog_.findRegister(key);
+    if (r < 0) return 1;
+    if (inst < 0 || inst >= n_) return fail(FX_E_ARG, "instance out of range");
+    if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    if (!laneResident(r)) {
+        int rc = fillRows({(uint32_t)r}, {bitsOf(hostValue_[r])});
+        if (rc != 0) return rc;
+        forcedLane_[r] = 1;
+        lowDirty_ = true;
+    }
+    hipError_t e = hipMemcpy(dState_ + (size_t)r * nPad_ + inst, &v, 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hipFail(e, "setRegisterAt");
+    return 0;
+}
+
+float Batch::getRegisterAt(const std::string& key, int64_t inst) {
+    (void)hipSetDevice(device_);
+    const int r = prog_.findRegister(key);
+    if (r < 0) return 1.0f;  // reference getRegisterValue default, source/FX8010.cpp:265
+    if (inst < 0 || inst >= n_ || !dState_ || !laneResident(r)) return hostValue_[r];
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    float v = 0.0f;
+    if (hipMemcpy(&v, dState_ + (size_t)r * nPad_ + inst, 4, hipMemcpyDeviceToHost) != hipSuccess) return hostValue_[r];
+    return v;
+}
+
+int Batch::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
+    (void)hipSetDevice(device_);
+    if (inst < 0 || inst >= n_) return fail(FX_E_ARG, "instance out of range");
+    if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    hipError_t e = hipMemcpy(dState_ + (size_t)(stateLayout_.noiseBase + 0) * nPad_ + inst, &x1, 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dState_ + (size_t)(stateLayout_.noiseBase + 1) * nPad_ + inst, &x2, 4, hipMemcpyHostToDevice);
+    return e == hipSuccess ? 0 : hipFail(e, "seedNoiseAt");
+}
+
+int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
+    (void)hipSetDevice(device_);
+    if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
+    int rc = ensureLowered();
+    if (rc != 0) return rc;
+    if (nSamples == 0) return 0;
+    if (!dIn || !dOut) return fail(FX_E_ARG, "null buffer");
+    hipStream_t s = pick(stream);
+    KernelArgs a{};
+    const size_t nOps = low_.steady.size();
+    a.steady = dStream_;
+    a.last = dStream_ + nOps * 8;
+    a.rowTable = dStream_ + nOps * 16;
+    a.state = dState_;
+    a.in = dIn;
+    a.out = dOut;
+    a.itram = dITram_;
+    a.xtram = dXTram_;
+    a.lut = dLut_;
+    a.n = n_;
+    a.nPad = nPad_;
+    a.nOps = (int)nOps;
+    a.nLoad = (int)low_.loadRows.size();
+    a.nStore = (int)low_.storeRows.size();
+    a.nSamples = nSamples;
+    a.channels = prog_.numChannels;
+    for (int c = 0; c < kMaxChannels; ++c) {
+        a.inRow[c] = c < prog_.numChannels ? low_.inRow[c] : -1;
+        a.latchRow[c] = c < prog_.numChannels ? low_.latchRow[c] : 0;
+    }
+    a.iSlots = iSlotsAlloc_;
+    a.xSlots = xSlotsAlloc_;
+    a.iSize = prog_.iTramSize;
+    a.xSize = prog_.xTramSize;
+    a.cursorBase = stateLayout_.cursorBase;
+    a.noiseBase = stateLayout_.noiseBase;
+    a.oodRow = stateLayout_.oodRow;
+    a.countLo = stateLayout_.countLo;
+    a.countHi = stateLayout_.countHi;
+    a.staticCount = low_.staticCount;
+    a.nRows = low_.nRows;
+    hipError_t e = hipEventRecord(ev0_, s);
+    if (e == hipSuccess) e = launchStepBlock(a, low_.multipass, s);
+    if (e == hipSuccess) e = hipEventRecord(ev1_, s);
+    if (e != hipSuccess) return hipFail(e, "launch fx_step_block");
+    lastStream_ = s;
+    timed_ = true;
+    lastGrid_ = (unsigned)(nPad_ / 64);
+    return 0;
+}
+
+int Batch::processHost(const float* in, float* out, int nSamples) {
+    (void)hipSetDevice(device_);
+    if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
+    if (nSamples == 0) return ensureLowered();
+    if (!in || !out) return fail(FX_E_ARG, "null buffer");
+    const size_t count = (size_t)nSamples * prog_.numChannels * (size_t)n_;
+    if (count > ioCap_) {
+        (void)hipStreamSynchronize(stream_);
+        (void)hipFree(dIn_);
+        (void)hipFree(dOut_);
+        dIn_ = dOut_ = nullptr;
+        ioCap_ = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dIn_), count * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dOut_), count * 4);
+        if (e != hipSuccess) return hipFail(e, "hipMalloc io");
+        ioCap_ = count;
+    }
+    hipError_t e = hipMemcpyAsync(dIn_, in, count * 4, hipMemcpyHostToDevice, stream_);
+    if (e != hipSuccess) return hipFail(e, "H2D");
+    int rc = processDevice(dIn_, dOut_, nSamples, stream_);
+    if (rc != 0) return rc;
+    e = hipMemcpyAsync(out, dOut_, count * 4, hipMemcpyDeviceToHost, stream_);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    if (e != hipSuccess) return hipFail(e, "D2H");
+    return 0;
+}
+
+int Batch::sync() {
+    (void)hipSetDevice(device_);
+    hipError_t e = hipStreamSynchronize(stream_);
+    if (e == hipSuccess && lastStream_ && lastStream_ != stream_) e = hipStreamSynchronize(lastStream_);
+    return e == hipSuccess ? 0 : hipFail(e, "sync");
+}
+
+int64_t Batch::instructionCounter() {
+    (void)hipSetDevice(device_);
+    if (!dState_) return 0;
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    unsigned long long zero[2] = {0, 0};
+    unsigned long long* dSum = reinterpret_cast<unsigned long long*>(dScratch_);
+    uint32_t* dOr = dScratch_ + 2;
+    if (hipMemcpy(dSum, zero, 16, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (launchReduceRow(dState_, nPad_, n_, stateLayout_.countLo, stateLayout_.countHi, stateLayout_.oodRow, dSum, dOr, stream_) != hipSuccess) return -1;
+    if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
+    unsigned long long res[2] = {0, 0};
+    if (hipMemcpy(res, dSum, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)res[0];
+}
+
+uint32_t Batch::oodFlags() {
+    (void)hipSetDevice(device_);
+    if (!dState_) return 0;
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    unsigned long long zero[2] = {0, 0};
+    unsigned long long* dSum = reinterpret_cast<unsigned long long*>(dScratch_);
+    uint32_t* dOr = dScratch_ + 2;
+    if (hipMemcpy(dSum, zero, 16, hipMemcpyHostToDevice) != hipSuccess) return ~0u;
+    if (launchReduceRow(dState_, nPad_, n_, stateLayout_.countLo, stateLayout_.countHi, stateLayout_.oodRow, dSum, dOr, stream_) != hipSuccess) return ~0u;
+    if (hipStreamSynchronize(stream_) != hipSuccess) return ~0u;
+    uint32_t res[4] = {0, 0, 0, 0};
+    if (hipMemcpy(res, dSum, 16, hipMemcpyDeviceToHost) != hipSuccess) return ~0u;
+    return res[2];
+}
+
+int64_t Batch::instructionCounterAt(int64_t inst) {
+    (void)hipSetDevice(device_);
+    if (!dState_ || inst < 0 || inst >= n_) return 0;
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    uint32_t lo = 0, hi = 0;
+    (void)hipMemcpy(&lo, dState_ + (size_t)stateLayout_.countLo * nPad_ + inst, 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&hi, dState_ + (size_t)stateLayout_.countHi * nPad_ + inst, 4, hipMemcpyDeviceToHost);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+float Batch::lastKernelMs() {
+    (void)hipSetDevice(device_);
+    if (!timed_) return -1.0f;
+    if (hipEventSynchronize(ev1_) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, ev0_, ev1_) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+int64_t Batch::info(int what) {
+    if (what == FXB_INFO_DEVICE) return device_;
+    if (what == FXB_INFO_NUM_INSTRUCTIONS) return (int64_t)prog_.instrs.size();
+    if (what == FXB_INFO_NUM_REGISTERS) return (int64_t)prog_.regs.size();
+    if (what == FXB_INFO_GRID) return lastGrid_;
+    if (what == FXB_INFO_WAVES_PER_WG) return 1;
+    if (what == FXB_INFO_INST_PER_LANE) return 1;
+    if (ensureLowered() != 0) return -1;
+    switch (what) {
+        case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
+        case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
+        case FXB_INFO_LDS_BYTES_PER_WG: return (int64_t)low_.nRows * 256;
+        case FXB_INFO_NUM_MICROOPS: return (int64_t)low_.steady.size();
+        case FXB_INFO_ITRAM_SLOTS: return iSlotsAlloc_;
+        case FXB_INFO_XTRAM_SLOTS: return xSlotsAlloc_;
+        case FXB_INFO_TRAM_OPS: return low_.tramOpsPerSample;
+        case FXB_INFO_MULTIPASS: return low_.multipass ? 1 : 0;
+        case FXB_INFO_NUM_SHADOWED: return low_.nShadowed;
+        case FXB_INFO_NUM_CCR_LIVE: return low_.nCcrLive;
+        default: return -1;
+    }
+}
+
+}  // namespace fx

@@ -1,0 +1,91 @@
+// fx_batch.hpp — host engine behind the C ABI: N instances of one program on one GPU.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "fx_decode.hpp"
+#include "fx_kernel.hpp"
+#include "fx_model.hpp"
+
+namespace fx {
+
+class Batch {
+public:
+    // throws std::runtime_error when no HIP device is usable (there is no CPU fallback)
+    Batch(int64_t nInstances, int channels, int device);
+    ~Batch();
+    Batch(const Batch&) = delete;
+    Batch& operator=(const Batch&) = delete;
+
+    bool loadFile(const std::string& path);
+    bool loadText(const std::string& text);
+
+    int setRegister(const std::string& key, float v);                    // 0 found, 1 not found, <0 error
+    int setRegisterAt(const std::string& key, int64_t inst, float v);
+    float getRegisterAt(const std::string& key, int64_t inst);           // 1.0f when not found
+    int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
+
+    int processHost(const float* in, float* out, int nSamples);           // synchronous
+    int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
+    int sync();
+
+    int64_t instructionCounter();
+    int64_t instructionCounterAt(int64_t inst);
+    uint32_t oodFlags();
+    float lastKernelMs();
+    int64_t info(int what);
+
+    const Program& program() const { return prog_; }
+    const std::string& lastError() const { return lastError_; }
+    int channels() const { return prog_.numChannels; }
+    void setChannels(int c) { prog_.numChannels = c; }
+
+private:
+    int fail(int code, const std::string& what);
+    int hipFail(hipError_t e, const char* where);
+    int afterLoad(bool ok);
+    int ensureLowered();          // (re)lower + upload the stream when dirty
+    int ensureState();            // allocate / grow the state block for the current register count
+    int ensureTram();
+    int fillRows(const std::vector<uint32_t>& rows, const std::vector<uint32_t>& values);
+    bool laneResident(int reg) const;
+    hipStream_t pick(hipStream_t s) const { return s ? s : stream_; }
+
+    Program prog_;
+    std::vector<float> hostValue_;      // current value of every register as the host knows it
+    std::vector<uint8_t> forcedLane_;   // registers given per-instance values by setRegisterAt
+    Lowered low_;
+    bool lowDirty_ = true;
+    bool loaded_ = false;
+
+    int64_t n_ = 0, nPad_ = 0;
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    hipStream_t lastStream_ = nullptr;
+    bool timed_ = false;
+
+    uint32_t* dState_ = nullptr;
+    StateLayout stateLayout_;
+    int stateRows_ = 0;
+    float* dITram_ = nullptr;
+    float* dXTram_ = nullptr;
+    int iSlotsAlloc_ = 0, xSlotsAlloc_ = 0;
+    double* dLut_ = nullptr;
+    uint32_t* dStream_ = nullptr;
+    size_t streamCap_ = 0;
+    uint32_t* dScratch_ = nullptr;  // small device scratch: fill lists, reductions
+    float* dIn_ = nullptr;
+    float* dOut_ = nullptr;
+    size_t ioCap_ = 0;
+    unsigned lastGrid_ = 0;
+
+    std::string lastError_;
+};
+
+}  // namespace fx

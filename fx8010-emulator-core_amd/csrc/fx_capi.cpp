@@ -1,0 +1,194 @@
+// fx_capi.cpp — extern "C" surface declared in include/fx8010_amd.h.
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <new>
+#include <string>
+
+#include "../../include/fx8010_amd.h"
+#include <vector>
+
+#include "fx_batch.hpp"
+
+struct fxb_handle {
+    fx::Batch batch;
+    fxb_handle(int64_t n, int ch, int dev) : batch(n, ch, dev) {}
+};
+struct fx_handle {
+    fx::Batch batch;
+    explicit fx_handle(int ch) : batch(1, ch, -1) {}
+};
+
+struct fxp_handle {
+    fx::Program prog;
+    fx::Lowered low;
+    bool lowered = false;
+    std::string err;
+    explicit fxp_handle(int ch) : prog(ch) {}
+};
+
+namespace {
+thread_local std::string g_createError;
+
+template <class H, class... A>
+H* create(A... args) {
+    try {
+        g_createError.clear();
+        return new H(args...);
+    } catch (const std::exception& e) {
+        g_createError = e.what();
+    } catch (...) {
+        g_createError = "unknown error";
+    }
+    return nullptr;
+}
+
+int errorCount(fx::Batch& b) { return (int)b.program().errors.size(); }
+const char* errorDesc(fx::Batch& b, int i) {
+    const auto& e = b.program().errors;
+    return (i < 0 || i >= (int)e.size()) ? "" : e[i].description.c_str();
+}
+int errorRow(fx::Batch& b, int i) {
+    const auto& e = b.program().errors;
+    return (i < 0 || i >= (int)e.size()) ? -1 : e[i].row;
+}
+int controlCount(fx::Batch& b) { return (int)b.program().controls.size(); }
+const char* controlAt(fx::Batch& b, int i) {
+    const auto& c = b.program().controls;
+    return (i < 0 || i >= (int)c.size()) ? "" : c[i].c_str();
+}
+int metaGet(fx::Batch& b, const char* key, char* buf, int buflen) {
+    if (!key) return 0;
+    for (const auto& kv : b.program().meta)
+        if (kv.first == key) {
+            if (buf && buflen > 0) std::snprintf(buf, (size_t)buflen, "%s", kv.second.c_str());
+            return 1;
+        }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+const char* fx_last_create_error(void) { return g_createError.c_str(); }
+const char* fxb_version(void) { return "fx8010_amd 0.1 (gfx950)"; }
+int fxb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* ---- single instance ---- */
+fx_handle* fx_create(int num_channels) { return create<fx_handle>(num_channels); }
+void fx_destroy(fx_handle* h) { delete h; }
+int fx_load_file(fx_handle* h, const char* path) { return (h && path && h->batch.loadFile(path)) ? 1 : 0; }
+int fx_process(fx_handle* h, const float* in, float* out) { return h ? h->batch.processHost(in, out, 1) : FX_E_ARG; }
+int fx_process_block(fx_handle* h, const float* in, float* out, int n) { return h ? h->batch.processHost(in, out, n) : FX_E_ARG; }
+int fx_set_register(fx_handle* h, const char* key, float v) { return (h && key) ? h->batch.setRegister(key, v) : 1; }
+float fx_get_register(fx_handle* h, const char* key) { return (h && key) ? h->batch.getRegisterAt(key, 0) : 1.0f; }
+int64_t fx_instruction_counter(fx_handle* h) { return h ? h->batch.instructionCounterAt(0) : 0; }
+int fx_error_count(fx_handle* h) { return h ? errorCount(h->batch) : 0; }
+const char* fx_error_desc(fx_handle* h, int i) { return h ? errorDesc(h->batch, i) : ""; }
+int fx_error_row(fx_handle* h, int i) { return h ? errorRow(h->batch, i) : -1; }
+int fx_control_count(fx_handle* h) { return h ? controlCount(h->batch) : 0; }
+const char* fx_control_at(fx_handle* h, int i) { return h ? controlAt(h->batch, i) : ""; }
+int fx_meta_get(fx_handle* h, const char* key, char* buf, int buflen) { return h ? metaGet(h->batch, key, buf, buflen) : 0; }
+void fx_set_channels(fx_handle* h, int c) { if (h) h->batch.setChannels(c); }
+int fx_get_channels(fx_handle* h) { return h ? h->batch.channels() : 0; }
+int fx_ready(fx_handle* h) { return (h && h->batch.program().ready) ? 1 : 0; }
+const char* fx_last_error(fx_handle* h) { return h ? h->batch.lastError().c_str() : "null handle"; }
+
+/* ---- batch ---- */
+fxb_handle* fxb_create(int64_t n, int ch, int device) { return create<fxb_handle>(n, ch, device); }
+void fxb_destroy(fxb_handle* h) { delete h; }
+int fxb_load_file(fxb_handle* h, const char* path) { return (h && path && h->batch.loadFile(path)) ? 1 : 0; }
+int fxb_load_text(fxb_handle* h, const char* text) { return (h && text && h->batch.loadText(text)) ? 1 : 0; }
+int fxb_set_register(fxb_handle* h, const char* key, float v) { return (h && key) ? h->batch.setRegister(key, v) : 1; }
+int fxb_set_register_i(fxb_handle* h, const char* key, int64_t inst, float v) { return (h && key) ? h->batch.setRegisterAt(key, inst, v) : 1; }
+float fxb_get_register_i(fxb_handle* h, const char* key, int64_t inst) { return (h && key) ? h->batch.getRegisterAt(key, inst) : 1.0f; }
+int fxb_seed_noise_i(fxb_handle* h, int64_t inst, int32_t x1, int32_t x2) { return h ? h->batch.seedNoiseAt(inst, x1, x2) : FX_E_ARG; }
+int fxb_process_block(fxb_handle* h, const float* in, float* out, int n) { return h ? h->batch.processHost(in, out, n) : FX_E_ARG; }
+int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n, void* stream) {
+    return h ? h->batch.processDevice(d_in, d_out, n, static_cast<hipStream_t>(stream)) : FX_E_ARG;
+}
+int fxb_sync(fxb_handle* h) { return h ? h->batch.sync() : FX_E_ARG; }
+int64_t fxb_instruction_counter(fxb_handle* h) { return h ? h->batch.instructionCounter() : 0; }
+int64_t fxb_instruction_counter_i(fxb_handle* h, int64_t inst) { return h ? h->batch.instructionCounterAt(inst) : 0; }
+uint32_t fxb_ood_flags(fxb_handle* h) { return h ? h->batch.oodFlags() : 0; }
+int fxb_error_count(fxb_handle* h) { return h ? errorCount(h->batch) : 0; }
+const char* fxb_error_desc(fxb_handle* h, int i) { return h ? errorDesc(h->batch, i) : ""; }
+int fxb_error_row(fxb_handle* h, int i) { return h ? errorRow(h->batch, i) : -1; }
+int fxb_control_count(fxb_handle* h) { return h ? controlCount(h->batch) : 0; }
+const char* fxb_control_at(fxb_handle* h, int i) { return h ? controlAt(h->batch, i) : ""; }
+int fxb_meta_get(fxb_handle* h, const char* key, char* buf, int buflen) { return h ? metaGet(h->batch, key, buf, buflen) : 0; }
+int fxb_ready(fxb_handle* h) { return (h && h->batch.program().ready) ? 1 : 0; }
+const char* fxb_last_error(fxb_handle* h) { return h ? h->batch.lastError().c_str() : "null handle"; }
+float fxb_last_kernel_ms(fxb_handle* h) { return h ? h->batch.lastKernelMs() : -1.0f; }
+int64_t fxb_info(fxb_handle* h, int what) { return h ? h->batch.info(what) : -1; }
+
+
+/* ---- front-end only ---- */
+fxp_handle* fxp_create(int ch) { return create<fxp_handle>(ch); }
+void fxp_destroy(fxp_handle* h) { delete h; }
+int fxp_load_file(fxp_handle* h, const char* path) { if (!h || !path) return 0; h->lowered = false; return h->prog.loadFile(path) ? 1 : 0; }
+int fxp_load_text(fxp_handle* h, const char* text) { if (!h || !text) return 0; h->lowered = false; return h->prog.loadText(text) ? 1 : 0; }
+int fxp_num_registers(fxp_handle* h) { return h ? (int)h->prog.regs.size() : 0; }
+const char* fxp_register_name(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.regs.size()) ? h->prog.regs[i].name.c_str() : ""; }
+int fxp_register_type(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.regs.size()) ? h->prog.regs[i].type : -1; }
+int fxp_register_ioindex(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.regs.size()) ? h->prog.regs[i].io : -1; }
+float fxp_register_value(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.regs.size()) ? h->prog.regs[i].value : 0.0f; }
+int fxp_num_instructions(fxp_handle* h) { return h ? (int)h->prog.instrs.size() : 0; }
+void fxp_instruction(fxp_handle* h, int i, int o[8]) {
+    if (!h || i < 0 || i >= (int)h->prog.instrs.size()) return;
+    const fx::Instr& I = h->prog.instrs[i];
+    o[0] = I.op; o[1] = I.r; o[2] = I.a; o[3] = I.x; o[4] = I.y; o[5] = I.hasInput; o[6] = I.hasOutput; o[7] = I.hasNoise;
+}
+int fxp_itram_size(fxp_handle* h) { return h ? h->prog.iTramSize : 0; }
+int fxp_xtram_size(fxp_handle* h) { return h ? h->prog.xTramSize : 0; }
+int fxp_error_count(fxp_handle* h) { return h ? (int)h->prog.errors.size() : 0; }
+const char* fxp_error_desc(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.errors.size()) ? h->prog.errors[i].description.c_str() : ""; }
+int fxp_error_row(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.errors.size()) ? h->prog.errors[i].row : -1; }
+int fxp_control_count(fxp_handle* h) { return h ? (int)h->prog.controls.size() : 0; }
+const char* fxp_control_at(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.controls.size()) ? h->prog.controls[i].c_str() : ""; }
+int fxp_meta_get(fxp_handle* h, const char* key, char* buf, int buflen) {
+    if (!h || !key) return 0;
+    for (const auto& kv : h->prog.meta)
+        if (kv.first == key) { if (buf && buflen > 0) std::snprintf(buf, (size_t)buflen, "%s", kv.second.c_str()); return 1; }
+    return 0;
+}
+int fxp_ready(fxp_handle* h) { return (h && h->prog.ready) ? 1 : 0; }
+const double* fxp_lut(int kind, int exponent) {
+    static const fx::Luts luts;
+    return kind ? luts.exp_[exponent & 31] : luts.log_[exponent & 31];
+}
+int fxp_lower(fxp_handle* h) {
+    if (!h) return FX_E_ARG;
+    if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
+    std::vector<float> values(h->prog.regs.size());
+    for (size_t r = 0; r < values.size(); ++r) values[r] = h->prog.regs[r].value;
+    h->low = fx::lowerProgram(h->prog, values, std::vector<uint8_t>(values.size(), 0));
+    h->lowered = h->low.error.empty();
+    h->err = h->low.error;
+    return h->lowered ? 0 : FX_E_PROGRAM;
+}
+int64_t fxp_lower_info(fxp_handle* h, int what) {
+    if (!h || !h->lowered) return -1;
+    switch (what) {
+        case FXB_INFO_NUM_INSTRUCTIONS: return (int64_t)h->prog.instrs.size();
+        case FXB_INFO_NUM_REGISTERS: return (int64_t)h->prog.regs.size();
+        case FXB_INFO_NUM_LANE_REGS: return h->low.nLaneRegs;
+        case FXB_INFO_NUM_UNIFORM_REGS: return h->low.nUniformRegs;
+        case FXB_INFO_LDS_BYTES_PER_WG: return (int64_t)h->low.nRows * 256;
+        case FXB_INFO_NUM_MICROOPS: return (int64_t)h->low.steady.size();
+        case FXB_INFO_ITRAM_SLOTS: return h->low.iSlots;
+        case FXB_INFO_XTRAM_SLOTS: return h->low.xSlots;
+        case FXB_INFO_TRAM_OPS: return h->low.tramOpsPerSample;
+        case FXB_INFO_MULTIPASS: return h->low.multipass ? 1 : 0;
+        case FXB_INFO_NUM_SHADOWED: return h->low.nShadowed;
+        case FXB_INFO_NUM_CCR_LIVE: return h->low.nCcrLive;
+        default: return -1;
+    }
+}
+const char* fxp_last_error(fxp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+}  // extern "C"

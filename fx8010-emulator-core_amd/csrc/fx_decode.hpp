@@ -1,0 +1,99 @@
+// fx_decode.hpp — lowering of a parsed program to the device opcode stream.
+//
+// The interpreter kernel steps one host-decoded stream for all instances (lanes).  The
+// decoder's job is to take everything that is the same for every instance out of the
+// per-lane work:
+//   * registers no instruction can write (literals, controls, untouched statics) are
+//     UNIFORM: their current value is folded into the stream as an immediate;
+//   * registers that can differ per instance get a row in the per-wave LDS register file
+//     (row r, lane l at byte r*256 + l*4);
+//   * INPUT registers are aliased onto the per-sample input row of their channel whenever
+//     that is provably identical to the reference's refresh-on-use (FX8010.cpp:1053-1061);
+//   * CCR (register 0) is an ordinary row that is only materialised by instructions whose
+//     CCR write can be observed (liveness over SKIP shadows);
+//   * instructions that can sit in the shadow of a SKIP are flagged, everything else runs
+//     without per-lane predication.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fx_model.hpp"
+
+namespace fx {
+
+// One record of the device stream: 8 dwords, fetched with a single scalar load.
+//   w0  handler id [7:0] | flags [31:8]
+//   w1  R row byte offset [15:0] | A row byte offset [31:16]
+//   w2  X row byte offset [15:0] | Y row byte offset [31:16]
+//   w3  extra0 (LUT table index, ...)
+//   w4  immediate A   w5 immediate X   w6 immediate Y   (IEEE bits, when the U* flag is set)
+//   w7  extra1
+struct MicroOp {
+    uint32_t w[8];
+};
+
+enum Handler : uint32_t {
+    H_END = 0, H_NOP, H_MACS, H_MACSN, H_ACC3, H_INTERP, H_MACW, H_MACWN, H_MACINTW, H_MACMV,
+    H_ANDXOR, H_TSTNEG, H_LIMIT, H_LIMITN, H_LOG, H_EXP, H_SKIP,
+    H_TRAM_IR, H_TRAM_IW, H_TRAM_XR, H_TRAM_XW, H_REFRESH, H_NOISE, H_LATCH,
+    H_COUNT_
+};
+
+enum : uint32_t {
+    F_SHADOW = 1u << 8,    // may be inside a SKIP shadow: run under the per-lane skip predicate
+    F_CCR = 1u << 9,       // materialise CCR
+    F_UA = 1u << 10,       // operand A is the immediate w4
+    F_UX = 1u << 11,
+    F_UY = 1u << 12,
+    F_PREFIX = 1u << 13,   // helper op ahead of its instruction (same predicate, no skip countdown)
+    F_POSTFIX = 1u << 14,  // helper op behind its instruction (runs where the instruction ran)
+    F_COUNT = 1u << 15,    // a reference instruction (counts towards getInstructionCounter)
+    F_STATIC_OOD = 1u << 16  // decoder already knows this op leaves the parity domain
+};
+
+// state rows (32-bit words per instance) in the device state block, after the register rows
+struct StateLayout {
+    int nRegs = 0;      // rows [0, nRegs): register values
+    int outBase = 0;    // rows [outBase, outBase+channels): output latches (reference outputBuffer)
+    int cursorBase = 0; // +0 iTRAM write, +1 iTRAM read, +2 xTRAM write, +3 xTRAM read
+    int noiseBase = 0;  // +0 g_x1, +1 g_x2
+    int oodRow = 0;     // sticky out-of-domain flags
+    int countLo = 0, countHi = 0;  // executed-instruction counter (64-bit)
+    int totalRows = 0;
+};
+
+struct RowCopy {
+    uint16_t ldsRow;
+    uint16_t stateRow;
+};
+
+struct Lowered {
+    std::vector<MicroOp> steady;  // samples 0 .. S-2
+    std::vector<MicroOp> last;    // final sample of a block: every CCR write materialised
+    std::vector<RowCopy> loadRows;   // prologue: LDS row <- state row
+    std::vector<RowCopy> storeRows;  // epilogue: state row <- LDS row
+    std::vector<int> rowOfReg;       // LDS row of a register, -1 if uniform
+    std::vector<int> inRow;          // per channel: LDS row of the input sample, -1 if unused
+    std::vector<int> latchRow;       // per channel: LDS row of the output latch
+    StateLayout layout;
+    int nRows = 0;
+    int nLaneRegs = 0, nUniformRegs = 0;
+    int staticCount = 0;   // unshadowed reference instructions per sample
+    int nShadowed = 0, nCcrLive = 0;
+    int tramOpsPerSample = 0;
+    bool multipass = false;
+    bool usesNoise = false, usesITram = false, usesXTram = false, usesLut = false;
+    int iSlots = 0, xSlots = 0;  // TRAM slots to allocate per instance
+    std::string error;            // non-empty: cannot be lowered
+};
+
+// forcedLane[r] != 0 keeps register r per-instance even if no instruction writes it
+// (set after fxb_set_register_i gave instances different values).
+Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue,
+                     const std::vector<uint8_t>& forcedLane);
+
+StateLayout makeLayout(int nRegs, int channels);
+
+}  // namespace fx

@@ -1,0 +1,86 @@
+// fx_model.hpp — host-side program model and front-end of the MI355X batch FX8010 interpreter.
+//
+// The model mirrors what the reference's loader leaves behind for its hot loop
+// (reference: include/FX8010.h:79-100 Opcode, :127-142 RegisterType, :167-174 GPR,
+// :180-191 Instruction).  Register INDEX ORDER is part of the contract: instructions
+// address registers by index, and indices are handed out in order of first appearance
+// (4 specials, then declarations and numeric literals as encountered).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace fx {
+
+enum Opcode : int {
+    MACS = 0x0, MACSN = 0x1, MACW = 0x2, MACWN = 0x3, MACINTS = 0x4, MACINTW = 0x5, ACC3 = 0x6,
+    MACMV = 0x7, ANDXOR = 0x8, TSTNEG = 0x9, LIMIT = 0xa, LIMITN = 0xb, LOG = 0xc, EXP = 0xd,
+    INTERP = 0xe, SKIP = 0xf, IDELAY = 0x10, XDELAY = 0x11, END = 0x12
+};
+
+enum RegType : int {
+    R_STATIC = 0, R_TEMP, R_CONTROL, R_INPUT, R_OUTPUT, R_CONST, R_ITRAMSIZE, R_XTRAMSIZE,
+    R_READ, R_WRITE, R_AT, R_CCR
+};
+
+constexpr int kMaxITram = 8192;     // reference MAX_IDELAY_SIZE, include/FX8010.h:41
+constexpr int kMaxXTram = 1048576;  // reference MAX_XDELAY_SIZE, include/FX8010.h:42
+
+struct Gpr {
+    int type = R_STATIC;
+    std::string name;
+    float value = 0.0f;  // initial / host-side value
+    int io = 0;          // channel for INPUT/OUTPUT registers
+};
+
+struct Instr {
+    int op = 0, r = 0, a = 0, x = 0, y = 0;
+    bool hasInput = false, hasOutput = false, hasNoise = false;
+};
+
+struct LoadError {
+    std::string description;
+    int row = 1;
+};
+
+// Front-end state of one program.  loadFile()/loadText() may be called more than once on
+// the same object; like the reference (which never clears its vectors) state accumulates.
+class Program {
+public:
+    explicit Program(int numChannels);
+
+    bool loadFile(const std::string& path);  // reference loadFile, source/FX8010.cpp:777-875
+    bool loadText(const std::string& text);  // same pipeline from memory
+
+    int findRegister(const std::string& name) const;  // -1 if absent
+
+    int numChannels;
+    std::vector<Gpr> regs;
+    std::vector<Instr> instrs;
+    std::vector<LoadError> errors;  // [0] is always {"Kein Fehler", 1}
+    std::vector<std::string> controls;
+    std::vector<std::pair<std::string, std::string>> meta;
+    int iTramSize = 0, xTramSize = 0;
+    bool ready = false;
+    bool sawUnparsable = false;  // input on which the reference itself throws (stoi/stof)
+
+private:
+    bool finishLoad(const std::vector<std::string>& lines);
+    void checkLine(const std::string& line);
+    int resolveOperand(const std::string& token);
+    void addError(const std::string& what);
+    int lineNo_ = 1;  // reference errorCounter, include/FX8010.h:273
+};
+
+// LOG/EXP tables exactly as the reference builds them at construction
+// (source/FX8010.cpp:63-105,129-199): 32 exponents x 64 doubles each, host libm pow.
+// Entry [64] duplicates [63] so that the x == 1.0 read of [idx+1] stays finite.
+struct Luts {
+    double log_[32][65];
+    double exp_[32][65];
+    Luts();
+};
+
+}  // namespace fx

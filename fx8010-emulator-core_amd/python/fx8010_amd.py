@@ -1,0 +1,296 @@
+"""ctypes binding of libfx8010_amd.so (the C ABI in include/fx8010_amd.h).
+
+Used by tests/, bench.py and __graft_entry__.py.  It only marshals arguments: every computation
+happens in the HIP kernel behind the C ABI.  There is no fallback — if the library is missing
+``load()`` raises, and if no GPU is usable ``Batch(...)`` raises with the library's own message.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "libfx8010_amd.so")
+
+_f32p = C.POINTER(C.c_float)
+_lib = None
+
+# selectors of fxb_info / fxp_lower_info
+INFO = {
+    "num_instructions": 0, "num_registers": 1, "num_lane_regs": 2, "num_uniform_regs": 3, "lds_bytes_per_wg": 4,
+    "waves_per_wg": 5, "num_microops": 6, "itram_slots": 7, "xtram_slots": 8, "tram_ops": 9, "multipass": 10,
+    "num_shadowed": 11, "num_ccr_live": 12, "device": 13, "grid": 14, "inst_per_lane": 15,
+}
+
+# every symbol include/fx8010_amd.h declares (tests check that the library exports them all)
+SYMBOLS = [
+    "fx_create", "fx_destroy", "fx_load_file", "fx_process", "fx_process_block", "fx_set_register", "fx_get_register",
+    "fx_instruction_counter", "fx_error_count", "fx_error_desc", "fx_error_row", "fx_control_count", "fx_control_at",
+    "fx_meta_get", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
+    "fxb_create", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
+    "fxb_get_register_i", "fxb_seed_noise_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
+    "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
+    "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error",
+    "fxb_last_kernel_ms", "fxb_info", "fxb_device_count", "fxb_version",
+    "fxp_create", "fxp_destroy", "fxp_load_file", "fxp_load_text", "fxp_num_registers", "fxp_register_name",
+    "fxp_register_type", "fxp_register_ioindex", "fxp_register_value", "fxp_num_instructions", "fxp_instruction",
+    "fxp_itram_size", "fxp_xtram_size", "fxp_error_count", "fxp_error_desc", "fxp_error_row", "fxp_control_count",
+    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_last_error",
+]
+
+
+def load():
+    """dlopen the in-tree library and declare the prototypes; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.abspath(LIB_PATH)
+    if not os.path.exists(path):
+        raise RuntimeError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C fx8010-emulator-core_amd/csrc`" % path)
+    lib = C.CDLL(path)
+    vp, cp, i32, i64, f32 = C.c_void_p, C.c_char_p, C.c_int, C.c_int64, C.c_float
+
+    def sig(name, res, *args):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("fx_create", vp, i32); sig("fx_destroy", None, vp); sig("fx_load_file", i32, vp, cp)
+    sig("fx_process", i32, vp, _f32p, _f32p); sig("fx_process_block", i32, vp, _f32p, _f32p, i32)
+    sig("fx_set_register", i32, vp, cp, f32); sig("fx_get_register", f32, vp, cp)
+    sig("fx_instruction_counter", i64, vp)
+    sig("fx_set_channels", None, vp, i32); sig("fx_get_channels", i32, vp); sig("fx_ready", i32, vp)
+    sig("fx_last_error", cp, vp); sig("fx_last_create_error", cp)
+    sig("fxb_create", vp, i64, i32, i32); sig("fxb_destroy", None, vp)
+    sig("fxb_load_file", i32, vp, cp); sig("fxb_load_text", i32, vp, cp)
+    sig("fxb_set_register", i32, vp, cp, f32); sig("fxb_set_register_i", i32, vp, cp, i64, f32)
+    sig("fxb_get_register_i", f32, vp, cp, i64); sig("fxb_seed_noise_i", i32, vp, i64, C.c_int32, C.c_int32)
+    sig("fxb_process_block", i32, vp, _f32p, _f32p, i32)
+    sig("fxb_process_block_dev", i32, vp, vp, vp, i32, vp); sig("fxb_sync", i32, vp)
+    sig("fxb_instruction_counter", i64, vp); sig("fxb_instruction_counter_i", i64, vp, i64)
+    sig("fxb_ood_flags", C.c_uint32, vp); sig("fxb_ready", i32, vp); sig("fxb_last_error", cp, vp)
+    sig("fxb_last_kernel_ms", f32, vp); sig("fxb_info", i64, vp, i32)
+    sig("fxb_device_count", i32); sig("fxb_version", cp)
+    for pfx in ("fx_", "fxb_", "fxp_"):
+        sig(pfx + "error_count", i32, vp); sig(pfx + "error_desc", cp, vp, i32); sig(pfx + "error_row", i32, vp, i32)
+        sig(pfx + "control_count", i32, vp); sig(pfx + "control_at", cp, vp, i32)
+        sig(pfx + "meta_get", i32, vp, cp, cp, i32)
+    sig("fxp_create", vp, i32); sig("fxp_destroy", None, vp); sig("fxp_load_file", i32, vp, cp); sig("fxp_load_text", i32, vp, cp)
+    sig("fxp_num_registers", i32, vp); sig("fxp_register_name", cp, vp, i32); sig("fxp_register_type", i32, vp, i32)
+    sig("fxp_register_ioindex", i32, vp, i32); sig("fxp_register_value", f32, vp, i32)
+    sig("fxp_num_instructions", i32, vp); sig("fxp_instruction", None, vp, i32, C.POINTER(C.c_int))
+    sig("fxp_itram_size", i32, vp); sig("fxp_xtram_size", i32, vp); sig("fxp_ready", i32, vp)
+    sig("fxp_lut", C.POINTER(C.c_double), i32, i32); sig("fxp_lower", i32, vp); sig("fxp_lower_info", i64, vp, i32)
+    sig("fxp_last_error", cp, vp)
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load().fxb_device_count())
+
+
+class _Reports:
+    """error list / control list / metadata accessors shared by the three handle kinds"""
+    _pfx = ""
+
+    def _call(self, name, *a):
+        return getattr(self._lib, self._pfx + name)(self._h, *a)
+
+    def errors(self):
+        return [(self._call("error_desc", i).decode("latin-1"), self._call("error_row", i)) for i in range(self._call("error_count"))]
+
+    def controls(self):
+        return [self._call("control_at", i).decode("latin-1") for i in range(self._call("control_count"))]
+
+    def meta(self):
+        out = {}
+        buf = C.create_string_buffer(1024)
+        for k in ("name", "copyright", "created", "engine", "comment", "guid"):
+            if self._call("meta_get", k.encode(), buf, 1024):
+                out[k] = buf.value.decode("latin-1")
+        return out
+
+    def ready(self):
+        return bool(self._call("ready"))
+
+
+class FrontEnd(_Reports):
+    """Host-only loader + lowering (fxp_*): no GPU needed."""
+    _pfx = "fxp_"
+
+    def __init__(self, channels=1):
+        self._lib = load()
+        self._h = self._lib.fxp_create(channels)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fxp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load_text(self, text):
+        return bool(self._lib.fxp_load_text(self._h, text.encode() if isinstance(text, str) else text))
+
+    def load_file(self, path):
+        return bool(self._lib.fxp_load_file(self._h, path.encode()))
+
+    def registers(self):
+        n = self._lib.fxp_num_registers(self._h)
+        return [(self._lib.fxp_register_name(self._h, i).decode("latin-1"), self._lib.fxp_register_type(self._h, i),
+                 self._lib.fxp_register_ioindex(self._h, i),
+                 int(np.float32(self._lib.fxp_register_value(self._h, i)).view(np.uint32))) for i in range(n)]
+
+    def instructions(self):
+        buf = (C.c_int * 8)()
+        out = []
+        for i in range(self._lib.fxp_num_instructions(self._h)):
+            self._lib.fxp_instruction(self._h, i, buf)
+            out.append(tuple(buf))
+        return out
+
+    def tram_sizes(self):
+        return self._lib.fxp_itram_size(self._h), self._lib.fxp_xtram_size(self._h)
+
+    def lower(self):
+        return int(self._lib.fxp_lower(self._h))
+
+    def lower_info(self, what):
+        return int(self._lib.fxp_lower_info(self._h, INFO[what]))
+
+    def last_error(self):
+        return self._lib.fxp_last_error(self._h).decode("latin-1")
+
+    @staticmethod
+    def lut(kind, exponent):
+        p = load().fxp_lut(kind, exponent)
+        return np.ctypeslib.as_array(p, shape=(64,)).copy()
+
+
+class Batch(_Reports):
+    """N instances of one program on one GPU (fxb_*)."""
+    _pfx = "fxb_"
+
+    def __init__(self, n_instances, channels=1, device=-1):
+        self._lib = load()
+        self.n = int(n_instances)
+        self.channels = channels
+        self._h = self._lib.fxb_create(self.n, channels, device)
+        if not self._h:
+            raise RuntimeError("fxb_create failed: " + self._lib.fx_last_create_error().decode("latin-1"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fxb_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self._lib.fxb_last_error(self._h).decode("latin-1")))
+        return rc
+
+    def load_text(self, text):
+        return bool(self._lib.fxb_load_text(self._h, text.encode() if isinstance(text, str) else text))
+
+    def load_file(self, path):
+        return bool(self._lib.fxb_load_file(self._h, path.encode()))
+
+    def set_register(self, key, v):
+        return self._check(self._lib.fxb_set_register(self._h, key.encode(), C.c_float(v)), "set_register")
+
+    def set_register_i(self, key, inst, v):
+        return self._check(self._lib.fxb_set_register_i(self._h, key.encode(), inst, C.c_float(v)), "set_register_i")
+
+    def get_register_i(self, key, inst):
+        return float(self._lib.fxb_get_register_i(self._h, key.encode(), inst))
+
+    def get_register_bits_i(self, key, inst):
+        return int(np.float32(self.get_register_i(key, inst)).view(np.uint32))
+
+    def seed_noise_i(self, inst, x1, x2):
+        return self._check(self._lib.fxb_seed_noise_i(self._h, inst, x1, x2), "seed_noise_i")
+
+    def process_block(self, x):
+        """x: float32 [S, N] (mono) or [S, channels, N]; returns the same shape."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        S = x.shape[0]
+        assert x.size == S * self.channels * self.n, "input must be [S, channels, N]"
+        out = np.empty_like(x)
+        self._check(self._lib.fxb_process_block(self._h, x.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p), S), "process_block")
+        return out
+
+    def process_block_dev(self, d_in, d_out, n_samples, stream=None):
+        """device pointers (ints); asynchronous."""
+        return self._check(self._lib.fxb_process_block_dev(self._h, C.c_void_p(d_in), C.c_void_p(d_out), n_samples, C.c_void_p(stream or 0)), "process_block_dev")
+
+    def sync(self):
+        return self._check(self._lib.fxb_sync(self._h), "sync")
+
+    def instruction_counter(self):
+        return int(self._lib.fxb_instruction_counter(self._h))
+
+    def instruction_counter_i(self, inst):
+        return int(self._lib.fxb_instruction_counter_i(self._h, inst))
+
+    def ood_flags(self):
+        return int(self._lib.fxb_ood_flags(self._h))
+
+    def last_kernel_ms(self):
+        return float(self._lib.fxb_last_kernel_ms(self._h))
+
+    def info(self, what):
+        return int(self._lib.fxb_info(self._h, INFO[what]))
+
+    def last_error(self):
+        return self._lib.fxb_last_error(self._h).decode("latin-1")
+
+
+class Single(_Reports):
+    """One emulated DSP with the reference's call-per-sample surface (fx_*)."""
+    _pfx = "fx_"
+
+    def __init__(self, channels=1):
+        self._lib = load()
+        self.channels = channels
+        self._h = self._lib.fx_create(channels)
+        if not self._h:
+            raise RuntimeError("fx_create failed: " + self._lib.fx_last_create_error().decode("latin-1"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load_file(self, path):
+        return bool(self._lib.fx_load_file(self._h, path.encode()))
+
+    def process(self, sample):
+        x = np.ascontiguousarray(sample, dtype=np.float32).reshape(self.channels)
+        out = np.empty_like(x)
+        rc = self._lib.fx_process(self._h, x.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p))
+        if rc < 0:
+            raise RuntimeError("fx_process failed: " + self._lib.fx_last_error(self._h).decode("latin-1"))
+        return out
+
+    def process_block(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        rc = self._lib.fx_process_block(self._h, x.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p), x.size // self.channels)
+        if rc < 0:
+            raise RuntimeError("fx_process_block failed: " + self._lib.fx_last_error(self._h).decode("latin-1"))
+        return out
+
+    def set_register(self, key, v):
+        return int(self._lib.fx_set_register(self._h, key.encode(), C.c_float(v)))
+
+    def get_register(self, key):
+        return float(self._lib.fx_get_register(self._h, key.encode()))
+
+    def instruction_counter(self):
+        return int(self._lib.fx_instruction_counter(self._h))

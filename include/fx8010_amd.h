@@ -1,0 +1,192 @@
+/* fx8010_amd.h — C ABI of the MI355X-native batch FX8010 interpreter (libfx8010_amd.so).
+ *
+ * This is the drop-in boundary for the one hot path this project accelerates: the
+ * per-sample instruction loop Klangraum::FX8010::process() of easypx/FX8010-Emulator-Core
+ * (reference: source/FX8010.cpp:1023-1249), together with the cold front-end it needs
+ * (loadFile, the by-name register API).  The reference has no FFI of its own — its boundary
+ * is the public surface of class Klangraum::FX8010 (include/FX8010.h:47-75) — so every entry
+ * point below names the class member it replaces.  A header-only C++ class with the
+ * reference's exact member names sits on top of this ABI:
+ *   fx8010-emulator-core_amd/host/FX8010.h.
+ *
+ * Two families:
+ *   fx_*   one emulated DSP, same call-per-sample convention as the reference class;
+ *   fxb_*  N independent DSPs stepping one program in SIMT lockstep on one GPU
+ *          ("batch"); fxb_process_block(S) ≡ calling process() S times on each of N objects.
+ *
+ * All compute runs in a hand-written HIP kernel on gfx950.  There is NO CPU fallback:
+ * when no HIP device is usable, fx_create/fxb_create return NULL and fx_last_create_error()
+ * says why; a failed launch returns a negative code and fxb_last_error() the text.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer it passes; the
+ * library owns the handle and all device state; a handle is not thread-safe, distinct
+ * handles are independent.  Return codes: the reference's own where one exists (noted per
+ * function), otherwise 0 = ok and <0 = FX_E_*.
+ */
+#ifndef FX8010_AMD_H
+#define FX8010_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_E_NODEVICE (-1) /* no usable HIP device / HIP call failed          */
+#define FX_E_NOTREADY (-2) /* no program loaded (reference: getReadyStatus()) */
+#define FX_E_ARG (-3)      /* bad argument                                    */
+#define FX_E_PROGRAM (-4)  /* program cannot be lowered for the device (see fxb_last_error) */
+#define FX_E_MEMORY (-5)   /* device allocation failed                        */
+
+typedef struct fx_handle fx_handle;   /* one emulated DSP  */
+typedef struct fxb_handle fxb_handle; /* a batch of N DSPs */
+
+/* ------------------------------------------------------------------ single instance
+ * Mirrors Klangraum::FX8010 one to one (batch of 1 on the current HIP device). */
+
+/* FX8010::FX8010(int numChannels)            include/FX8010.h:51, source/FX8010.cpp:9-12 */
+fx_handle* fx_create(int num_channels);
+/* FX8010::~FX8010()                          include/FX8010.h:52 */
+void fx_destroy(fx_handle* h);
+/* bool loadFile(const string& path)          include/FX8010.h:62, source/FX8010.cpp:777-875
+ * returns 1 = loaded, 0 = open failure or syntax errors (see fx_error_*). */
+int fx_load_file(fx_handle* h, const char* path);
+/* vector<float> process(const vector<float>&) include/FX8010.h:57, source/FX8010.cpp:1023-1249
+ * in[num_channels] -> out[num_channels], one sample period.  0 or FX_E_*. */
+int fx_process(fx_handle* h, const float* in, float* out);
+/* S consecutive process() calls in one launch; in/out are [S][num_channels]. */
+int fx_process_block(fx_handle* h, const float* in, float* out, int n_samples);
+/* int setRegisterValue(const string&, float)  source/FX8010.cpp:236-253: 0 = found, 1 = not found */
+int fx_set_register(fx_handle* h, const char* key, float value);
+/* float getRegisterValue(const string&)       source/FX8010.cpp:256-266: 1.0f when not found */
+float fx_get_register(fx_handle* h, const char* key);
+/* int getInstructionCounter()                 source/FX8010.cpp:986-989 (64-bit here) */
+int64_t fx_instruction_counter(fx_handle* h);
+/* vector<MyError> getErrorList()              include/FX8010.h:63-68, source/FX8010.cpp:894-897
+ * entry 0 is always {"Kein Fehler", 1}. */
+int fx_error_count(fx_handle* h);
+const char* fx_error_desc(fx_handle* h, int i);
+int fx_error_row(fx_handle* h, int i);
+/* vector<string> getControlRegisters()        source/FX8010.cpp:201-204 */
+int fx_control_count(fx_handle* h);
+const char* fx_control_at(fx_handle* h, int i);
+/* unordered_map<string,string> getMetaData()  source/FX8010.cpp:1003-1006
+ * keys name, copyright, created, engine, comment, guid; 1 = present, 0 = absent */
+int fx_meta_get(fx_handle* h, const char* key, char* buf, int buflen);
+/* setChannels / getChannels / getReadyStatus  include/FX8010.h:73-75 */
+void fx_set_channels(fx_handle* h, int num_channels);
+int fx_get_channels(fx_handle* h);
+int fx_ready(fx_handle* h);
+const char* fx_last_error(fx_handle* h);
+/* why the last fx_create / fxb_create returned NULL (thread-local string) */
+const char* fx_last_create_error(void);
+
+/* ------------------------------------------------------------------ batch (the GPU path)
+ * N independent instances of one program; instance n of sample s, channel c lives at
+ * buf[(s * num_channels + c) * N + n]  — instance-fastest, so a wavefront (64 consecutive
+ * instances) reads and writes 256 contiguous bytes. */
+
+/* device: HIP ordinal, or -1 for the calling thread's current device. */
+fxb_handle* fxb_create(int64_t n_instances, int num_channels, int device);
+void fxb_destroy(fxb_handle* h);
+/* as fx_load_file; the program is parsed once on the host and lowered to the device
+ * opcode stream.  fxb_load_text takes the program text itself. */
+int fxb_load_file(fxb_handle* h, const char* path);
+int fxb_load_text(fxb_handle* h, const char* text);
+/* setRegisterValue on every instance / on one instance (0 found, 1 not found, <0 FX_E_*) */
+int fxb_set_register(fxb_handle* h, const char* key, float value);
+int fxb_set_register_i(fxb_handle* h, const char* key, int64_t instance, float value);
+/* getRegisterValue of one instance (1.0f when not found) */
+float fxb_get_register_i(fxb_handle* h, const char* key, int64_t instance);
+/* white-noise generator seeds of one instance (reference: g_x1/g_x2, include/FX8010.h:290-291;
+ * every instance starts with the reference's seeds) */
+int fxb_seed_noise_i(fxb_handle* h, int64_t instance, int32_t x1, int32_t x2);
+/* S sample periods for all N instances.  Host buffers: synchronous (H2D, kernel, D2H). */
+int fxb_process_block(fxb_handle* h, const float* in, float* out, int n_samples);
+/* Same with device-resident buffers (hipMalloc'ed, on h's device); asynchronous on `stream`
+ * (a hipStream_t, NULL = the handle's own stream).  Pair with fxb_sync(). */
+int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n_samples, void* stream);
+int fxb_sync(fxb_handle* h);
+/* executed instructions (reference counting: END and SKIP count, skipped ones do not):
+ * summed over all instances / of one instance */
+int64_t fxb_instruction_counter(fxb_handle* h);
+int64_t fxb_instruction_counter_i(fxb_handle* h, int64_t instance);
+/* OR of the per-instance "outside the parity domain" flags (0 = the whole batch stayed
+ * inside the domain where the reference's behaviour is defined) */
+uint32_t fxb_ood_flags(fxb_handle* h);
+/* front-end results, as fx_* */
+int fxb_error_count(fxb_handle* h);
+const char* fxb_error_desc(fxb_handle* h, int i);
+int fxb_error_row(fxb_handle* h, int i);
+int fxb_control_count(fxb_handle* h);
+const char* fxb_control_at(fxb_handle* h, int i);
+int fxb_meta_get(fxb_handle* h, const char* key, char* buf, int buflen);
+int fxb_ready(fxb_handle* h);
+const char* fxb_last_error(fxb_handle* h);
+/* HIP-event duration (ms) of the most recent interpreter-kernel launch, measured on the
+ * stream it ran on; <0 if none.  Implies a sync on that stream. */
+float fxb_last_kernel_ms(fxb_handle* h);
+
+/* introspection of the lowered program (what the kernel actually runs) */
+enum {
+    FXB_INFO_NUM_INSTRUCTIONS = 0, /* reference instruction count, END included           */
+    FXB_INFO_NUM_REGISTERS = 1,    /* reference register count                            */
+    FXB_INFO_NUM_LANE_REGS = 2,    /* registers kept per instance (LDS rows)              */
+    FXB_INFO_NUM_UNIFORM_REGS = 3, /* registers folded into the opcode stream             */
+    FXB_INFO_LDS_BYTES_PER_WG = 4,
+    FXB_INFO_WAVES_PER_WG = 5,
+    FXB_INFO_NUM_MICROOPS = 6,     /* records in the device opcode stream                 */
+    FXB_INFO_ITRAM_SLOTS = 7,      /* allocated slots per instance                        */
+    FXB_INFO_XTRAM_SLOTS = 8,
+    FXB_INFO_TRAM_OPS = 9,         /* delay reads+writes per sample (static)              */
+    FXB_INFO_MULTIPASS = 10,       /* 1 if END can be skipped (generic pass loop in use)  */
+    FXB_INFO_NUM_SHADOWED = 11,    /* instructions that can sit in a SKIP shadow          */
+    FXB_INFO_NUM_CCR_LIVE = 12,    /* instructions whose CCR write is observable          */
+    FXB_INFO_DEVICE = 13,
+    FXB_INFO_GRID = 14,            /* workgroups of the last launch                       */
+    FXB_INFO_INST_PER_LANE = 15    /* instances one lane steps (kernel variant)           */
+};
+int64_t fxb_info(fxb_handle* h, int what);
+
+
+/* ------------------------------------------------------------------ front-end only (no device)
+ * The host-side loader and lowering, usable without a GPU: what the .da text became.
+ * Mirrors the reference's private model (include/FX8010.h:167-194) for inspection and tests. */
+typedef struct fxp_handle fxp_handle;
+fxp_handle* fxp_create(int num_channels);
+void fxp_destroy(fxp_handle* h);
+int fxp_load_file(fxp_handle* h, const char* path);
+int fxp_load_text(fxp_handle* h, const char* text);
+int fxp_num_registers(fxp_handle* h);
+const char* fxp_register_name(fxp_handle* h, int i);
+int fxp_register_type(fxp_handle* h, int i);    /* reference RegisterType numbering */
+int fxp_register_ioindex(fxp_handle* h, int i);
+float fxp_register_value(fxp_handle* h, int i);
+int fxp_num_instructions(fxp_handle* h);
+/* out8 = opcode (reference Opcode numbering), R, A, X, Y, hasInput, hasOutput, hasNoise */
+void fxp_instruction(fxp_handle* h, int i, int out8[8]);
+int fxp_itram_size(fxp_handle* h);
+int fxp_xtram_size(fxp_handle* h);
+int fxp_error_count(fxp_handle* h);
+const char* fxp_error_desc(fxp_handle* h, int i);
+int fxp_error_row(fxp_handle* h, int i);
+int fxp_control_count(fxp_handle* h);
+const char* fxp_control_at(fxp_handle* h, int i);
+int fxp_meta_get(fxp_handle* h, const char* key, char* buf, int buflen);
+int fxp_ready(fxp_handle* h);
+/* LOG (kind 0) / EXP (kind 1) table of one exponent: 64 doubles (reference FX8010.cpp:63-105) */
+const double* fxp_lut(int kind, int exponent);
+/* lower for the device with the registers' initial values; 0 or FX_E_PROGRAM.  fxp_lower_info
+ * takes the FXB_INFO_* selectors that describe the lowering. */
+int fxp_lower(fxp_handle* h);
+int64_t fxp_lower_info(fxp_handle* h, int what);
+const char* fxp_last_error(fxp_handle* h);
+
+/* library / device probe: number of HIP devices visible (0 if none), never throws */
+int fxb_device_count(void);
+const char* fxb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FX8010_AMD_H */

@@ -1,0 +1,248 @@
+"""GPU parity: the HIP interpreter (through the C ABI) against the CPU oracle, bit for bit.
+
+Every test drives libfx8010_amd.so exactly as a user would (load .da text, process blocks,
+read registers / counters) and compares with oracle/ (the C restatement of the reference,
+itself pinned by tests/golden).  Bar: bit-exact outputs, registers and instruction counts.
+"""
+import numpy as np
+import pytest
+
+import fx8010_programs as progs
+from pyoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+HDR = "static a\nstatic b\ninput in 0\noutput out 0\nstatic noise\nstatic rd\ncontrol vol = 0.5\n"
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def oracle_run(text, x, channels=1, pre=None, regs=()):
+    """x: [S] or [S, channels] for ONE instance -> (out, counter, {reg: bits}, ood)"""
+    o = Oracle(channels)
+    assert o.load_text(text), o.errors()
+    if pre:
+        pre(o)
+    y = o.process_block(x)
+    return y, o.instruction_counter(), {r: o.get_register_bits(r) for r in regs}, o.ood_flags()
+
+
+def check_batch(gpu, text, x, regs=("ccr",), channels=1, instances=None, blocks=1, expect_ood=0):
+    """x: [S, N] (mono) or [S, channels, N]."""
+    S = x.shape[0]
+    N = x.shape[-1]
+    b = gpu.Batch(N, channels, 0)
+    assert b.load_text(text), b.errors()
+    if blocks == 1:
+        y = b.process_block(x)
+    else:
+        cuts = np.linspace(0, S, blocks + 1).astype(int)
+        y = np.concatenate([b.process_block(x[cuts[i]:cuts[i + 1]]) for i in range(blocks) if cuts[i + 1] > cuts[i]], axis=0)
+    total = 0
+    for n in (range(N) if instances is None else instances):
+        xin = x[..., n] if channels == 1 else np.ascontiguousarray(x[:, :, n])
+        ref, cnt, rv, ood = oracle_run(text, xin, channels, regs=regs)
+        got = y[..., n] if channels == 1 else y[:, :, n]
+        bad = np.nonzero(bits(ref).reshape(-1) != bits(got).reshape(-1))[0]
+        assert bad.size == 0, "instance %d: first mismatch at flat sample %d: ref %08x got %08x" % (
+            n, bad[0], bits(ref).reshape(-1)[bad[0]], bits(got).reshape(-1)[bad[0]])
+        assert b.instruction_counter_i(n) == cnt, "instance %d instruction counter" % n
+        for r in regs:
+            assert b.get_register_bits_i(r, n) == rv[r], "instance %d register %s" % (n, r)
+        assert ood == expect_ood
+        total += cnt
+    if instances is None:
+        assert b.instruction_counter() == total
+    assert b.ood_flags() == expect_ood
+    return b, y
+
+
+@pytest.mark.parametrize("name", ["config1_shipped", "config1_logtube", "config2", "config3", "config4", "config5"])
+def test_config_programs_bit_exact(gpu, name):
+    text = progs.CONFIGS[name]()
+    N, S = 130, 257  # ragged last wavefront, odd block length
+    x = progs.stimulus(N, S)
+    regs = {"config2": ("t", "s30", "in", "out", "ccr"), "config3": ("rd", "a", "t", "ccr"), "config4": ("x", "a", "b", "o", "ccr"),
+            "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
+    check_batch(gpu, text, x, regs=regs)
+
+
+def test_block_boundaries_do_not_matter(gpu):
+    text = progs.config3()
+    x = progs.stimulus(70, 1200)  # > 1000-sample delay: the feedback path wraps
+    _, y1 = check_batch(gpu, text, x, instances=[0, 69], regs=("rd", "ccr"))
+    _, y7 = check_batch(gpu, text, x, instances=[0, 69], regs=("rd", "ccr"), blocks=7)
+    assert np.array_equal(bits(y1), bits(y7))
+
+
+OPCODE_PROGRAMS = {
+    "macs": "macs out, in, vol, 0.75",
+    "macsn": "macsn out, in, vol, 0.75",
+    "macints": "macints out, in, in, 2",
+    "acc3": "acc3 out, in, vol, 0.25",
+    "macw": "macw out, in, 1.5, 1.0",
+    "macwn": "macwn out, in, 1.5, in",
+    "macintw": "macintw out, in, 1.5, 1.0",
+    "macw_ccr_as_a": "macw out, ccr, 1.5, in",
+    "macmv": "macmv out, in, 0.5, 0.5",
+    "andxor_and": "macs a, 0, in, 100\nandxor out, a, 15, 0",
+    "andxor_xor": "macw a, 0, in, 100\nandxor out, a, 16777215, 5",
+    "andxor_generic": "macw a, 0, in, 100\nandxor out, a, 12, 3",
+    "andxor_literals": "andxor out, 7, 5, 2",
+    "tstneg": "tstneg out, in, 0.25, 0",
+    "tstneg_overflow": "tstneg out, in, 1.0, 0",
+    "limit": "limit out, in, 0.5, 0.25",
+    "limitn": "limitn out, in, 0.5, 0.25",
+    "log3": "log a, in, 3, 0\nmacs out, 0, a, 1.0",
+    "log0": "log a, in, 0, 0\nmacs out, 0, a, 1.0",
+    "log31": "log a, in, 31, 1\nmacs out, 0, a, 1.0",
+    "exp7": "exp a, in, 7, 0\nmacs out, 0, a, 1.0",
+    "exp0": "exp a, in, 0, 0\nmacs out, 0, a, 1.0",
+    "exp_unclamped_r": "exp out, in, 2, 0",
+    "interp": "interp out, out, 0.1, in",
+    "interp_literals": "interp out, -0.25, vol, 0.25",
+    "highpass": "interp a, a, 0.1, in\nmacsn out, in, a, 1",
+    "skip_neg": "macs a, in, 0, 0\nskip ccr, ccr, 6, 1\nmacs out, 0, in, 1.0",
+    "skip_zero": "macs a, in, 0, 0\nskip ccr, ccr, 8, 2\nmacs out, 0, in, 1.0\nmacs out, out, 0.5, 0.5",
+    "skip_sat": "macs a, in, in, 1.0\nskip ccr, ccr, 16, 1\nmacs out, 0, a, 0.5",
+    "skip_negative_count": "macs a, in, 0, 0\nskip ccr, ccr, 6, -3\nmacs out, 0, in, 1.0\nmacs b, out, 0.5, 0.5",
+    "skip_never": "macs a, in, 0, 0\nskip ccr, ccr, 384, 1\nmacs out, 0, in, 1.0",
+    "ccr_as_operand": "macs a, in, 0, 0\nmacs out, 0, ccr, 0.03125",
+    "noise": "macs out, 0, noise, 1.0",
+    "noise_twice": "macs a, 0, noise, 0.5\nmacs out, a, noise, 0.5",
+    "literal_as_r": "macs 0.5, in, 0.5, 0.5\nmacs out, 0, 0.5, 1.0",
+    "write_ccr_directly": "macs ccr, in, 0, 0\nmacs out, 0, ccr, 0.03125",
+    "out_read_back": "macs out, out, in, 0.1",
+    "idelay_nop_r": "idelay a, in, at, 0\nmacs out, 0, in, 1.0",
+    "latch_on_skip": "macs out, 0, in, 1.0\nmacs out, out, 0.5, 0.5\nskip out, ccr, 2, 0",
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPCODE_PROGRAMS))
+def test_opcode_programs(gpu, name):
+    text = HDR + OPCODE_PROGRAMS[name] + "\nend"
+    S, N = 48, 70
+    ramp = np.array([i / 16.0 for i in range(-16, 16)] + [1.0, -1.0, 0.0, -0.0, 1e-39, -1e-39, 0.999999, -0.999999] * 2, dtype=np.float32)
+    x = np.stack([np.roll(ramp, n) for n in range(N)], axis=1)  # [S, N], each instance a rotation
+    check_batch(gpu, text, x, regs=("a", "b", "out", "ccr", "in"))
+
+
+def test_delay_line_exact(gpu):
+    text = "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend"
+    x = progs.stimulus(66, 64)
+    check_batch(gpu, text, x, regs=("rd", "ccr"))
+    text = "xtramsize 37 \n" + HDR + "xdelay read, rd, at, 0\nmacs a, in, rd, 0.5\nxdelay write, a, at, 0\nxdelay read, b, at, 0\nxdelay write, in, at, 0\nmacs out, b, rd, 0.5\nend"
+    check_batch(gpu, text, x, regs=("rd", "b", "a"))
+
+
+def test_delay_write_offset_and_ood(gpu):
+    # write offset 3 stays inside the reference's array (wpos+3 < 8192) and lands beyond `size`
+    text = "itramsize 8 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 3\nmacs out, 0, rd, 1.0\nend"
+    x = progs.stimulus(64, 40)
+    check_batch(gpu, text, x, regs=("rd",))
+    # read offset 2 goes negative when the cursor is < 2: outside the parity domain, flagged
+    text = "itramsize 8 \n" + HDR + "idelay write, in, at, 0\nidelay read, rd, at, 2\nmacs out, 0, rd, 1.0\nend"
+    check_batch(gpu, text, x, regs=("rd",), expect_ood=1)
+
+
+def test_skip_over_end_multipass(gpu):
+    # the SKIP can jump over END: the reference re-runs the program with the leftover count
+    text = HDR + "macs a, in, 0, 0\nmacs out, out, 0.125, 0.5\nskip ccr, ccr, 6, 2\nmacs b, in, 0.5, 0.5\nend"
+    x = progs.stimulus(70, 50)
+    b, _ = check_batch(gpu, text, x, regs=("a", "b", "out", "ccr"))
+    assert b.info("multipass") == 1
+
+
+def test_stereo_and_input_channel_quirk(gpu):
+    # X and Y inputs are read through A's channel (source/FX8010.cpp:1058,1060)
+    text = ("input l 0\ninput r 1\noutput ol 0\noutput or 1\nstatic t\n"
+            "macs ol, l, r, 0.5\nmacs or, r, l, 0.5\nmacs t, 0, r, 1.0\nmacs or, or, t, 0.25\nend")
+    N, S = 70, 33
+    x = np.stack([progs.stimulus(N, S), progs.stimulus(N, S, seed=99)], axis=1)  # [S, 2, N]
+    check_batch(gpu, text, x, regs=("l", "r", "t", "ccr"), channels=2)
+
+
+def test_set_register_broadcast_and_per_instance(gpu):
+    text = progs.config1_shipped()
+    N, S = 70, 32
+    ramp = np.array([i / 16.0 for i in range(-16, 16)], dtype=np.float32)
+    x = np.repeat(ramp[:, None], N, axis=1)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text)
+    o = [Oracle(1) for _ in range(N)]
+    for q in o:
+        assert q.load_text(text)
+    ys, refs = [], [[] for _ in range(N)]
+    for blk, v in enumerate((0.1, 0.25, 0.5, 1.0)):  # the reference harness's slider schedule (main.cpp:80,107-114)
+        assert b.set_register("volume", v) == 0
+        if blk == 2:
+            assert b.set_register_i("volume", 5, 0.75) == 0
+            o[5].set_register("volume", 0.75)
+        for n, q in enumerate(o):
+            if not (blk == 2 and n == 5):
+                q.set_register("volume", v)
+        ys.append(b.process_block(x[blk * 8:(blk + 1) * 8]))
+        for n, q in enumerate(o):
+            refs[n].append(q.process_block(x[blk * 8:(blk + 1) * 8, n].copy()))
+    y = np.concatenate(ys, axis=0)
+    for n in range(N):
+        assert np.array_equal(bits(np.concatenate(refs[n])), bits(y[:, n])), n
+        assert b.get_register_bits_i("volume", n) == o[n].get_register_bits("volume")
+    assert b.set_register("nonexistent", 1.0) == 1
+    assert b.get_register_i("nonexistent", 0) == 1.0
+
+
+def test_noise_seed_per_instance(gpu):
+    text = HDR + "macs out, 0, noise, 1.0\nend"
+    N, S = 66, 40
+    x = np.zeros((S, N), dtype=np.float32)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text)
+    b.seed_noise_i(3, 12345, -99999)
+    y = b.process_block(x)
+    for n in (0, 3, 65):
+        o = Oracle(1)
+        assert o.load_text(text)
+        if n == 3:
+            o.seed_noise(12345, -99999)
+        assert np.array_equal(bits(o.process_block(x[:, n].copy())), bits(y[:, n]))
+
+
+def test_single_instance_api_matches_reference_harness(gpu):
+    """fx_* mirror: the reference's own main.cpp loop (slider every 8 samples, bipolar ramp)."""
+    import os
+    import tempfile
+
+    text = progs.config1_shipped()
+    fd, path = tempfile.mkstemp(suffix=".da")
+    with os.fdopen(fd, "wb") as fh:
+        fh.write(text.encode())
+    try:
+        fx = gpu.Single(1)
+        assert fx.load_file(path)
+        o = Oracle(1)
+        assert o.load_file(path)
+        ramp = np.array([i / 16.0 for i in range(-16, 16)], dtype=np.float32)
+        sliders = [0.1, 0.25, 0.5, 1.0]
+        for i in range(32):
+            if i % 8 == 0:
+                assert fx.set_register("volume", sliders[i // 8]) == 0
+                o.set_register("volume", sliders[i // 8])
+            got = fx.process(ramp[i:i + 1])
+            ref = o.process_block(ramp[i:i + 1])
+            assert bits(got)[0] == bits(ref)[0], i
+        assert fx.instruction_counter() == o.instruction_counter() == 64
+        assert fx.get_register("filter_cutoff") == o.get_register("filter_cutoff")
+        assert fx.controls() == o.controls() and fx.meta() == o.meta() and fx.errors() == o.errors()
+    finally:
+        os.unlink(path)
+
+
+def test_load_failure_reports_errors(gpu):
+    b = gpu.Batch(64, 1, 0)
+    assert not b.load_text("static a\nmacs a, b, 0, 0\nend")
+    assert b.errors()[1] == ("Variable nicht deklariert", 2)
+    with pytest.raises(RuntimeError):
+        b.process_block(np.zeros((4, 64), dtype=np.float32))
