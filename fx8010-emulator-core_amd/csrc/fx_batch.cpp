@@ -11,6 +11,7 @@
 // stream); their state rows are refreshed when they turn per-instance.
 #include "fx_batch.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -40,7 +41,7 @@ Batch::Batch(int64_t nInstances, int channels, int device) : prog_(channels) {
     if (device >= count) throw std::runtime_error("HIP device ordinal out of range");
     device_ = device;
     n_ = nInstances;
-    nPad_ = (nInstances + 63) / 64 * 64;
+    nPad_ = (nInstances + 255) / 256 * 256;  // whole wavefronts for every K in {1,2,4}
     auto chk = [&](hipError_t r, const char* what) {
         if (r != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(r));
     };
@@ -48,11 +49,10 @@ Batch::Batch(int64_t nInstances, int channels, int device) : prog_(channels) {
     chk(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     chk(hipEventCreate(&ev0_), "hipEventCreate");
     chk(hipEventCreate(&ev1_), "hipEventCreate");
-    chk(hipMalloc(reinterpret_cast<void**>(&dLut_), sizeof(double) * 64 * 65), "hipMalloc lut");
+    chk(hipMalloc(reinterpret_cast<void**>(&dLut_), sizeof(double) * kLutBlobDoubles), "hipMalloc lut");
     chk(hipMalloc(reinterpret_cast<void**>(&dScratch_), kScratchBytes), "hipMalloc scratch");
-    const Luts& L = sharedLuts();
-    chk(hipMemcpy(dLut_, &L.log_[0][0], sizeof(double) * 32 * 65, hipMemcpyHostToDevice), "lut upload");
-    chk(hipMemcpy(dLut_ + 32 * 65, &L.exp_[0][0], sizeof(double) * 32 * 65, hipMemcpyHostToDevice), "lut upload");
+    static const LutDevice lutDev(sharedLuts());
+    chk(hipMemcpy(dLut_, lutDev.blob.data(), sizeof(double) * kLutBlobDoubles, hipMemcpyHostToDevice), "lut upload");
 }
 
 Batch::~Batch() {
@@ -152,15 +152,16 @@ int Batch::ensureState() {
 int Batch::ensureTram() {
     auto grow = [&](float*& buf, int& have, int want) -> int {
         if (want <= have) return 0;
-        const size_t waves = (size_t)(nPad_ / 64);
+        const size_t waves = (size_t)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
+        const size_t pitch = 256 * (size_t)instPerLane_;  // bytes of one slot of one wavefront
         float* fresh = nullptr;
-        const size_t bytes = waves * (size_t)want * 256;
+        const size_t bytes = waves * (size_t)want * pitch;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), bytes);
         if (e != hipSuccess) return hipFail(e, "hipMalloc TRAM");
         e = hipMemsetAsync(fresh, 0, bytes, stream_);  // the parity domain assumes zeroed delay memory
         if (e == hipSuccess && buf && have > 0) {
             if (lastStream_) (void)hipStreamSynchronize(lastStream_);
-            e = hipMemcpy2DAsync(fresh, (size_t)want * 256, buf, (size_t)have * 256, (size_t)have * 256, waves, hipMemcpyDeviceToDevice, stream_);
+            e = hipMemcpy2DAsync(fresh, (size_t)want * pitch, buf, (size_t)have * pitch, (size_t)have * pitch, waves, hipMemcpyDeviceToDevice, stream_);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(stream_);
         if (e != hipSuccess) { (void)hipFree(fresh); return hipFail(e, "TRAM init"); }
@@ -174,6 +175,26 @@ int Batch::ensureTram() {
     return rc;
 }
 
+// K = instances stepped by one lane.  More instances per lane amortise the scalar fetch/dispatch of
+// a record over more work and widen every LDS access, but shrink the number of wavefronts; the LDS
+// register file (rows * 256 * K bytes per wavefront) bounds how many wavefronts a CU can hold.
+// Once TRAM has been allocated its [wave][slot][64][K] tiling pins K for the life of the batch.
+int Batch::chooseInstPerLane() const {
+    if (iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0) return instPerLane_;
+    if (const char* env = std::getenv("FX_INST_PER_LANE")) {
+        const int k = std::atoi(env);
+        if (k == 1 || k == 2 || k == 4) return k;
+    }
+    const Lowered probe = lowerProgram(prog_, hostValue_, forcedLane_, 1);
+    if (!probe.error.empty()) return 1;
+    for (int k : {4, 2}) {
+        const long long waves = (n_ + 64LL * k - 1) / (64LL * k);
+        const long long perCu = kLdsBytesPerCU / ((long long)probe.nRows * 256 * k);
+        if (waves >= 2048 && perCu >= 4) return k;  // >= 2 wavefronts per SIMD in flight and one per SIMD resident
+    }
+    return 1;
+}
+
 bool Batch::laneResident(int reg) const {
     if (reg < (int)forcedLane_.size() && forcedLane_[reg]) return true;
     return !lowDirty_ ? low_.rowOfReg[reg] >= 0 : (reg < (int)low_.rowOfReg.size() && low_.rowOfReg[reg] >= 0);
@@ -183,8 +204,9 @@ int Batch::ensureLowered() {
     if (!loaded_ || !prog_.ready) return fail(FX_E_NOTREADY, "no program loaded");
     if (!lowDirty_) return 0;
     std::vector<int> before = low_.rowOfReg;
-    Lowered fresh = lowerProgram(prog_, hostValue_, forcedLane_);
+    Lowered fresh = lowerProgram(prog_, hostValue_, forcedLane_, chooseInstPerLane());
     if (!fresh.error.empty()) return fail(FX_E_PROGRAM, fresh.error);
+    instPerLane_ = fresh.instPerLane;
     int rc = ensureState();
     if (rc != 0) return rc;
     // registers that were uniform and are per-instance from now on: seed their rows
@@ -200,7 +222,7 @@ int Batch::ensureLowered() {
 
     // upload: steady | last | row table
     const size_t nOps = low_.steady.size();
-    const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size();
+    const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size();
     if (words > streamCap_) {
         if (lastStream_) (void)hipStreamSynchronize(lastStream_);
         (void)hipFree(dStream_);
@@ -215,6 +237,7 @@ int Batch::ensureLowered() {
     size_t p = nOps * 16;
     for (const RowCopy& rcp : low_.loadRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
     for (const RowCopy& rcp : low_.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+    for (int zr : low_.zeroRows) host[p++] = (uint32_t)zr;
     if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still read the old stream
     hipError_t e = hipMemcpy(dStream_, host.data(), words * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipFail(e, "stream upload");
@@ -311,8 +334,15 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     a.xSlots = xSlotsAlloc_;
     a.iSize = prog_.iTramSize;
     a.xSize = prog_.xTramSize;
-    a.cursorBase = stateLayout_.cursorBase;
-    a.noiseBase = stateLayout_.noiseBase;
+    a.nZero = (int)low_.zeroRows.size();
+    const uint32_t rowBytes = 256u * (uint32_t)instPerLane_;
+    a.skipOff = low_.skipRow >= 0 ? (uint32_t)low_.skipRow * rowBytes : 0;
+    a.cursorOff = low_.cursorRow >= 0 ? (uint32_t)low_.cursorRow * rowBytes : 0;
+    a.noiseOff = low_.noiseRow >= 0 ? (uint32_t)low_.noiseRow * rowBytes : 0;
+    a.oodOff = (uint32_t)low_.oodRow * rowBytes;
+    a.aliveOff = low_.aliveRow >= 0 ? (uint32_t)low_.aliveRow * rowBytes : 0;
+    a.hasShadow = low_.skipRow >= 0 ? 1 : 0;
+    a.instPerLane = instPerLane_;
     a.oodRow = stateLayout_.oodRow;
     a.countLo = stateLayout_.countLo;
     a.countHi = stateLayout_.countHi;
@@ -324,7 +354,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     if (e != hipSuccess) return hipFail(e, "launch fx_step_block");
     lastStream_ = s;
     timed_ = true;
-    lastGrid_ = (unsigned)(nPad_ / 64);
+    lastGrid_ = (unsigned)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
     return 0;
 }
 
@@ -417,12 +447,12 @@ int64_t Batch::info(int what) {
     if (what == FXB_INFO_NUM_REGISTERS) return (int64_t)prog_.regs.size();
     if (what == FXB_INFO_GRID) return lastGrid_;
     if (what == FXB_INFO_WAVES_PER_WG) return 1;
-    if (what == FXB_INFO_INST_PER_LANE) return 1;
     if (ensureLowered() != 0) return -1;
     switch (what) {
+        case FXB_INFO_INST_PER_LANE: return instPerLane_;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
-        case FXB_INFO_LDS_BYTES_PER_WG: return (int64_t)low_.nRows * 256;
+        case FXB_INFO_LDS_BYTES_PER_WG: return (int64_t)low_.nRows * 256 * instPerLane_;
         case FXB_INFO_NUM_MICROOPS: return (int64_t)low_.steady.size();
         case FXB_INFO_ITRAM_SLOTS: return iSlotsAlloc_;
         case FXB_INFO_XTRAM_SLOTS: return xSlotsAlloc_;

@@ -54,6 +54,7 @@ private:
     int ensureTram();
     int fillRows(const std::vector<uint32_t>& rows, const std::vector<uint32_t>& values);
     bool laneResident(int reg) const;
+    int chooseInstPerLane() const;
     hipStream_t pick(hipStream_t s) const { return s ? s : stream_; }
 
     Program prog_;
@@ -76,6 +77,7 @@ private:
     float* dITram_ = nullptr;
     float* dXTram_ = nullptr;
     int iSlotsAlloc_ = 0, xSlotsAlloc_ = 0;
+    int instPerLane_ = 1;
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;
     size_t streamCap_ = 0;

@@ -166,7 +166,7 @@ int fxp_lower(fxp_handle* h) {
     if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
     std::vector<float> values(h->prog.regs.size());
     for (size_t r = 0; r < values.size(); ++r) values[r] = h->prog.regs[r].value;
-    h->low = fx::lowerProgram(h->prog, values, std::vector<uint8_t>(values.size(), 0));
+    h->low = fx::lowerProgram(h->prog, values, std::vector<uint8_t>(values.size(), 0), 1);
     h->lowered = h->low.error.empty();
     h->err = h->low.error;
     return h->lowered ? 0 : FX_E_PROGRAM;

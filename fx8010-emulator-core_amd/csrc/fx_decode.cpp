@@ -33,8 +33,10 @@ StateLayout makeLayout(int nRegs, int channels) {
     return L;
 }
 
-Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, const std::vector<uint8_t>& forcedLane) {
+Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, const std::vector<uint8_t>& forcedLane, int instPerLane) {
     Lowered out;
+    out.instPerLane = instPerLane;
+    const uint32_t rowBytes = 256u * (uint32_t)instPerLane;
     const int nRegs = (int)prog.regs.size();
     const int P = (int)prog.instrs.size();
     const int CH = prog.numChannels;
@@ -131,10 +133,20 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
         if (aliasChan[r] >= 0) out.rowOfReg[r] = out.inRow[aliasChan[r]];
         else out.rowOfReg[r] = nextRow++;
     }
+    // bookkeeping rows, only what this program needs
+    bool anyShadow = false;  // a SKIP writes numSkip even when its count is statically 0
+    for (int k = 0; k < P; ++k) anyShadow = anyShadow || shadow[k] || prog.instrs[k].op == SKIP;
+    out.oodRow = nextRow++;
+    out.zeroRows.push_back(out.oodRow);
+    if (anyShadow) { out.skipRow = nextRow; nextRow += 3; for (int q = 0; q < 3; ++q) out.zeroRows.push_back(out.skipRow + q); }
+    if (out.usesITram || out.usesXTram) { out.cursorRow = nextRow; nextRow += 4; }
+    if (out.usesNoise) { out.noiseRow = nextRow; nextRow += 2; }
+    if (out.multipass) { out.aliveRow = nextRow; nextRow += 2; out.zeroRows.push_back(out.aliveRow); out.zeroRows.push_back(out.aliveRow + 1); }
     out.nRows = nextRow;
     for (int r = 0; r < nRegs; ++r) (lane[r] ? out.nLaneRegs : out.nUniformRegs)++;
-    if (out.nRows > 255) {
-        out.error = "program needs " + std::to_string(out.nRows) + " per-instance register rows; the LDS register file holds 255";
+    if ((long)out.nRows * rowBytes > 160 * 1024) {
+        out.error = "program needs " + std::to_string(out.nRows) + " per-instance rows: more than the 160 KiB LDS register file holds at " +
+                    std::to_string(instPerLane) + " instance(s) per lane";
         return out;
     }
     for (int r = 0; r < nRegs; ++r) {
@@ -146,6 +158,16 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
         out.loadRows.push_back({(uint16_t)out.latchRow[c], (uint16_t)(out.layout.outBase + c)});
         out.storeRows.push_back({(uint16_t)out.latchRow[c], (uint16_t)(out.layout.outBase + c)});
     }
+    if (out.cursorRow >= 0)
+        for (int q = 0; q < 4; ++q) {
+            out.loadRows.push_back({(uint16_t)(out.cursorRow + q), (uint16_t)(out.layout.cursorBase + q)});
+            out.storeRows.push_back({(uint16_t)(out.cursorRow + q), (uint16_t)(out.layout.cursorBase + q)});
+        }
+    if (out.noiseRow >= 0)
+        for (int q = 0; q < 2; ++q) {
+            out.loadRows.push_back({(uint16_t)(out.noiseRow + q), (uint16_t)(out.layout.noiseBase + q)});
+            out.storeRows.push_back({(uint16_t)(out.noiseRow + q), (uint16_t)(out.layout.noiseBase + q)});
+        }
 
     // ---- 5. CCR liveness ------------------------------------------------------------------------
     // A CCR write is observable if, walking forward (wrapping into the next sample), a reader of
@@ -188,8 +210,7 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
     }
 
     // ---- 7. emission ------------------------------------------------------------------------------
-    auto rowOff = [&](int reg) { return (uint32_t)(out.rowOfReg[reg] * 256); };
-    auto emit = [&](std::vector<MicroOp>& dst, const MicroOp& m) { dst.push_back(m); };
+    auto rowOff = [&](int reg) { return (uint32_t)out.rowOfReg[reg] * rowBytes; };
 
     for (int pass = 0; pass < 2; ++pass) {
         std::vector<MicroOp>& dst = pass == 0 ? out.steady : out.last;
@@ -202,8 +223,15 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
                 if (prog.regs[reg].type == R_INPUT && aliasChan[reg] >= 0) return out.inRow[chanOf(I)];
                 return out.rowOfReg[reg];
             };
+            auto mov = [&](uint32_t flags, uint32_t dstOff, uint32_t srcOff) {
+                MicroOp m{};
+                m.w[0] = H_MOV | flags | F_WRITE_R | F_UX | F_UY;
+                m.w[1] = dstOff;
+                m.w[2] = srcOff;
+                dst.push_back(m);
+            };
 
-            // prefix: refresh of INPUT operands that could not be aliased
+            // prefix: refresh of INPUT operands that could not be aliased (FX8010.cpp:1053-1061)
             if (I.hasInput) {
                 int seen[3] = {-1, -1, -1};
                 const int ops[3] = {I.a, I.x, I.y};
@@ -212,18 +240,15 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
                     if (prog.regs[o].type != R_INPUT || aliasChan[o] >= 0) continue;
                     if (o == seen[0] || o == seen[1]) continue;
                     seen[q] = o;
-                    MicroOp m{};
-                    m.w[0] = H_REFRESH | sh | F_PREFIX;
-                    m.w[1] = rowOff(o) | ((uint32_t)(out.inRow[chanOf(I)] * 256) << 16);
-                    emit(dst, m);
+                    mov(sh | F_PREFIX, rowOff(o), (uint32_t)out.inRow[chanOf(I)] * rowBytes);
                 }
             }
             if (I.hasNoise) {
                 int t = prog.regs[I.a].name == "noise" ? I.a : (prog.regs[I.x].name == "noise" ? I.x : I.y);
                 MicroOp m{};
-                m.w[0] = H_NOISE | sh | F_PREFIX;
+                m.w[0] = H_NOISE | sh | F_PREFIX | F_WRITE_R | F_UA | F_UX | F_UY;
                 m.w[1] = rowOff(t);
-                emit(dst, m);
+                dst.push_back(m);
             }
 
             MicroOp m{};
@@ -236,7 +261,7 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
                 case MACW: h = H_MACW; break;
                 case MACWN: h = H_MACWN; break;
                 case MACINTW: h = H_MACINTW; break;
-                case MACMV: h = H_MACMV; break;
+                case MACMV: h = H_MOV; break;
                 case ANDXOR: h = H_ANDXOR; break;
                 case TSTNEG: h = H_TSTNEG; break;
                 case LIMIT: h = H_LIMIT; break;
@@ -252,50 +277,46 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
             uint32_t flags = sh | F_COUNT;
             if (setsCcr(I.op) && (pass == 1 || ccrLive[k])) flags |= F_CCR;
 
-            uint32_t rOff = 0, aOff = 0, xOff = 0, yOff = 0;
-            auto src = [&](int reg, uint32_t uflag, int immSlot, uint32_t& off) {
-                if (lane[reg]) off = (uint32_t)(operandRow(reg) * 256);
-                else { flags |= uflag; m.w[immSlot] = bitsOf(hostValue[reg]); }
+            // operand slots: LDS byte offset of a per-instance row, or the immediate of a uniform register;
+            // slots an opcode does not read are immediates too, so the kernel issues no LDS read for them
+            auto src = [&](int reg, uint32_t uflag, int slot) {
+                if (lane[reg]) m.w[slot] = (uint32_t)operandRow(reg) * rowBytes;
+                else { flags |= uflag; m.w[slot] = bitsOf(hostValue[reg]); }
             };
-            const bool isDelay = (h == H_TRAM_IR || h == H_TRAM_IW || h == H_TRAM_XR || h == H_TRAM_XW);
-            if (writesResult(I.op)) rOff = rowOff(I.r);
+            auto unused = [&](uint32_t uflag, int slot) { flags |= uflag; m.w[slot] = 0; };
+            if (writesResult(I.op)) { m.w[1] = rowOff(I.r); flags |= F_WRITE_R; }
             if (h == H_TRAM_IR || h == H_TRAM_XR) {
-                aOff = rowOff(I.a);  // destination of the read
-                src(I.y, F_UY, 6, yOff);
+                m.w[1] = rowOff(I.a);  // the read lands in A (FX8010.cpp:1192,1204)
+                flags |= F_WRITE_R;
+                unused(F_UA, 2); unused(F_UX, 3); src(I.y, F_UY, 4);
             } else if (h == H_TRAM_IW || h == H_TRAM_XW) {
-                src(I.a, F_UA, 4, aOff);
-                src(I.y, F_UY, 6, yOff);
+                src(I.a, F_UA, 2); unused(F_UX, 3); src(I.y, F_UY, 4);
             } else if (h == H_SKIP) {
-                src(I.x, F_UX, 5, xOff);
-                src(I.y, F_UY, 6, yOff);
+                unused(F_UA, 2); src(I.x, F_UX, 3); src(I.y, F_UY, 4);
             } else if (h == H_LOG || h == H_EXP) {
-                src(I.a, F_UA, 4, aOff);
-                if (lane[I.x]) xOff = (uint32_t)(operandRow(I.x) * 256);
+                src(I.a, F_UA, 2);
+                unused(F_UY, 4);  // Y (sign) is ignored by the reference (FX8010.cpp:1114)
+                if (lane[I.x]) m.w[3] = (uint32_t)operandRow(I.x) * rowBytes;
                 else {
                     flags |= F_UX;
                     int32_t t = x86Trunc(hostValue[I.x]);
                     if (t < 0 || t > 31) { flags |= F_STATIC_OOD; t = t < 0 ? 0 : 31; }
-                    m.w[3] = (uint32_t)((h == H_EXP ? 32 : 0) + t);
-                    m.w[5] = bitsOf(hostValue[I.x]);
+                    m.w[5] = (uint32_t)((h == H_EXP ? 32 : 0) + t);
+                    m.w[3] = bitsOf(hostValue[I.x]);
                 }
-            } else if (h != H_END && h != H_NOP) {
-                src(I.a, F_UA, 4, aOff);
-                src(I.x, F_UX, 5, xOff);
-                src(I.y, F_UY, 6, yOff);
+            } else if (h == H_MOV) {  // MACMV: R = A
+                src(I.a, F_UA, 2); unused(F_UX, 3); unused(F_UY, 4);
+            } else if (h == H_END || h == H_NOP) {
+                unused(F_UA, 2); unused(F_UX, 3); unused(F_UY, 4);
+            } else {
+                src(I.a, F_UA, 2); src(I.x, F_UX, 3); src(I.y, F_UY, 4);
             }
-            (void)isDelay;
             m.w[0] = h | flags;
-            m.w[1] = rOff | (aOff << 16);
-            m.w[2] = xOff | (yOff << 16);
-            emit(dst, m);
+            dst.push_back(m);
 
             // postfix: output latch (FX8010.cpp:1229-1233) after ANY executed instruction whose R is an OUTPUT
-            if (prog.regs[I.r].type == R_OUTPUT) {
-                MicroOp l{};
-                l.w[0] = H_LATCH | sh | F_POSTFIX;
-                l.w[1] = (uint32_t)(out.latchRow[prog.regs[I.r].io] * 256) | (rowOff(I.r) << 16);
-                emit(dst, l);
-            }
+            if (prog.regs[I.r].type == R_OUTPUT)
+                mov(sh | F_POSTFIX, (uint32_t)out.latchRow[prog.regs[I.r].io] * rowBytes, rowOff(I.r));
         }
     }
 

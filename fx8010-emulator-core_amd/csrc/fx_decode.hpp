@@ -25,19 +25,20 @@ namespace fx {
 
 // One record of the device stream: 8 dwords, fetched with a single scalar load.
 //   w0  handler id [7:0] | flags [31:8]
-//   w1  R row byte offset [15:0] | A row byte offset [31:16]
-//   w2  X row byte offset [15:0] | Y row byte offset [31:16]
-//   w3  extra0 (LUT table index, ...)
-//   w4  immediate A   w5 immediate X   w6 immediate Y   (IEEE bits, when the U* flag is set)
-//   w7  extra1
+//   w1  R: LDS byte offset of the destination row (row * 256 * K)
+//   w2  A: LDS byte offset of the operand row, or its IEEE bits when F_UA is set
+//   w3  X: likewise (F_UX)      w4  Y: likewise (F_UY)
+//   w5  extra (LOG/EXP: table index 0..63 when X is uniform)
+//   w6, w7 reserved
 struct MicroOp {
     uint32_t w[8];
 };
 
 enum Handler : uint32_t {
-    H_END = 0, H_NOP, H_MACS, H_MACSN, H_ACC3, H_INTERP, H_MACW, H_MACWN, H_MACINTW, H_MACMV,
+    H_END = 0, H_NOP, H_MACS, H_MACSN, H_ACC3, H_INTERP, H_MACW, H_MACWN, H_MACINTW,
+    H_MOV,  // R = A: MACMV, refresh of an INPUT operand, output latch
     H_ANDXOR, H_TSTNEG, H_LIMIT, H_LIMITN, H_LOG, H_EXP, H_SKIP,
-    H_TRAM_IR, H_TRAM_IW, H_TRAM_XR, H_TRAM_XW, H_REFRESH, H_NOISE, H_LATCH,
+    H_TRAM_IR, H_TRAM_IW, H_TRAM_XR, H_TRAM_XW, H_NOISE,
     H_COUNT_
 };
 
@@ -50,7 +51,8 @@ enum : uint32_t {
     F_PREFIX = 1u << 13,   // helper op ahead of its instruction (same predicate, no skip countdown)
     F_POSTFIX = 1u << 14,  // helper op behind its instruction (runs where the instruction ran)
     F_COUNT = 1u << 15,    // a reference instruction (counts towards getInstructionCounter)
-    F_STATIC_OOD = 1u << 16  // decoder already knows this op leaves the parity domain
+    F_STATIC_OOD = 1u << 16,  // decoder already knows this op leaves the parity domain
+    F_WRITE_R = 1u << 17      // the handler's result is stored to row R (and CCR derived from it if F_CCR)
 };
 
 // state rows (32-bit words per instance) in the device state block, after the register rows
@@ -77,6 +79,13 @@ struct Lowered {
     std::vector<int> rowOfReg;       // LDS row of a register, -1 if uniform
     std::vector<int> inRow;          // per channel: LDS row of the input sample, -1 if unused
     std::vector<int> latchRow;       // per channel: LDS row of the output latch
+    std::vector<int> zeroRows;       // LDS rows cleared at kernel start (bookkeeping rows)
+    int skipRow = -1;    // numSkip, ran, dynCount (3 rows) when any instruction is shadowed
+    int cursorRow = -1;  // 4 TRAM cursor rows when the program touches TRAM
+    int noiseRow = -1;   // 2 LFSR rows when the program draws noise
+    int oodRow = -1;     // sticky out-of-domain flags
+    int aliveRow = -1;   // alive, ended (2 rows) in multipass programs
+    int instPerLane = 1;
     StateLayout layout;
     int nRows = 0;
     int nLaneRegs = 0, nUniformRegs = 0;
@@ -91,8 +100,9 @@ struct Lowered {
 
 // forcedLane[r] != 0 keeps register r per-instance even if no instruction writes it
 // (set after fxb_set_register_i gave instances different values).
+// instPerLane (K) fixes the LDS row pitch (256*K bytes) the record offsets are expressed in.
 Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue,
-                     const std::vector<uint8_t>& forcedLane);
+                     const std::vector<uint8_t>& forcedLane, int instPerLane);
 
 StateLayout makeLayout(int nRegs, int channels);
 

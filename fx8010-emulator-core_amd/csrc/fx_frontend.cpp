@@ -320,4 +320,30 @@ Luts::Luts() {
     }
 }
 
+LutDevice::LutDevice(const Luts& l) : blob(kLutBlobDoubles, 0.0), invStep(63.0 / 2.0) {
+    const double step = (1.0 - -1.0) / 63.0;
+    auto indexOf = [&](double t) { return (int)(t / step); };  // t in [0, 2]: in range, plain truncation
+    blob[kLutThrOff + 0] = 0.0;
+    for (int k = 1; k <= 63; ++k) {
+        double t = k * step;
+        // walk to the exact boundary: the smallest t whose quotient truncates to >= k
+        while (indexOf(t) >= k) t = std::nextafter(t, 0.0);
+        while (indexOf(t) < k) t = std::nextafter(t, 4.0);
+        blob[kLutThrOff + k] = t;
+    }
+    blob[kLutThrOff + 64] = HUGE_VAL;
+    for (int k = 0; k < 64; ++k) blob[kLutX1Off + k] = -1.0 + k * step;
+    for (int tsel = 0; tsel < 64; ++tsel) {
+        const double* tbl = tsel < 32 ? l.log_[tsel] : l.exp_[tsel - 32];
+        for (int k = 0; k < 64; ++k) {
+            const double x1 = -1.0 + k * step;
+            const double x2 = -1.0 + (k + 1) * step;
+            const double y1 = tbl[k];
+            const double y2 = tbl[k + 1];
+            blob[kLutSegOff + (tsel * 64 + k) * 2 + 0] = (y2 - y1) / (x2 - x1);
+            blob[kLutSegOff + (tsel * 64 + k) * 2 + 1] = y1;
+        }
+    }
+}
+
 }  // namespace fx

@@ -1,19 +1,24 @@
 // fx_kernel.hip — the FX8010 interpreter kernel for gfx950 (MI355X, CDNA4).
 //
-// One lane = one emulated DSP.  A wavefront (64 lanes = 64 consecutive instances) walks the
-// host-decoded opcode stream; every record is fetched with one scalar load and dispatched
-// with a wave-uniform branch, so the only per-lane control flow is the SKIP predicate.
+// One lane steps K emulated DSPs (K = 1, 2 or 4 consecutive instances); a wavefront therefore
+// owns 64*K instances and walks the host-decoded opcode stream for all of them.  Every record is
+// fetched with ONE scalar load (constant address space, prefetched one record ahead) and
+// dispatched with wave-uniform branches, so the fixed cost of fetch/decode/dispatch is shared by
+// 64*K instances and the only per-instance control flow is the SKIP predicate (a select).
 //
-//   per-lane register file : LDS, row r of lane l at byte r*256 + l*4 (bank = lane: conflict-free)
-//   CCR                    : LDS row 0, written only where the decoder proved it observable
-//   uniform registers      : immediates inside the record (SGPRs)
-//   TRAM                   : HBM, [wave][slot][64]; a wave's read/write of one slot is 256 contiguous bytes
-//   PCM in/out             : HBM, [sample][channel][instance]; next sample's input is prefetched
-//   cursors, LFSR, skip    : VGPRs
+//   per-instance register file : LDS, row r = [64 lanes][K] floats at byte r*256*K; a lane reads its
+//                                K values of a row with one ds_read_b32/b64/b128 (conflict-free)
+//   CCR                        : LDS row 0, written only where the decoder proved it observable
+//   uniform registers          : immediates inside the record (SGPRs)
+//   skip / cursors / LFSR      : LDS rows too, allocated only for programs that need them, so the
+//                                dispatch loop carries no per-lane VGPR state
+//   TRAM                       : HBM, [wave][slot][64][K]: a wave's access to one slot is 256*K
+//                                contiguous bytes
+//   PCM in/out                 : HBM, [sample][channel][instance]; next sample's input prefetched
 //
-// Arithmetic is the reference's (source/FX8010.cpp:1023-1249): IEEE fp32 with fp64 in
-// INTERP/LOG/EXP, multiply and add never fused, fp32 denormals kept, x86 float->int
-// conversion semantics reproduced by cvtt_*.  Compile with -ffp-contract=off.
+// Arithmetic is the reference's (source/FX8010.cpp:1023-1249): IEEE fp32, fp64 inside
+// INTERP/LOG/EXP, multiply and add never fused, fp32 denormals kept, x86 float->int conversion
+// semantics reproduced by cvtt_*.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
 #include "fx_decode.hpp"
@@ -24,18 +29,24 @@
 namespace fx {
 namespace {
 
-struct LaneState {
-    int numSkip;
-    int iw, ir, xw, xr;    // TRAM cursors (reference: include/FX8010.h:214-217)
-    int g1, g2;            // white-noise generator (include/FX8010.h:290-291)
-    uint32_t ood;
-    uint32_t dynCount;     // executed instructions among the shadowed ones
-    bool ran;              // did the last counted instruction execute on this lane
-    bool alive, isEnd;     // multipass bookkeeping
-};
+typedef const uint32_t __attribute__((address_space(4))) * ConstU32;  // scalar-loadable stream
 
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t asU(float f) { return __float_as_uint(f); }
+
+// K floats of one lane
+template <int K>
+struct Vec {
+    float v[K];
+};
+
+template <int K>
+__device__ __forceinline__ Vec<K> splat(float f) {
+    Vec<K> r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.v[k] = f;
+    return r;
+}
 
 // x86 cvttss2si / cvttsd2si: NaN and out-of-range give 0x80000000
 __device__ __forceinline__ int cvtt_f32(float v) {
@@ -78,307 +89,464 @@ __device__ __forceinline__ int logicOps(float a_, float x_, float y_) {
     return r;
 }
 
-struct Ctx {
-    char* lds;            // this lane's LDS base: wave region + lane*4
-    const KernelArgs* a;
-    float* itramLane;     // itram + wave*iSlots*64 + lane
-    float* xtramLane;
-};
+// ---- LDS access: a lane's K values of one row are contiguous (4*K bytes) ----
+template <int K>
+__device__ __forceinline__ Vec<K> ldsLoad(const char* lane, uint32_t off) {
+    Vec<K> r;
+    if constexpr (K == 1) {
+        r.v[0] = *reinterpret_cast<const float*>(lane + off);
+    } else if constexpr (K == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(lane + off);
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else {
+        const float4 t = *reinterpret_cast<const float4*>(lane + off);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    }
+    return r;
+}
+template <int K>
+__device__ __forceinline__ void ldsStore(char* lane, uint32_t off, const Vec<K>& x) {
+    if constexpr (K == 1) {
+        *reinterpret_cast<float*>(lane + off) = x.v[0];
+    } else if constexpr (K == 2) {
+        *reinterpret_cast<float2*>(lane + off) = make_float2(x.v[0], x.v[1]);
+    } else {
+        *reinterpret_cast<float4*>(lane + off) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    }
+}
+// ---- global access of K consecutive floats (vector when the run is aligned and complete) ----
+template <int K>
+__device__ __forceinline__ Vec<K> gLoad(const float* __restrict__ p, bool vecOk, int nValid) {
+    Vec<K> r;
+    if constexpr (K == 1) {
+        r.v[0] = nValid > 0 ? p[0] : 0.0f;
+    } else {
+        if (vecOk) {
+            if constexpr (K == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+            else { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) r.v[k] = k < nValid ? p[k] : 0.0f;
+        }
+    }
+    return r;
+}
+template <int K>
+__device__ __forceinline__ void gStore(float* __restrict__ p, const Vec<K>& x, bool vecOk, int nValid) {
+    if constexpr (K == 1) {
+        if (nValid > 0) p[0] = x.v[0];
+    } else {
+        if (vecOk) {
+            if constexpr (K == 2) *reinterpret_cast<float2*>(p) = make_float2(x.v[0], x.v[1]);
+            else *reinterpret_cast<float4*>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) if (k < nValid) p[k] = x.v[k];
+        }
+    }
+}
 
-__device__ __forceinline__ float ldsRead(const Ctx& c, uint32_t off) { return *reinterpret_cast<const float*>(c.lds + off); }
-__device__ __forceinline__ void ldsWrite(const Ctx& c, uint32_t off, float v) { *reinterpret_cast<float*>(c.lds + off) = v; }
-
-// reference linearInterpolate, source/FX8010.cpp:283-296 with x_min=-1, x_max=1 and a 64-entry table
-__device__ __forceinline__ float lutInterpolate(const double* __restrict__ tbl, float xin, uint32_t& ood) {
+// reference linearInterpolate, source/FX8010.cpp:283-296 (x_min=-1, x_max=1, 64-entry table), evaluated
+// from the host-precomputed thresholds / segment table (fx_model.hpp, LutDevice): same IEEE results, no
+// fp64 division in the kernel.  `seg` points at the table's 64 {slope, y1} pairs.
+__device__ __forceinline__ float lutInterpolate(const double* __restrict__ lut, int table, float xin, uint32_t& ood) {
     const double x = (double)xin;
-    const double step = (1.0 - -1.0) / 63.0;
-    int idx = cvtt_f64((x - -1.0) / step);
-    if (idx < 0 || idx > 63) { ood |= OOD_LUT_INDEX; idx = idx < 0 ? 0 : 63; }
-    const double x1 = -1.0 + idx * step;
-    const double x2 = -1.0 + (idx + 1) * step;
-    const double y1 = tbl[idx];
-    const double y2 = tbl[idx + 1];
-    const double y = (y2 - y1) / (x2 - x1) * (x - x1) + y1;
+    const double t = x - -1.0;
+    int idx = 0;
+    if (!(t >= 0.0) || t > 2.0) {
+        // outside [-1,1] (or NaN): outside the parity domain; follow the reference's arithmetic, then clamp
+        idx = cvtt_f64(t / ((1.0 - -1.0) / 63.0));
+        if (idx < 0 || idx > 63) { ood |= OOD_LUT_INDEX; idx = idx < 0 ? 0 : 63; }
+    } else {
+        idx = (int)(t * 31.5);
+        idx = idx > 63 ? 63 : idx;
+        const double* thr = lut + kLutThrOff;
+        idx += (t >= thr[idx + 1]) ? 1 : 0;
+        idx -= (t < thr[idx]) ? 1 : 0;
+    }
+    const double x1 = lut[kLutX1Off + idx];
+    const double* seg = lut + kLutSegOff + ((size_t)table * 64 + idx) * 2;
+    const double y = seg[0] * (x - x1) + seg[1];
     return (float)y;
 }
 
-// reference read/write{Small,Large}Delay, source/FX8010.cpp:909-967
-__device__ __forceinline__ float tramRead(float* __restrict__ base, int slots, int size, int& rpos, int position, uint32_t& ood) {
-    if (size <= 0) { ood |= OOD_TRAM_SIZE0; return 0.0f; }
-    position = position > size - 1 ? size - 1 : position;
-    position = position < 0 ? 0 : position;
-    int idx = rpos - position;               // (rpos - p) % size with 0 <= rpos < size
-    if (idx < 0) { ood |= OOD_TRAM_READ_NEG; idx += size; }
-    const float v = (idx < slots) ? base[(size_t)idx * 64] : 0.0f;
-    rpos = (rpos + 1 >= size) ? 0 : rpos + 1;
-    return v;
-}
-__device__ __forceinline__ void tramWrite(float* __restrict__ base, int slots, int size, int refCap, int& wpos, int position, float v, uint32_t& ood) {
-    if (size <= 0) { ood |= OOD_TRAM_SIZE0; return; }
-    position = position > size - 1 ? size - 1 : position;
-    position = position < 0 ? 0 : position;
-    const int idx = wpos + position;         // the reference applies no modulo here
-    if (idx >= refCap || idx >= slots) ood |= OOD_TRAM_WRITE_OOB;
-    else base[(size_t)idx * 64] = v;
-    wpos = (wpos + 1 >= size) ? 0 : wpos + 1;
+template <int K>
+struct Ctx {
+    char* lane;           // this lane's LDS base: smem + lane*4*K
+    const KernelArgs* a;
+    float* itramLane;     // itram + (wave*iSlots*64 + lane)*K
+    float* xtramLane;
+};
+
+template <int K>
+__device__ __forceinline__ void orOod(const Ctx<K>& c, const uint32_t (&bits)[K]) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) any = any || bits[k] != 0;
+    if (any) {
+        Vec<K> o = ldsLoad<K>(c.lane, c.a->oodOff);
+#pragma unroll
+        for (int k = 0; k < K; ++k) o.v[k] = asF(asU(o.v[k]) | bits[k]);
+        ldsStore<K>(c.lane, c.a->oodOff, o);
+    }
 }
 
-// Execute one record for the lanes currently enabled.
-template <bool MULTIPASS>
-__device__ __forceinline__ void execOp(const Ctx& c, LaneState& st, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
-                                       uint32_t w4, uint32_t w5, uint32_t w6) {
-    const uint32_t rOff = w1 & 0xffffu, aOff = w1 >> 16, xOff = w2 & 0xffffu, yOff = w2 >> 16;
-    auto opA = [&]() { return (w0 & F_UA) ? asF(w4) : ldsRead(c, aOff); };
-    auto opX = [&]() { return (w0 & F_UX) ? asF(w5) : ldsRead(c, xOff); };
-    auto opY = [&]() { return (w0 & F_UY) ? asF(w6) : ldsRead(c, yOff); };
-    auto finish = [&](float r) {  // store R, then setCCR(R) where observable
-        ldsWrite(c, rOff, r);
-        if (w0 & F_CCR) ldsWrite(c, 0, ccrOf(r));
-    };
+// reference read/write{Small,Large}Delay, source/FX8010.cpp:909-967; the cursors live in LDS rows
+template <int K>
+__device__ __forceinline__ Vec<K> tramRead(const Ctx<K>& c, float* __restrict__ base, int slots, int size, uint32_t cursorOff,
+                                           const Vec<K>& yv, const bool (&run)[K]) {
+    Vec<K> out = splat<K>(0.0f);
+    uint32_t ood[K];
+    Vec<K> cur = ldsLoad<K>(c.lane, cursorOff);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ood[k] = 0;
+        if (!run[k]) continue;
+        if (size <= 0) { ood[k] = OOD_TRAM_SIZE0; continue; }
+        int rpos = (int)asU(cur.v[k]);
+        int position = cvtt_f32(yv.v[k]);
+        position = position > size - 1 ? size - 1 : position;
+        position = position < 0 ? 0 : position;
+        int idx = rpos - position;               // (rpos - p) % size with 0 <= rpos < size
+        if (idx < 0) { ood[k] = OOD_TRAM_READ_NEG; idx += size; }
+        out.v[k] = (idx < slots) ? base[(size_t)idx * (64 * K) + k] : 0.0f;
+        rpos = (rpos + 1 >= size) ? 0 : rpos + 1;
+        cur.v[k] = asF((uint32_t)rpos);
+    }
+    ldsStore<K>(c.lane, cursorOff, cur);
+    orOod<K>(c, ood);
+    return out;
+}
+template <int K>
+__device__ __forceinline__ void tramWrite(const Ctx<K>& c, float* __restrict__ base, int slots, int size, int refCap, uint32_t cursorOff,
+                                          const Vec<K>& av, const Vec<K>& yv, const bool (&run)[K]) {
+    uint32_t ood[K];
+    Vec<K> cur = ldsLoad<K>(c.lane, cursorOff);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ood[k] = 0;
+        if (!run[k]) continue;
+        if (size <= 0) { ood[k] = OOD_TRAM_SIZE0; continue; }
+        int wpos = (int)asU(cur.v[k]);
+        int position = cvtt_f32(yv.v[k]);
+        position = position > size - 1 ? size - 1 : position;
+        position = position < 0 ? 0 : position;
+        const int idx = wpos + position;         // the reference applies no modulo here
+        if (idx >= refCap || idx >= slots) ood[k] = OOD_TRAM_WRITE_OOB;
+        else base[(size_t)idx * (64 * K) + k] = av.v[k];
+        wpos = (wpos + 1 >= size) ? 0 : wpos + 1;
+        cur.v[k] = asF((uint32_t)wpos);
+    }
+    ldsStore<K>(c.lane, cursorOff, cur);
+    orOod<K>(c, ood);
+}
+
+// One record.  `run` = which of this lane's K instances execute it (all true outside SKIP shadows).
+template <int K, bool MULTIPASS>
+__device__ __forceinline__ void execOp(const Ctx<K>& c, uint32_t w0, uint32_t rOff, uint32_t wA, uint32_t wX, uint32_t wY, uint32_t w5,
+                                       const bool (&run)[K], bool shadow) {
+    constexpr uint32_t ROWB = 256u * K;
+    // operand fetch is opcode-independent: LDS row or immediate
+    const Vec<K> a = (w0 & F_UA) ? splat<K>(asF(wA)) : ldsLoad<K>(c.lane, wA);
+    const Vec<K> x = (w0 & F_UX) ? splat<K>(asF(wX)) : ldsLoad<K>(c.lane, wX);
+    const Vec<K> y = (w0 & F_UY) ? splat<K>(asF(wY)) : ldsLoad<K>(c.lane, wY);
+    Vec<K> r = a;
     switch (w0 & 0xffu) {
-        case H_MACS: {  // R = sat(A + X*Y)            FX8010.cpp:1077-1085 (MACINTS :1095-1103 is identical)
-            const float a = opA(), x = opX(), y = opY();
-            const float p = x * y;
-            finish(saturate1(a + p));
+        case H_MACS:  // R = sat(A + X*Y)   FX8010.cpp:1077-1085 (MACINTS :1095-1103 is the same expression)
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const float p = x.v[k] * y.v[k]; r.v[k] = saturate1(a.v[k] + p); }
             break;
-        }
-        case H_MACSN: {  // R = sat(A - X*Y)           :1086-1094
-            const float a = opA(), x = opX(), y = opY();
-            const float p = x * y;
-            finish(saturate1(a - p));
+        case H_MACSN:  // R = sat(A - X*Y)   :1086-1094
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const float p = x.v[k] * y.v[k]; r.v[k] = saturate1(a.v[k] - p); }
             break;
-        }
-        case H_ACC3: {  // R = sat((A + X) + Y)        :1104-1112
-            const float a = opA(), x = opX(), y = opY();
-            const float t = a + x;
-            finish(saturate1(t + y));
+        case H_ACC3:  // R = sat((A + X) + Y)   :1104-1112
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const float t = a.v[k] + x.v[k]; r.v[k] = saturate1(t + y.v[k]); }
             break;
-        }
-        case H_INTERP: {  // R = sat((float)((1.0 - X)*A + (double)(X*Y)))   :1180-1187
-            const float a = opA(), x = opX(), y = opY();
-            const float p = x * y;
-            const double d = (1.0 - (double)x) * (double)a + (double)p;
-            finish(saturate1((float)d));
+        case H_INTERP:  // R = sat((float)((1.0 - X)*A + (double)(X*Y)))   :1180-1187
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float p = x.v[k] * y.v[k];
+                const double d = (1.0 - (double)x.v[k]) * (double)a.v[k] + (double)p;
+                r.v[k] = saturate1((float)d);
+            }
             break;
-        }
-        case H_MACW: {  // R = A + wrap(X*Y)           :1126-1131
-            const float a = opA(), x = opX(), y = opY();
-            finish(a + wrapAround(x * y));
+        case H_MACW:  // R = A + wrap(X*Y)   :1126-1131
+#pragma unroll
+            for (int k = 0; k < K; ++k) r.v[k] = a.v[k] + wrapAround(x.v[k] * y.v[k]);
             break;
-        }
-        case H_MACWN: {  // R = A - wrap(X*Y)          :1132-1137
-            const float a = opA(), x = opX(), y = opY();
-            finish(a - wrapAround(x * y));
+        case H_MACWN:  // R = A - wrap(X*Y)   :1132-1137
+#pragma unroll
+            for (int k = 0; k < K; ++k) r.v[k] = a.v[k] - wrapAround(x.v[k] * y.v[k]);
             break;
-        }
-        case H_MACINTW: {  // R = wrap(A + X*Y)        :1138-1143
-            const float a = opA(), x = opX(), y = opY();
-            const float p = x * y;
-            finish(wrapAround(a + p));
+        case H_MACINTW:  // R = wrap(A + X*Y)   :1138-1143
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const float p = x.v[k] * y.v[k]; r.v[k] = wrapAround(a.v[k] + p); }
             break;
-        }
-        case H_MACMV: {  // R = A (the accumulator it feeds is never observable)   :1144-1149
-            finish(opA());
+        case H_MOV:  // MACMV (:1144-1149, accumulator unobservable), input refresh (:1053-1061), output latch (:1229-1233)
             break;
-        }
-        case H_ANDXOR: {  // :1150-1154
-            const float a = opA(), x = opX(), y = opY();
-            finish((float)logicOps(a, x, y));
+        case H_ANDXOR:  // :1150-1154
+#pragma unroll
+            for (int k = 0; k < K; ++k) r.v[k] = (float)logicOps(a.v[k], x.v[k], y.v[k]);
             break;
-        }
-        case H_TSTNEG: {  // R = A >= Y ? X : intToFloat(~floatToInt(X))   :1155-1162, :1009-1020
-            const float a = opA(), x = opX(), y = opY();
-            const int xi = cvtt_f32(x * 2147483648.0f);
-            const float neg = (float)(~xi) * 4.656612873077392578125e-10f;  // exact /2^31
-            finish(a >= y ? x : neg);
+        case H_TSTNEG:  // R = A >= Y ? X : intToFloat(~floatToInt(X))   :1155-1162, :1009-1020
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int xi = cvtt_f32(x.v[k] * 2147483648.0f);
+                const float neg = (float)(~xi) * 4.656612873077392578125e-10f;  // exact /2^31
+                r.v[k] = a.v[k] >= y.v[k] ? x.v[k] : neg;
+            }
             break;
-        }
-        case H_LIMIT: {  // R = A >= Y ? X : Y         :1163-1168
-            const float a = opA(), x = opX(), y = opY();
-            finish(a >= y ? x : y);
+        case H_LIMIT:  // R = A >= Y ? X : Y   :1163-1168
+#pragma unroll
+            for (int k = 0; k < K; ++k) r.v[k] = a.v[k] >= y.v[k] ? x.v[k] : y.v[k];
             break;
-        }
-        case H_LIMITN: {  // R = A < Y ? X : Y         :1169-1174
-            const float a = opA(), x = opX(), y = opY();
-            finish(a < y ? x : y);
+        case H_LIMITN:  // R = A < Y ? X : Y   :1169-1174
+#pragma unroll
+            for (int k = 0; k < K; ++k) r.v[k] = a.v[k] < y.v[k] ? x.v[k] : y.v[k];
             break;
-        }
         case H_LOG:
         case H_EXP: {  // R = (float)linearInterpolate(A, table[(int)X])   :1113-1125; no clamp
-            const float a = opA();
-            int t;
-            if (w0 & F_UX) {
-                t = (int)w3;
-                if (w0 & F_STATIC_OOD) st.ood |= OOD_LUT_TABLE;
-            } else {
-                t = cvtt_f32(ldsRead(c, xOff));
-                if (t < 0 || t > 31) { st.ood |= OOD_LUT_TABLE; t = t < 0 ? 0 : 31; }
-                t += ((w0 & 0xffu) == H_EXP) ? 32 : 0;
+            uint32_t ood[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                ood[k] = 0;
+                int t;
+                if (w0 & F_UX) {
+                    t = (int)w5;
+                    if (w0 & F_STATIC_OOD) ood[k] = OOD_LUT_TABLE;
+                } else {
+                    t = cvtt_f32(x.v[k]);
+                    if (t < 0 || t > 31) { ood[k] = OOD_LUT_TABLE; t = t < 0 ? 0 : 31; }
+                    t += ((w0 & 0xffu) == H_EXP) ? 32 : 0;
+                }
+                r.v[k] = lutInterpolate(c.a->lut, t, a.v[k], ood[k]);
+                if (!run[k]) ood[k] = 0;
             }
-            finish(lutInterpolate(c.a->lut + (size_t)t * 65, a, st.ood));
+            orOod<K>(c, ood);
             break;
         }
         case H_SKIP: {  // if ((float)(int)X == CCR) numSkip = (int)Y   :1175-1179
-            const float x = opX(), y = opY();
-            const float ccr = ldsRead(c, 0);
-            if ((float)cvtt_f32(x) == ccr) st.numSkip = cvtt_f32(y);
+            const Vec<K> ccr = ldsLoad<K>(c.lane, 0);
+            Vec<K> ns = ldsLoad<K>(c.lane, c.a->skipOff);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (run[k] && (float)cvtt_f32(x.v[k]) == ccr.v[k]) ns.v[k] = asF((uint32_t)cvtt_f32(y.v[k]));
+            ldsStore<K>(c.lane, c.a->skipOff, ns);
             break;
         }
-        case H_TRAM_IR: {  // A = readSmallDelay((int)Y)   :1188-1193
-            const int p = cvtt_f32(opY());
-            ldsWrite(c, aOff, tramRead(c.itramLane, c.a->iSlots, c.a->iSize, st.ir, p, st.ood));
+        case H_TRAM_IR:  // A = readSmallDelay((int)Y)   :1188-1193
+            r = tramRead<K>(c, c.itramLane, c.a->iSlots, c.a->iSize, c.a->cursorOff + 1u * ROWB, y, run);
             break;
-        }
-        case H_TRAM_IW: {  // writeSmallDelay(A, (int)Y)   :1194-1198
-            const float v = opA();
-            const int p = cvtt_f32(opY());
-            tramWrite(c.itramLane, c.a->iSlots, c.a->iSize, kMaxITram, st.iw, p, v, st.ood);
+        case H_TRAM_IW:  // writeSmallDelay(A, (int)Y)   :1194-1198
+            tramWrite<K>(c, c.itramLane, c.a->iSlots, c.a->iSize, kMaxITram, c.a->cursorOff, a, y, run);
             break;
-        }
-        case H_TRAM_XR: {  // :1200-1205
-            const int p = cvtt_f32(opY());
-            ldsWrite(c, aOff, tramRead(c.xtramLane, c.a->xSlots, c.a->xSize, st.xr, p, st.ood));
+        case H_TRAM_XR:  // :1200-1205
+            r = tramRead<K>(c, c.xtramLane, c.a->xSlots, c.a->xSize, c.a->cursorOff + 3u * ROWB, y, run);
             break;
-        }
-        case H_TRAM_XW: {  // :1206-1210
-            const float v = opA();
-            const int p = cvtt_f32(opY());
-            tramWrite(c.xtramLane, c.a->xSlots, c.a->xSize, kMaxXTram, st.xw, p, v, st.ood);
-            break;
-        }
-        case H_REFRESH:  // INPUT operand <- this sample's input of A's channel   :1053-1061
-        case H_LATCH:    // outputBuffer[R.IOIndex] = R                           :1229-1233
-            ldsWrite(c, rOff, ldsRead(c, aOff));
+        case H_TRAM_XW:  // :1206-1210
+            tramWrite<K>(c, c.xtramLane, c.a->xSlots, c.a->xSize, kMaxXTram, c.a->cursorOff + 2u * ROWB, a, y, run);
             break;
         case H_NOISE: {  // whitenoise()   :993-1000
-            st.g1 ^= st.g2;
-            const float nz = (float)st.g2 * 4.656612873077392578125e-10f;  // g_fScale = 2.0f/0xffffffff = 2^-31
-            st.g2 = (int)((uint32_t)st.g2 + (uint32_t)st.g1);
-            ldsWrite(c, rOff, nz);
+            Vec<K> g1 = ldsLoad<K>(c.lane, c.a->noiseOff);
+            Vec<K> g2 = ldsLoad<K>(c.lane, c.a->noiseOff + ROWB);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t n1 = asU(g1.v[k]) ^ asU(g2.v[k]);
+                const float nz = (float)(int)asU(g2.v[k]) * 4.656612873077392578125e-10f;  // g_fScale = 2.0f/0xffffffff = 2^-31
+                const uint32_t n2 = asU(g2.v[k]) + n1;
+                r.v[k] = nz;
+                if (run[k]) { g1.v[k] = asF(n1); g2.v[k] = asF(n2); }
+            }
+            ldsStore<K>(c.lane, c.a->noiseOff, g1);
+            ldsStore<K>(c.lane, c.a->noiseOff + ROWB, g2);
             break;
         }
         case H_END:  // :1212-1215
-            if (MULTIPASS) st.isEnd = true;
+            if (MULTIPASS) {
+                Vec<K> e = ldsLoad<K>(c.lane, c.a->aliveOff + ROWB);
+#pragma unroll
+                for (int k = 0; k < K; ++k) if (run[k]) e.v[k] = asF(1u);
+                ldsStore<K>(c.lane, c.a->aliveOff + ROWB, e);
+            }
             break;
         default:  // H_NOP: counted, does nothing (e.g. idelay whose R is neither read nor write)
             break;
     }
+    if (w0 & F_WRITE_R) {
+        if (shadow) {
+            const Vec<K> old = ldsLoad<K>(c.lane, rOff);
+#pragma unroll
+            for (int k = 0; k < K; ++k) r.v[k] = run[k] ? r.v[k] : old.v[k];
+        }
+        ldsStore<K>(c.lane, rOff, r);
+        if (w0 & F_CCR) {  // setCCR(R), source/FX8010.cpp:211-232
+            Vec<K> cc;
+#pragma unroll
+            for (int k = 0; k < K; ++k) cc.v[k] = ccrOf(r.v[k]);
+            if (shadow) {
+                const Vec<K> oldc = ldsLoad<K>(c.lane, 0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) cc.v[k] = run[k] ? cc.v[k] : oldc.v[k];
+            }
+            ldsStore<K>(c.lane, 0, cc);
+        }
+    }
 }
 
-template <bool MULTIPASS>
+struct Rec {
+    uint32_t w0, w1, w2, w3, w4, w5;
+};
+__device__ __forceinline__ Rec fetch(ConstU32 prog, int pc) {
+    ConstU32 p = prog + (size_t)pc * 8;
+    Rec r;
+    r.w0 = p[0]; r.w1 = p[1]; r.w2 = p[2]; r.w3 = p[3]; r.w4 = p[4]; r.w5 = p[5];
+    return r;
+}
+
+template <int K, bool MULTIPASS>
 __global__ __launch_bounds__(64) void fx_step_block(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr uint32_t ROWB = 256u * K;
     const int lane = threadIdx.x;
     const long long wave = blockIdx.x;
-    const long long inst = wave * 64 + lane;
-    const bool live = inst < a.n;
+    const long long inst0 = (wave * 64 + lane) * K;  // first of this lane's K instances
+    const long long left = a.n - inst0;
+    const int nValid = left >= K ? K : (left > 0 ? (int)left : 0);
+    const bool vecIo = (nValid == K) && ((a.n % K) == 0);  // aligned, complete run of K instances
 
-    Ctx c;
-    c.lds = smem + lane * 4;
+    Ctx<K> c;
+    c.lane = smem + lane * 4 * K;
     c.a = &a;
-    c.itramLane = a.itram ? a.itram + (size_t)wave * a.iSlots * 64 + lane : nullptr;
-    c.xtramLane = a.xtram ? a.xtram + (size_t)wave * a.xSlots * 64 + lane : nullptr;
+    c.itramLane = a.itram ? a.itram + ((size_t)wave * a.iSlots * 64 + lane) * K : nullptr;
+    c.xtramLane = a.xtram ? a.xtram + ((size_t)wave * a.xSlots * 64 + lane) * K : nullptr;
 
-    uint32_t* __restrict__ stLane = a.state + inst;  // rows are nPad apart; inst < nPad always
+    ConstU32 rowTable = (ConstU32)a.rowTable;
+    uint32_t* __restrict__ stLane = a.state + inst0;  // rows are nPad apart; inst0+K <= nPad
     const size_t rowStride = (size_t)a.nPad;
 
-    // ---- prologue: state -> LDS rows / VGPRs
+    // ---- prologue: state rows -> LDS rows (nPad is a multiple of 256: always full vectors)
     for (int i = 0; i < a.nLoad; ++i) {
-        const uint32_t e = a.rowTable[i];
-        ldsWrite(c, (e & 0xffffu) * 256u, asF(stLane[(size_t)(e >> 16) * rowStride]));
+        const uint32_t e = rowTable[i];
+        ldsStore<K>(c.lane, (e & 0xffffu) * ROWB, gLoad<K>(reinterpret_cast<const float*>(stLane + (size_t)(e >> 16) * rowStride), true, K));
     }
-    LaneState st;
-    st.numSkip = 0;
-    st.iw = (int)stLane[(size_t)(a.cursorBase + 0) * rowStride];
-    st.ir = (int)stLane[(size_t)(a.cursorBase + 1) * rowStride];
-    st.xw = (int)stLane[(size_t)(a.cursorBase + 2) * rowStride];
-    st.xr = (int)stLane[(size_t)(a.cursorBase + 3) * rowStride];
-    st.g1 = (int)stLane[(size_t)(a.noiseBase + 0) * rowStride];
-    st.g2 = (int)stLane[(size_t)(a.noiseBase + 1) * rowStride];
-    st.ood = 0;
-    st.dynCount = 0;
-    st.ran = true;
-    st.alive = true;
-    st.isEnd = false;
+    for (int i = 0; i < a.nZero; ++i) ldsStore<K>(c.lane, rowTable[a.nLoad + a.nStore + i] * ROWB, splat<K>(0.0f));
 
     const size_t n = (size_t)a.n;
     const int CH = a.channels;
-    float nextIn[kMaxChannels];
+    Vec<K> nextIn[kMaxChannels];
 #pragma unroll
     for (int ch = 0; ch < kMaxChannels; ++ch)
-        nextIn[ch] = (ch < CH && a.inRow[ch] >= 0 && live && a.nSamples > 0) ? a.in[(size_t)ch * n + inst] : 0.0f;
+        nextIn[ch] = (ch < CH && a.inRow[ch] >= 0 && a.nSamples > 0) ? gLoad<K>(a.in + (size_t)ch * n + inst0, vecIo, nValid) : splat<K>(0.0f);
+
+    bool allRun[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) allRun[k] = true;
 
     for (int s = 0; s < a.nSamples; ++s) {
 #pragma unroll
         for (int ch = 0; ch < kMaxChannels; ++ch)
-            if (ch < CH && a.inRow[ch] >= 0) ldsWrite(c, (uint32_t)a.inRow[ch] * 256u, nextIn[ch]);
+            if (ch < CH && a.inRow[ch] >= 0) ldsStore<K>(c.lane, (uint32_t)a.inRow[ch] * ROWB, nextIn[ch]);
         if (s + 1 < a.nSamples) {
 #pragma unroll
             for (int ch = 0; ch < kMaxChannels; ++ch)
-                if (ch < CH && a.inRow[ch] >= 0 && live) nextIn[ch] = a.in[((size_t)(s + 1) * CH + ch) * n + inst];
+                if (ch < CH && a.inRow[ch] >= 0) nextIn[ch] = gLoad<K>(a.in + ((size_t)(s + 1) * CH + ch) * n + inst0, vecIo, nValid);
         }
 
-        const uint32_t* __restrict__ prog = (s == a.nSamples - 1) ? a.last : a.steady;
-        st.numSkip = 0;  // reference: local to process(), FX8010.cpp:1030
-        if (MULTIPASS) { st.alive = true; st.isEnd = false; }
+        ConstU32 prog = (ConstU32)((s == a.nSamples - 1) ? a.last : a.steady);
+        if (a.hasShadow) ldsStore<K>(c.lane, a.skipOff, splat<K>(0.0f));  // numSkip is local to process(), FX8010.cpp:1030
+        if (MULTIPASS) {
+            ldsStore<K>(c.lane, a.aliveOff, splat<K>(asF(1u)));
+            ldsStore<K>(c.lane, a.aliveOff + ROWB, splat<K>(0.0f));
+        }
         int passes = 0;
         bool again;
         do {
+            Rec cur = fetch(prog, 0);
             for (int pc = 0; pc < a.nOps; ++pc) {
-                const uint32_t* __restrict__ rec = prog + (size_t)pc * 8;
-                const uint32_t w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], w4 = rec[4], w5 = rec[5], w6 = rec[6];
+                const Rec nxt = fetch(prog, pc + 1 < a.nOps ? pc + 1 : pc);  // prefetch one record ahead
+                const uint32_t w0 = cur.w0;
                 if (w0 & F_SHADOW) {
-                    bool run;
-                    if (w0 & F_POSTFIX) run = st.ran;
-                    else {
-                        run = (st.numSkip == 0);
-                        if (MULTIPASS) run = run && st.alive;
-                        if (!(w0 & F_PREFIX)) {
+                    bool run[K];
+                    bool any = false;
+                    if (w0 & F_POSTFIX) {
+                        const Vec<K> ran = ldsLoad<K>(c.lane, a.skipOff + ROWB);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { run[k] = asU(ran.v[k]) != 0; any = any || run[k]; }
+                    } else {
+                        Vec<K> ns = ldsLoad<K>(c.lane, a.skipOff);
+                        Vec<K> alive = splat<K>(0.0f);
+                        if (MULTIPASS) alive = ldsLoad<K>(c.lane, a.aliveOff);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int v = (int)asU(ns.v[k]);
+                            const bool live = MULTIPASS ? (asU(alive.v[k]) != 0) : true;
+                            run[k] = live && v == 0;
+                            any = any || run[k];
                             // a skipped instruction only counts the skip down (FX8010.cpp:1235-1241)
-                            const bool countDown = MULTIPASS ? (st.alive && !run) : !run;
-                            if (countDown) st.numSkip = st.numSkip > 0 ? st.numSkip - 1 : 0;
-                            st.ran = run;
-                            st.dynCount += run ? 1u : 0u;
+                            if (live && !run[k]) ns.v[k] = asF((uint32_t)(v > 0 ? v - 1 : 0));
+                        }
+                        if (!(w0 & F_PREFIX)) {
+                            ldsStore<K>(c.lane, a.skipOff, ns);
+                            Vec<K> ran, dyn = ldsLoad<K>(c.lane, a.skipOff + 2 * ROWB);
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { ran.v[k] = asF(run[k] ? 1u : 0u); dyn.v[k] = asF(asU(dyn.v[k]) + (run[k] ? 1u : 0u)); }
+                            ldsStore<K>(c.lane, a.skipOff + ROWB, ran);
+                            ldsStore<K>(c.lane, a.skipOff + 2 * ROWB, dyn);
                         }
                     }
-                    if (run) execOp<MULTIPASS>(c, st, w0, w1, w2, w3, w4, w5, w6);
+                    if (__any(any)) execOp<K, MULTIPASS>(c, w0, cur.w1, cur.w2, cur.w3, cur.w4, cur.w5, run, true);
                 } else {
-                    execOp<MULTIPASS>(c, st, w0, w1, w2, w3, w4, w5, w6);
+                    execOp<K, MULTIPASS>(c, w0, cur.w1, cur.w2, cur.w3, cur.w4, cur.w5, allRun, false);
                 }
+                cur = nxt;
             }
             again = false;
             if (MULTIPASS) {
-                st.alive = st.alive && !st.isEnd;
+                Vec<K> alive = ldsLoad<K>(c.lane, a.aliveOff);
+                const Vec<K> ended = ldsLoad<K>(c.lane, a.aliveOff + ROWB);
+                bool anyAlive = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool al = asU(alive.v[k]) != 0 && asU(ended.v[k]) == 0;
+                    alive.v[k] = asF(al ? 1u : 0u);
+                    anyAlive = anyAlive || al;
+                }
+                ldsStore<K>(c.lane, a.aliveOff, alive);
                 ++passes;
-                again = __any(st.alive) && passes < kPassCap;
-                if (!again && st.alive) st.ood |= OOD_PASS_CAP;
+                again = __any(anyAlive) && passes < kPassCap;
+                if (!again && __any(anyAlive)) {
+                    uint32_t ood[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) ood[k] = asU(alive.v[k]) ? OOD_PASS_CAP : 0u;
+                    orOod<K>(c, ood);
+                }
             }
         } while (again);
 
-        if (live) {
 #pragma unroll
-            for (int ch = 0; ch < kMaxChannels; ++ch)
-                if (ch < CH) a.out[((size_t)s * CH + ch) * n + inst] = ldsRead(c, (uint32_t)a.latchRow[ch] * 256u);
-        }
+        for (int ch = 0; ch < kMaxChannels; ++ch)
+            if (ch < CH) gStore<K>(a.out + ((size_t)s * CH + ch) * n + inst0, ldsLoad<K>(c.lane, (uint32_t)a.latchRow[ch] * ROWB), vecIo, nValid);
     }
 
-    // ---- epilogue: LDS rows / VGPRs -> state
+    // ---- epilogue: LDS rows -> state rows
     for (int i = 0; i < a.nStore; ++i) {
-        const uint32_t e = a.rowTable[a.nLoad + i];
-        stLane[(size_t)(e >> 16) * rowStride] = asU(ldsRead(c, (e & 0xffffu) * 256u));
+        const uint32_t e = rowTable[a.nLoad + i];
+        gStore<K>(reinterpret_cast<float*>(stLane + (size_t)(e >> 16) * rowStride), ldsLoad<K>(c.lane, (e & 0xffffu) * ROWB), true, K);
     }
-    stLane[(size_t)(a.cursorBase + 0) * rowStride] = (uint32_t)st.iw;
-    stLane[(size_t)(a.cursorBase + 1) * rowStride] = (uint32_t)st.ir;
-    stLane[(size_t)(a.cursorBase + 2) * rowStride] = (uint32_t)st.xw;
-    stLane[(size_t)(a.cursorBase + 3) * rowStride] = (uint32_t)st.xr;
-    stLane[(size_t)(a.noiseBase + 0) * rowStride] = (uint32_t)st.g1;
-    stLane[(size_t)(a.noiseBase + 1) * rowStride] = (uint32_t)st.g2;
-    stLane[(size_t)a.oodRow * rowStride] |= st.ood;
-    const unsigned long long add = (unsigned long long)a.staticCount * (unsigned long long)a.nSamples + st.dynCount;
-    unsigned long long cnt = ((unsigned long long)stLane[(size_t)a.countHi * rowStride] << 32) | stLane[(size_t)a.countLo * rowStride];
-    cnt += add;
-    stLane[(size_t)a.countLo * rowStride] = (uint32_t)cnt;
-    stLane[(size_t)a.countHi * rowStride] = (uint32_t)(cnt >> 32);
+    const Vec<K> oodv = ldsLoad<K>(c.lane, a.oodOff);
+    Vec<K> dyn = splat<K>(0.0f);
+    if (a.hasShadow) dyn = ldsLoad<K>(c.lane, a.skipOff + 2 * ROWB);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        stLane[(size_t)a.oodRow * rowStride + k] |= asU(oodv.v[k]);
+        const unsigned long long add = (unsigned long long)a.staticCount * (unsigned long long)a.nSamples + asU(dyn.v[k]);
+        unsigned long long cnt = ((unsigned long long)stLane[(size_t)a.countHi * rowStride + k] << 32) | stLane[(size_t)a.countLo * rowStride + k];
+        cnt += add;
+        stLane[(size_t)a.countLo * rowStride + k] = (uint32_t)cnt;
+        stLane[(size_t)a.countHi * rowStride + k] = (uint32_t)(cnt >> 32);
+    }
 }
 
 __global__ void fx_fill_rows(uint32_t* state, long long nPad, const uint32_t* rows, const uint32_t* values, int nRows) {
@@ -405,18 +573,28 @@ __global__ void fx_reduce_row(const uint32_t* state, long long nPad, long long n
     }
 }
 
-}  // namespace
-
-hipError_t launchStepBlock(const KernelArgs& a, bool multipass, hipStream_t stream) {
-    const unsigned grid = (unsigned)(a.nPad / 64);
-    const size_t ldsBytes = (size_t)a.nRows * 256;
-    auto kern = multipass ? fx_step_block<true> : fx_step_block<false>;
+template <int K>
+hipError_t launchK(const KernelArgs& a, bool multipass, hipStream_t stream) {
+    const unsigned grid = (unsigned)((a.n + 64 * K - 1) / (64 * K));
+    const size_t ldsBytes = (size_t)a.nRows * 256 * K;
+    auto kern = multipass ? fx_step_block<K, true> : fx_step_block<K, false>;
     if (ldsBytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), ldsBytes, stream, a);
     return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launchStepBlock(const KernelArgs& a, bool multipass, hipStream_t stream) {
+    switch (a.instPerLane) {
+        case 1: return launchK<1>(a, multipass, stream);
+        case 2: return launchK<2>(a, multipass, stream);
+        case 4: return launchK<4>(a, multipass, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launchFillRows(uint32_t* state, long long nPad, const uint32_t* d_rows, const uint32_t* d_values, int nRows,

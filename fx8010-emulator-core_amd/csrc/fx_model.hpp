@@ -83,4 +83,25 @@ struct Luts {
     Luts();
 };
 
+// Device form of the LOG/EXP evaluation.  The reference computes, per call
+// (linearInterpolate, source/FX8010.cpp:283-296):
+//     idx = (int)((x - -1.0) / step);  x1 = -1.0 + idx*step;  x2 = -1.0 + (idx+1)*step;
+//     y   = (y2 - y1) / (x2 - x1) * (x - x1) + y1
+// Everything except the last multiply-add depends only on (table, idx), and idx is a monotone
+// step function of t = x + 1.0.  So the two fp64 divisions are done here, once, with the very
+// same IEEE operations, and the kernel only compares against thresholds and does one mul + add:
+//   thr[k]   k = 0..64 : smallest double t with (int)(t / step) >= k   (thr[0] = 0, thr[64] = +inf)
+//   x1[k]    k = 0..63 : -1.0 + k*step
+//   seg[table][k]      : { (y2 - y1) / (x2 - x1), y1 }   table 0..31 LOG, 32..63 EXP
+// Blob layout (doubles): thr[65] | pad to 66 | x1[64] | seg[64][64][2]   => kLutBlobDoubles.
+constexpr int kLutThrOff = 0;
+constexpr int kLutX1Off = 66;
+constexpr int kLutSegOff = 66 + 64;
+constexpr int kLutBlobDoubles = kLutSegOff + 64 * 64 * 2;
+struct LutDevice {
+    std::vector<double> blob;
+    double invStep;  // 63/2: only used to guess idx, the thresholds decide
+    explicit LutDevice(const Luts& l);
+};
+
 }  // namespace fx

@@ -12,6 +12,13 @@ from pyoracle import Oracle
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=[1, 2, 4], ids=["k1", "k2", "k4"])
+def k(request, monkeypatch):
+    """instances stepped per lane (kernel variant); FX_INST_PER_LANE pins the library's choice"""
+    monkeypatch.setenv("FX_INST_PER_LANE", str(request.param))
+    return request.param
+
 HDR = "static a\nstatic b\ninput in 0\noutput out 0\nstatic noise\nstatic rd\ncontrol vol = 0.5\n"
 
 
@@ -60,16 +67,17 @@ def check_batch(gpu, text, x, regs=("ccr",), channels=1, instances=None, blocks=
 
 
 @pytest.mark.parametrize("name", ["config1_shipped", "config1_logtube", "config2", "config3", "config4", "config5"])
-def test_config_programs_bit_exact(gpu, name):
+def test_config_programs_bit_exact(gpu, name, k):
     text = progs.CONFIGS[name]()
     N, S = 130, 257  # ragged last wavefront, odd block length
     x = progs.stimulus(N, S)
     regs = {"config2": ("t", "s30", "in", "out", "ccr"), "config3": ("rd", "a", "t", "ccr"), "config4": ("x", "a", "b", "o", "ccr"),
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
-    check_batch(gpu, text, x, regs=regs)
+    b, _ = check_batch(gpu, text, x, regs=regs)
+    assert b.info("inst_per_lane") == k
 
 
-def test_block_boundaries_do_not_matter(gpu):
+def test_block_boundaries_do_not_matter(gpu, k):
     text = progs.config3()
     x = progs.stimulus(70, 1200)  # > 1000-sample delay: the feedback path wraps
     _, y1 = check_batch(gpu, text, x, instances=[0, 69], regs=("rd", "ccr"))
@@ -121,7 +129,7 @@ OPCODE_PROGRAMS = {
 
 
 @pytest.mark.parametrize("name", sorted(OPCODE_PROGRAMS))
-def test_opcode_programs(gpu, name):
+def test_opcode_programs(gpu, name, k):
     text = HDR + OPCODE_PROGRAMS[name] + "\nend"
     S, N = 48, 70
     ramp = np.array([i / 16.0 for i in range(-16, 16)] + [1.0, -1.0, 0.0, -0.0, 1e-39, -1e-39, 0.999999, -0.999999] * 2, dtype=np.float32)
@@ -129,7 +137,28 @@ def test_opcode_programs(gpu, name):
     check_batch(gpu, text, x, regs=("a", "b", "out", "ccr", "in"))
 
 
-def test_delay_line_exact(gpu):
+@pytest.mark.parametrize("op,table", [("log", 1), ("log", 3), ("log", 16), ("log", 31), ("exp", 0), ("exp", 2), ("exp", 7), ("exp", 31)])
+def test_log_exp_dense_sweep(gpu, op, table):
+    """LOG/EXP on the device use precomputed thresholds/slopes instead of the reference's two fp64
+    divisions: sweep random x, every table knot and its float neighbours, the domain edges."""
+    text = HDR + "%s out, in, %d, 0\nend" % (op, table)
+    rng = np.random.default_rng(table * 7 + len(op))
+    knots = (-1.0 + np.arange(64, dtype=np.float64) * (2.0 / 63.0)).astype(np.float32)
+    near = [knots]
+    for d in (1, 2, 3):
+        up, dn = knots.copy(), knots.copy()
+        for _ in range(d):
+            up = np.nextafter(up, np.float32(2.0)); dn = np.nextafter(dn, np.float32(-2.0))
+        near += [up, dn]
+    special = np.clip(np.concatenate(near + [np.array([1.0, -1.0, 0.0, -0.0, 1e-30, -1e-30, 1e-42, 0.99999994, -0.99999994], dtype=np.float32)]), -1.0, 1.0)
+    S, N = 48, 128
+    x = rng.uniform(-1.0, 1.0, size=S * N).astype(np.float32)
+    x[:special.size] = special
+    x = x.reshape(S, N)
+    check_batch(gpu, text, x, regs=("out", "ccr"), instances=range(0, N, 1))
+
+
+def test_delay_line_exact(gpu, k):
     text = "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend"
     x = progs.stimulus(66, 64)
     check_batch(gpu, text, x, regs=("rd", "ccr"))
@@ -137,7 +166,7 @@ def test_delay_line_exact(gpu):
     check_batch(gpu, text, x, regs=("rd", "b", "a"))
 
 
-def test_delay_write_offset_and_ood(gpu):
+def test_delay_write_offset_and_ood(gpu, k):
     # write offset 3 stays inside the reference's array (wpos+3 < 8192) and lands beyond `size`
     text = "itramsize 8 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 3\nmacs out, 0, rd, 1.0\nend"
     x = progs.stimulus(64, 40)
@@ -147,7 +176,7 @@ def test_delay_write_offset_and_ood(gpu):
     check_batch(gpu, text, x, regs=("rd",), expect_ood=1)
 
 
-def test_skip_over_end_multipass(gpu):
+def test_skip_over_end_multipass(gpu, k):
     # the SKIP can jump over END: the reference re-runs the program with the leftover count
     text = HDR + "macs a, in, 0, 0\nmacs out, out, 0.125, 0.5\nskip ccr, ccr, 6, 2\nmacs b, in, 0.5, 0.5\nend"
     x = progs.stimulus(70, 50)
@@ -155,7 +184,7 @@ def test_skip_over_end_multipass(gpu):
     assert b.info("multipass") == 1
 
 
-def test_stereo_and_input_channel_quirk(gpu):
+def test_stereo_and_input_channel_quirk(gpu, k):
     # X and Y inputs are read through A's channel (source/FX8010.cpp:1058,1060)
     text = ("input l 0\ninput r 1\noutput ol 0\noutput or 1\nstatic t\n"
             "macs ol, l, r, 0.5\nmacs or, r, l, 0.5\nmacs t, 0, r, 1.0\nmacs or, or, t, 0.25\nend")
@@ -164,7 +193,7 @@ def test_stereo_and_input_channel_quirk(gpu):
     check_batch(gpu, text, x, regs=("l", "r", "t", "ccr"), channels=2)
 
 
-def test_set_register_broadcast_and_per_instance(gpu):
+def test_set_register_broadcast_and_per_instance(gpu, k):
     text = progs.config1_shipped()
     N, S = 70, 32
     ramp = np.array([i / 16.0 for i in range(-16, 16)], dtype=np.float32)
@@ -194,7 +223,7 @@ def test_set_register_broadcast_and_per_instance(gpu):
     assert b.get_register_i("nonexistent", 0) == 1.0
 
 
-def test_noise_seed_per_instance(gpu):
+def test_noise_seed_per_instance(gpu, k):
     text = HDR + "macs out, 0, noise, 1.0\nend"
     N, S = 66, 40
     x = np.zeros((S, N), dtype=np.float32)
