@@ -1,0 +1,126 @@
+// fx_asm.cpp — record encoding for, and launching of, the hand-written gfx950 interpreter.
+#include "fx_asm.hpp"
+
+#include <cstring>
+#include <mutex>
+
+#include "fx_kernel.hpp"
+#include "fx_model.hpp"
+
+namespace fx {
+namespace {
+
+// the linked code object of fx_interp_gfx950.s, embedded by the Makefile
+const unsigned char kInterpBlob[] = {
+#include "build/fx_interp_blob.inc"
+};
+
+inline uint32_t handlerOf(const MicroOp& m) { return m.w[0] & 0xffu; }
+inline bool has(const MicroOp& m, uint32_t f) { return (m.w[0] & f) != 0; }
+
+}  // namespace
+
+bool asmEligible(const Lowered& low, std::string* why) {
+    auto no = [&](const char* w) { if (why) *why = w; return false; };
+    if (low.instPerLane != 1) return no("more than one instance per lane");
+    if (low.multipass) return no("END can be skipped (multi-pass program)");
+    if ((size_t)low.nRows * 256 > 64 * 1024) return no("register file above 64 KiB of LDS");
+    for (const MicroOp& m : low.steady) {
+        const uint32_t h = handlerOf(m);
+        if ((h == H_LOG || h == H_EXP) && (!has(m, F_UX) || has(m, F_STATIC_OOD))) return no("LOG/EXP with a per-instance or out-of-range table");
+    }
+    return true;
+}
+
+std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
+    std::vector<MicroOp> out;
+    out.reserve(ops.size() + ops.size() / 2 + 2);
+    auto bare = [&](uint32_t slot) {
+        MicroOp r{};
+        r.w[0] = slot * 4;
+        out.push_back(r);
+    };
+    bool predOpen = false;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const MicroOp& m = ops[i];
+        // a group = [prefix ops] main [postfix op]; it starts at the first prefix, or at a main op not preceded by one
+        const bool groupStart = !has(m, F_POSTFIX) && (i == 0 || !has(ops[i - 1], F_PREFIX));
+        if (groupStart) {
+            if (has(m, F_SHADOW)) { bare(AS_PRED); predOpen = true; }   // PRED re-opens EXEC itself
+            else if (predOpen) { bare(AS_UNPRED); predOpen = false; }
+        }
+        const uint32_t h = handlerOf(m);
+        const uint32_t kind = (has(m, F_UA) ? 1u : 0u) | (has(m, F_UX) ? 2u : 0u) | (has(m, F_UY) ? 4u : 0u);
+        const uint32_t ccr = has(m, F_CCR) ? 1u : 0u;
+        MicroOp r{};
+        r.w[1] = m.w[1];
+        r.w[2] = m.w[2];
+        r.w[3] = m.w[3];
+        r.w[4] = m.w[4];
+        r.w[5] = kind | (ccr << 3);
+        uint32_t slot = AS_NOP;
+        switch (h) {
+            case H_MACS: slot = AS_MACS + kind * 2 + ccr; break;
+            case H_MACSN: slot = AS_MACSN + kind * 2 + ccr; break;
+            case H_ACC3: slot = AS_ACC3 + kind * 2 + ccr; break;
+            case H_INTERP: {
+                slot = AS_INTERP + kind * 2 + ccr;
+                if (kind & 2u) {  // uniform X: (1.0 - (double)X) is the same for every instance
+                    float x;
+                    std::memcpy(&x, &m.w[3], 4);
+                    const double omx = 1.0 - (double)x;
+                    std::memcpy(&r.w[6], &omx, 8);
+                }
+                break;
+            }
+            case H_MACW: slot = AS_MACW; break;
+            case H_MACWN: slot = AS_MACWN; break;
+            case H_MACINTW: slot = AS_MACINTW; break;
+            case H_MOV: slot = AS_MOV; break;
+            case H_ANDXOR: slot = AS_ANDXOR; break;
+            case H_TSTNEG: slot = AS_TSTNEG; break;
+            case H_LIMIT: slot = AS_LIMIT; break;
+            case H_LIMITN: slot = AS_LIMITN; break;
+            case H_LOG:
+            case H_EXP:
+                slot = AS_LUT;
+                r.w[3] = (uint32_t)((kLutSegOff + (size_t)m.w[5] * 128) * 8);  // this table's {slope, y1}[64]
+                break;
+            case H_SKIP: slot = AS_SKIP; break;
+            case H_TRAM_IR: slot = AS_TRAM_IR; break;
+            case H_TRAM_IW: slot = AS_TRAM_IW; break;
+            case H_TRAM_XR: slot = AS_TRAM_XR; break;
+            case H_TRAM_XW: slot = AS_TRAM_XW; break;
+            case H_NOISE: slot = AS_NOISE; break;
+            default: slot = AS_NOP; break;  // END (single pass) and NOP only count
+        }
+        r.w[0] = slot * 4;
+        out.push_back(r);
+    }
+    bare(AS_ENDSAMPLE);
+    bare(AS_NOP);  // pad: the fetch runs one record ahead
+    return out;
+}
+
+hipError_t launchAsmInterp(const AsmArgs& args, size_t ldsBytes, int device, hipStream_t stream) {
+    static std::mutex mu;
+    static hipModule_t modules[64] = {};
+    static hipFunction_t funcs[64] = {};
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!funcs[device]) {
+            hipError_t e = hipModuleLoadData(&modules[device], kInterpBlob);
+            if (e != hipSuccess) return e;
+            e = hipModuleGetFunction(&funcs[device], modules[device], "fx_interp_k1");
+            if (e != hipSuccess) return e;
+        }
+    }
+    AsmArgs a = args;
+    size_t size = sizeof(a);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    const unsigned grid = (unsigned)((args.n + 63) / 64);
+    return hipModuleLaunchKernel(funcs[device], grid, 1, 1, 64, 1, 1, (unsigned)ldsBytes, stream, nullptr, config);
+}
+
+}  // namespace fx

@@ -1,0 +1,69 @@
+// fx_asm.hpp — host side of the hand-written gfx950 interpreter (fx_interp_gfx950.s):
+// record encoding, code-object loading and launch.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fx_decode.hpp"
+
+namespace fx {
+
+// kernarg block of fx_interp_k1 — offsets are the KA_* constants in fx_interp_gfx950.s
+struct AsmArgs {
+    const uint32_t* steady;
+    const uint32_t* last;
+    const uint32_t* rowTable;
+    uint32_t* state;
+    const float* in;
+    float* out;
+    float* itram;
+    float* xtram;
+    const double* lut;
+    long long n;
+    long long nPad;
+    int nLoad, nStore;
+    int nSamples, channels;
+    int inOff[4];
+    int latchOff[4];
+    int iSlots, xSlots, iSize, xSize;
+    int cursorRow, noiseRow;
+    int oodRow, countLo, countHi, staticCount;
+    int lutX1Off;
+    int pad_;
+};
+static_assert(offsetof(AsmArgs, lut) == 0x40, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, nLoad) == 0x58, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, nSamples) == 0x60, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, inOff) == 0x68, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, latchOff) == 0x78, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, iSlots) == 0x88, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, cursorRow) == 0x98, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, oodRow) == 0xa0, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, lutX1Off) == 0xb0, "AsmArgs layout");
+static_assert(sizeof(AsmArgs) == 0xb8, "AsmArgs layout");
+
+// branch-table slots of fx_interp_gfx950.s (jump_table)
+enum AsmSlot : uint32_t {
+    AS_ENDSAMPLE = 0, AS_NOP = 1, AS_PRED = 2, AS_UNPRED = 3, AS_MOV = 4, AS_MACW = 5, AS_MACWN = 6, AS_MACINTW = 7,
+    AS_ANDXOR = 8, AS_TSTNEG = 9, AS_LIMIT = 10, AS_LIMITN = 11, AS_LUT = 12, AS_SKIP = 13, AS_TRAM_IR = 14,
+    AS_TRAM_IW = 15, AS_TRAM_XR = 16, AS_TRAM_XW = 17, AS_NOISE = 18,
+    AS_MACS = 20, AS_MACSN = 36, AS_ACC3 = 52, AS_INTERP = 68  // + kind*2 + ccr, kind = UA | UX<<1 | UY<<2
+};
+
+// Can this lowering (K = 1, bookkeeping in VGPRs) run on the assembly kernel?  `why` says why not.
+bool asmEligible(const Lowered& low, std::string* why);
+
+// Translate one lowered stream into the assembly kernel's records (SKIP shadows become PRED/UNPRED
+// brackets, the stream ends with ENDSAMPLE plus one pad record for the fetch-ahead).
+std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops);
+
+// Loads the embedded code object on the current device (once per device) and launches
+// fx_interp_k1 with ceil(n/64) single-wavefront workgroups and ldsBytes of dynamic LDS.
+hipError_t launchAsmInterp(const AsmArgs& args, size_t ldsBytes, int device, hipStream_t stream);
+
+}  // namespace fx

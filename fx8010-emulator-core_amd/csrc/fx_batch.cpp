@@ -204,9 +204,23 @@ int Batch::ensureLowered() {
     if (!loaded_ || !prog_.ready) return fail(FX_E_NOTREADY, "no program loaded");
     if (!lowDirty_) return 0;
     std::vector<int> before = low_.rowOfReg;
-    Lowered fresh = lowerProgram(prog_, hostValue_, forcedLane_, chooseInstPerLane());
+    // Preferred: the hand-written gfx950 interpreter (one instance per lane, bookkeeping in VGPRs).
+    // Programs it does not cover run on the HIP C++ kernel.  TRAM tiling pins K once allocated.
+    Lowered fresh;
+    bool asmOk = false;
+    const bool tramPinned = iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0;
+    const char* forceHip = std::getenv("FX_KERNEL");
+    const bool wantAsm = !(forceHip && std::strcmp(forceHip, "hip") == 0) && !std::getenv("FX_INST_PER_LANE");
+    if (wantAsm && (!tramPinned || instPerLane_ == 1)) {
+        fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false);
+        asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
+    } else {
+        asmWhyNot_ = "disabled by FX_KERNEL / FX_INST_PER_LANE";
+    }
+    if (!asmOk) fresh = lowerProgram(prog_, hostValue_, forcedLane_, chooseInstPerLane());
     if (!fresh.error.empty()) return fail(FX_E_PROGRAM, fresh.error);
     instPerLane_ = fresh.instPerLane;
+    useAsm_ = asmOk;
     int rc = ensureState();
     if (rc != 0) return rc;
     // registers that were uniform and are per-instance from now on: seed their rows
@@ -221,6 +235,10 @@ int Batch::ensureLowered() {
     if ((rc = ensureTram()) != 0) return rc;
 
     // upload: steady | last | row table
+    if (useAsm_) {
+        low_.steady = encodeAsmStream(low_.steady);
+        low_.last = encodeAsmStream(low_.last);
+    }
     const size_t nOps = low_.steady.size();
     const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size();
     if (words > streamCap_) {
@@ -339,7 +357,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     a.skipOff = low_.skipRow >= 0 ? (uint32_t)low_.skipRow * rowBytes : 0;
     a.cursorOff = low_.cursorRow >= 0 ? (uint32_t)low_.cursorRow * rowBytes : 0;
     a.noiseOff = low_.noiseRow >= 0 ? (uint32_t)low_.noiseRow * rowBytes : 0;
-    a.oodOff = (uint32_t)low_.oodRow * rowBytes;
+    a.oodOff = low_.oodRow >= 0 ? (uint32_t)low_.oodRow * rowBytes : 0;
     a.aliveOff = low_.aliveRow >= 0 ? (uint32_t)low_.aliveRow * rowBytes : 0;
     a.hasShadow = low_.skipRow >= 0 ? 1 : 0;
     a.instPerLane = instPerLane_;
@@ -349,7 +367,26 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     a.staticCount = low_.staticCount;
     a.nRows = low_.nRows;
     hipError_t e = hipEventRecord(ev0_, s);
-    if (e == hipSuccess) e = launchStepBlock(a, low_.multipass, s);
+    if (e == hipSuccess) {
+        if (useAsm_) {
+            AsmArgs g{};
+            g.steady = a.steady; g.last = a.last; g.rowTable = a.rowTable; g.state = a.state;
+            g.in = a.in; g.out = a.out; g.itram = a.itram; g.xtram = a.xtram; g.lut = a.lut;
+            g.n = a.n; g.nPad = a.nPad; g.nLoad = a.nLoad; g.nStore = a.nStore;
+            g.nSamples = a.nSamples; g.channels = a.channels;
+            for (int c = 0; c < kMaxChannels; ++c) {
+                g.inOff[c] = a.inRow[c] >= 0 ? a.inRow[c] * 256 : -1;
+                g.latchOff[c] = a.latchRow[c] * 256;
+            }
+            g.iSlots = a.iSlots; g.xSlots = a.xSlots; g.iSize = a.iSize; g.xSize = a.xSize;
+            g.cursorRow = stateLayout_.cursorBase; g.noiseRow = stateLayout_.noiseBase;
+            g.oodRow = a.oodRow; g.countLo = a.countLo; g.countHi = a.countHi; g.staticCount = a.staticCount;
+            g.lutX1Off = kLutX1Off * 8;
+            e = launchAsmInterp(g, (size_t)a.nRows * 256, device_, s);
+        } else {
+            e = launchStepBlock(a, low_.multipass, s);
+        }
+    }
     if (e == hipSuccess) e = hipEventRecord(ev1_, s);
     if (e != hipSuccess) return hipFail(e, "launch fx_step_block");
     lastStream_ = s;
@@ -450,6 +487,7 @@ int64_t Batch::info(int what) {
     if (ensureLowered() != 0) return -1;
     switch (what) {
         case FXB_INFO_INST_PER_LANE: return instPerLane_;
+        case FXB_INFO_KERNEL: return useAsm_ ? 1 : 0;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
         case FXB_INFO_LDS_BYTES_PER_WG: return (int64_t)low_.nRows * 256 * instPerLane_;

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "fx_asm.hpp"
 #include "fx_decode.hpp"
 #include "fx_kernel.hpp"
 #include "fx_model.hpp"
@@ -78,6 +79,8 @@ private:
     float* dXTram_ = nullptr;
     int iSlotsAlloc_ = 0, xSlotsAlloc_ = 0;
     int instPerLane_ = 1;
+    bool useAsm_ = false;          // the current lowering runs on the hand-written gfx950 kernel
+    std::string asmWhyNot_;
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;
     size_t streamCap_ = 0;

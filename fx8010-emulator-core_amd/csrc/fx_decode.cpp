@@ -33,7 +33,8 @@ StateLayout makeLayout(int nRegs, int channels) {
     return L;
 }
 
-Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, const std::vector<uint8_t>& forcedLane, int instPerLane) {
+Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, const std::vector<uint8_t>& forcedLane, int instPerLane,
+                     bool ldsBookkeeping) {
     Lowered out;
     out.instPerLane = instPerLane;
     const uint32_t rowBytes = 256u * (uint32_t)instPerLane;
@@ -136,12 +137,14 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
     // bookkeeping rows, only what this program needs
     bool anyShadow = false;  // a SKIP writes numSkip even when its count is statically 0
     for (int k = 0; k < P; ++k) anyShadow = anyShadow || shadow[k] || prog.instrs[k].op == SKIP;
-    out.oodRow = nextRow++;
-    out.zeroRows.push_back(out.oodRow);
-    if (anyShadow) { out.skipRow = nextRow; nextRow += 3; for (int q = 0; q < 3; ++q) out.zeroRows.push_back(out.skipRow + q); }
-    if (out.usesITram || out.usesXTram) { out.cursorRow = nextRow; nextRow += 4; }
-    if (out.usesNoise) { out.noiseRow = nextRow; nextRow += 2; }
-    if (out.multipass) { out.aliveRow = nextRow; nextRow += 2; out.zeroRows.push_back(out.aliveRow); out.zeroRows.push_back(out.aliveRow + 1); }
+    if (ldsBookkeeping) {
+        out.oodRow = nextRow++;
+        out.zeroRows.push_back(out.oodRow);
+        if (anyShadow) { out.skipRow = nextRow; nextRow += 3; for (int q = 0; q < 3; ++q) out.zeroRows.push_back(out.skipRow + q); }
+        if (out.usesITram || out.usesXTram) { out.cursorRow = nextRow; nextRow += 4; }
+        if (out.usesNoise) { out.noiseRow = nextRow; nextRow += 2; }
+        if (out.multipass) { out.aliveRow = nextRow; nextRow += 2; out.zeroRows.push_back(out.aliveRow); out.zeroRows.push_back(out.aliveRow + 1); }
+    }
     out.nRows = nextRow;
     for (int r = 0; r < nRegs; ++r) (lane[r] ? out.nLaneRegs : out.nUniformRegs)++;
     if ((long)out.nRows * rowBytes > 160 * 1024) {

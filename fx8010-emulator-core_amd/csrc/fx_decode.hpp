@@ -101,8 +101,10 @@ struct Lowered {
 // forcedLane[r] != 0 keeps register r per-instance even if no instruction writes it
 // (set after fxb_set_register_i gave instances different values).
 // instPerLane (K) fixes the LDS row pitch (256*K bytes) the record offsets are expressed in.
+// ldsBookkeeping: give skip counter / TRAM cursors / LFSR / flags their own LDS rows (the HIP C++
+// kernel); false keeps them out of the register file (the assembly kernel holds them in VGPRs).
 Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue,
-                     const std::vector<uint8_t>& forcedLane, int instPerLane);
+                     const std::vector<uint8_t>& forcedLane, int instPerLane, bool ldsBookkeeping = true);
 
 StateLayout makeLayout(int nRegs, int channels);
 

@@ -144,7 +144,8 @@ enum {
     FXB_INFO_NUM_CCR_LIVE = 12,    /* instructions whose CCR write is observable          */
     FXB_INFO_DEVICE = 13,
     FXB_INFO_GRID = 14,            /* workgroups of the last launch                       */
-    FXB_INFO_INST_PER_LANE = 15    /* instances one lane steps (kernel variant)           */
+    FXB_INFO_INST_PER_LANE = 15,   /* instances one lane steps (kernel variant)           */
+    FXB_INFO_KERNEL = 16           /* 1 = hand-written gfx950 assembly interpreter, 0 = HIP C++ kernel */
 };
 int64_t fxb_info(fxb_handle* h, int what);
 

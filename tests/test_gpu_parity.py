@@ -13,10 +13,15 @@ from pyoracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2, 4], ids=["k1", "k2", "k4"])
+@pytest.fixture(params=["asm", 1, 2, 4], ids=["asm", "k1", "k2", "k4"])
 def k(request, monkeypatch):
-    """instances stepped per lane (kernel variant); FX_INST_PER_LANE pins the library's choice"""
-    monkeypatch.setenv("FX_INST_PER_LANE", str(request.param))
+    """kernel variant: the hand-written gfx950 interpreter (default choice), or the HIP C++ kernel
+    with 1/2/4 instances per lane (FX_INST_PER_LANE pins it)"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    if request.param == "asm":
+        monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    else:
+        monkeypatch.setenv("FX_INST_PER_LANE", str(request.param))
     return request.param
 
 HDR = "static a\nstatic b\ninput in 0\noutput out 0\nstatic noise\nstatic rd\ncontrol vol = 0.5\n"
@@ -74,7 +79,10 @@ def test_config_programs_bit_exact(gpu, name, k):
     regs = {"config2": ("t", "s30", "in", "out", "ccr"), "config3": ("rd", "a", "t", "ccr"), "config4": ("x", "a", "b", "o", "ccr"),
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
     b, _ = check_batch(gpu, text, x, regs=regs)
-    assert b.info("inst_per_lane") == k
+    if k == "asm":
+        assert b.info("kernel") == 1 and b.info("inst_per_lane") == 1
+    else:
+        assert b.info("kernel") == 0 and b.info("inst_per_lane") == k
 
 
 def test_block_boundaries_do_not_matter(gpu, k):
@@ -138,9 +146,12 @@ def test_opcode_programs(gpu, name, k):
 
 
 @pytest.mark.parametrize("op,table", [("log", 1), ("log", 3), ("log", 16), ("log", 31), ("exp", 0), ("exp", 2), ("exp", 7), ("exp", 31)])
-def test_log_exp_dense_sweep(gpu, op, table):
+@pytest.mark.parametrize("kern", ["asm", "hip"])
+def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
     """LOG/EXP on the device use precomputed thresholds/slopes instead of the reference's two fp64
     divisions: sweep random x, every table knot and its float neighbours, the domain edges."""
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.setenv("FX_KERNEL", kern)
     text = HDR + "%s out, in, %d, 0\nend" % (op, table)
     rng = np.random.default_rng(table * 7 + len(op))
     knots = (-1.0 + np.arange(64, dtype=np.float64) * (2.0 / 63.0)).astype(np.float32)
@@ -155,7 +166,8 @@ def test_log_exp_dense_sweep(gpu, op, table):
     x = rng.uniform(-1.0, 1.0, size=S * N).astype(np.float32)
     x[:special.size] = special
     x = x.reshape(S, N)
-    check_batch(gpu, text, x, regs=("out", "ccr"), instances=range(0, N, 1))
+    b, _ = check_batch(gpu, text, x, regs=("out", "ccr"), instances=range(0, N, 1))
+    assert b.info("kernel") == (1 if kern == "asm" else 0)
 
 
 def test_delay_line_exact(gpu, k):
