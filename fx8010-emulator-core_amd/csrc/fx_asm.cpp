@@ -24,7 +24,8 @@ bool asmEligible(const Lowered& low, std::string* why) {
     auto no = [&](const char* w) { if (why) *why = w; return false; };
     if (low.instPerLane != 1) return no("more than one instance per lane");
     if (low.multipass) return no("END can be skipped (multi-pass program)");
-    if ((size_t)low.nRows * 256 > 64 * 1024) return no("register file above 64 KiB of LDS");
+    if (low.rowPitch != 1 && (size_t)low.nRows * 256 > 64 * 1024) return no("register file above 64 KiB of LDS");
+    if (low.rowPitch == 1 && low.nRows > kAsmVgprRows[ASM_V256]) return no("register file above 216 VGPR rows");
     for (const MicroOp& m : low.steady) {
         const uint32_t h = handlerOf(m);
         if ((h == H_LOG || h == H_EXP) && (!has(m, F_UX) || has(m, F_STATIC_OOD))) return no("LOG/EXP with a per-instance or out-of-range table");
@@ -102,17 +103,20 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
     return out;
 }
 
-hipError_t launchAsmInterp(const AsmArgs& args, size_t ldsBytes, int device, hipStream_t stream) {
+hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream) {
     static std::mutex mu;
     static hipModule_t modules[64] = {};
-    static hipFunction_t funcs[64] = {};
+    static hipFunction_t funcs[64][ASM_VARIANTS] = {};
+    static const char* const names[ASM_VARIANTS] = {"fx_interp_lds", "fx_interp_v64", "fx_interp_v128", "fx_interp_v256"};
     if (device < 0 || device >= 64) return hipErrorInvalidDevice;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!funcs[device]) {
+        if (!modules[device]) {
             hipError_t e = hipModuleLoadData(&modules[device], kInterpBlob);
             if (e != hipSuccess) return e;
-            e = hipModuleGetFunction(&funcs[device], modules[device], "fx_interp_k1");
+        }
+        if (!funcs[device][variant]) {
+            hipError_t e = hipModuleGetFunction(&funcs[device][variant], modules[device], names[variant]);
             if (e != hipSuccess) return e;
         }
     }
@@ -120,7 +124,7 @@ hipError_t launchAsmInterp(const AsmArgs& args, size_t ldsBytes, int device, hip
     size_t size = sizeof(a);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     const unsigned grid = (unsigned)((args.n + 63) / 64);
-    return hipModuleLaunchKernel(funcs[device], grid, 1, 1, 64, 1, 1, (unsigned)ldsBytes, stream, nullptr, config);
+    return hipModuleLaunchKernel(funcs[device][variant], grid, 1, 1, 64, 1, 1, (unsigned)ldsBytes, stream, nullptr, config);
 }
 
 }  // namespace fx

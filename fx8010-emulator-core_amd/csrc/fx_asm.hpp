@@ -55,6 +55,10 @@ enum AsmSlot : uint32_t {
     AS_MACS = 20, AS_MACSN = 36, AS_ACC3 = 52, AS_INTERP = 68  // + kind*2 + ccr, kind = UA | UX<<1 | UY<<2
 };
 
+// the builds of fx_interp_gfx950.S
+enum AsmVariant { ASM_LDS = 0, ASM_V64 = 1, ASM_V128 = 2, ASM_V256 = 3, ASM_VARIANTS = 4 };
+constexpr int kAsmVgprRows[ASM_VARIANTS] = {0, 24, 88, 216};  // register-file rows of the VGPR builds
+
 // Can this lowering (K = 1, bookkeeping in VGPRs) run on the assembly kernel?  `why` says why not.
 bool asmEligible(const Lowered& low, std::string* why);
 
@@ -62,8 +66,8 @@ bool asmEligible(const Lowered& low, std::string* why);
 // brackets, the stream ends with ENDSAMPLE plus one pad record for the fetch-ahead).
 std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops);
 
-// Loads the embedded code object on the current device (once per device) and launches
-// fx_interp_k1 with ceil(n/64) single-wavefront workgroups and ldsBytes of dynamic LDS.
-hipError_t launchAsmInterp(const AsmArgs& args, size_t ldsBytes, int device, hipStream_t stream);
+// Loads the embedded code object on the device (once per device) and launches the chosen build
+// with ceil(n/64) single-wavefront workgroups and ldsBytes of dynamic LDS (0 for the VGPR builds).
+hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream);
 
 }  // namespace fx

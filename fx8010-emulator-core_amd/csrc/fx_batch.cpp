@@ -212,8 +212,20 @@ int Batch::ensureLowered() {
     const char* forceHip = std::getenv("FX_KERNEL");
     const bool wantAsm = !(forceHip && std::strcmp(forceHip, "hip") == 0) && !std::getenv("FX_INST_PER_LANE");
     if (wantAsm && (!tramPinned || instPerLane_ == 1)) {
-        fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false);
-        asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
+        // first choice: register file in VGPRs (row pitch 1 = plain indices), else in LDS
+        const bool tryVgpr = !(forceHip && std::strcmp(forceHip, "asm_lds") == 0);
+        if (tryVgpr) {
+            fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false, 1);
+            asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
+            if (asmOk) asmVariant_ = fresh.nRows <= kAsmVgprRows[ASM_V64] ? ASM_V64 : (fresh.nRows <= kAsmVgprRows[ASM_V128] ? ASM_V128 : ASM_V256);
+            if (asmOk && forceHip && std::strcmp(forceHip, "asm_v256") == 0) asmVariant_ = ASM_V256;
+            if (asmOk && forceHip && std::strcmp(forceHip, "asm_v128") == 0 && fresh.nRows <= kAsmVgprRows[ASM_V128]) asmVariant_ = ASM_V128;
+        }
+        if (!asmOk) {
+            fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false);
+            asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
+            asmVariant_ = ASM_LDS;
+        }
     } else {
         asmWhyNot_ = "disabled by FX_KERNEL / FX_INST_PER_LANE";
     }
@@ -375,14 +387,14 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             g.n = a.n; g.nPad = a.nPad; g.nLoad = a.nLoad; g.nStore = a.nStore;
             g.nSamples = a.nSamples; g.channels = a.channels;
             for (int c = 0; c < kMaxChannels; ++c) {
-                g.inOff[c] = a.inRow[c] >= 0 ? a.inRow[c] * 256 : -1;
-                g.latchOff[c] = a.latchRow[c] * 256;
+                g.inOff[c] = a.inRow[c] >= 0 ? a.inRow[c] * (int)low_.rowPitch : -1;
+                g.latchOff[c] = a.latchRow[c] * (int)low_.rowPitch;
             }
             g.iSlots = a.iSlots; g.xSlots = a.xSlots; g.iSize = a.iSize; g.xSize = a.xSize;
             g.cursorRow = stateLayout_.cursorBase; g.noiseRow = stateLayout_.noiseBase;
             g.oodRow = a.oodRow; g.countLo = a.countLo; g.countHi = a.countHi; g.staticCount = a.staticCount;
             g.lutX1Off = kLutX1Off * 8;
-            e = launchAsmInterp(g, (size_t)a.nRows * 256, device_, s);
+            e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
         } else {
             e = launchStepBlock(a, low_.multipass, s);
         }
@@ -487,10 +499,11 @@ int64_t Batch::info(int what) {
     if (ensureLowered() != 0) return -1;
     switch (what) {
         case FXB_INFO_INST_PER_LANE: return instPerLane_;
-        case FXB_INFO_KERNEL: return useAsm_ ? 1 : 0;
+        case FXB_INFO_KERNEL: return useAsm_ ? 1 + (int)asmVariant_ : 0;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
-        case FXB_INFO_LDS_BYTES_PER_WG: return (int64_t)low_.nRows * 256 * instPerLane_;
+        case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? 0 : (int64_t)low_.nRows * 256 * instPerLane_;
+        case FXB_INFO_NUM_ROWS: return low_.nRows;
         case FXB_INFO_NUM_MICROOPS: return (int64_t)low_.steady.size();
         case FXB_INFO_ITRAM_SLOTS: return iSlotsAlloc_;
         case FXB_INFO_XTRAM_SLOTS: return xSlotsAlloc_;

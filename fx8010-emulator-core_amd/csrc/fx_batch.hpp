@@ -80,6 +80,7 @@ private:
     int iSlotsAlloc_ = 0, xSlotsAlloc_ = 0;
     int instPerLane_ = 1;
     bool useAsm_ = false;          // the current lowering runs on the hand-written gfx950 kernel
+    AsmVariant asmVariant_ = ASM_LDS;
     std::string asmWhyNot_;
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;

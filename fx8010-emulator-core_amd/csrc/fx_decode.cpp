@@ -34,10 +34,11 @@ StateLayout makeLayout(int nRegs, int channels) {
 }
 
 Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, const std::vector<uint8_t>& forcedLane, int instPerLane,
-                     bool ldsBookkeeping) {
+                     bool ldsBookkeeping, uint32_t rowPitch) {
     Lowered out;
     out.instPerLane = instPerLane;
-    const uint32_t rowBytes = 256u * (uint32_t)instPerLane;
+    const uint32_t rowBytes = rowPitch ? rowPitch : 256u * (uint32_t)instPerLane;
+    out.rowPitch = rowBytes;
     const int nRegs = (int)prog.regs.size();
     const int P = (int)prog.instrs.size();
     const int CH = prog.numChannels;
@@ -147,7 +148,7 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
     }
     out.nRows = nextRow;
     for (int r = 0; r < nRegs; ++r) (lane[r] ? out.nLaneRegs : out.nUniformRegs)++;
-    if ((long)out.nRows * rowBytes > 160 * 1024) {
+    if (rowPitch == 0 && (long)out.nRows * rowBytes > 160 * 1024) {
         out.error = "program needs " + std::to_string(out.nRows) + " per-instance rows: more than the 160 KiB LDS register file holds at " +
                     std::to_string(instPerLane) + " instance(s) per lane";
         return out;

@@ -86,6 +86,7 @@ struct Lowered {
     int oodRow = -1;     // sticky out-of-domain flags
     int aliveRow = -1;   // alive, ended (2 rows) in multipass programs
     int instPerLane = 1;
+    uint32_t rowPitch = 256;  // bytes between rows as encoded in the records
     StateLayout layout;
     int nRows = 0;
     int nLaneRegs = 0, nUniformRegs = 0;
@@ -103,8 +104,11 @@ struct Lowered {
 // instPerLane (K) fixes the LDS row pitch (256*K bytes) the record offsets are expressed in.
 // ldsBookkeeping: give skip counter / TRAM cursors / LFSR / flags their own LDS rows (the HIP C++
 // kernel); false keeps them out of the register file (the assembly kernel holds them in VGPRs).
+// rowPitch: bytes between rows as written into the records (0 = 256*K, the LDS layout; 1 = plain row
+// indices, for the assembly kernel that keeps the register file in VGPRs).
 Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue,
-                     const std::vector<uint8_t>& forcedLane, int instPerLane, bool ldsBookkeeping = true);
+                     const std::vector<uint8_t>& forcedLane, int instPerLane, bool ldsBookkeeping = true,
+                     uint32_t rowPitch = 0);
 
 StateLayout makeLayout(int nRegs, int channels);
 

@@ -24,6 +24,19 @@
 // gfx950 hazards handled by hand: a VALU instruction that writes VCC/SGPRs needs 2 wait states
 // before a VALU instruction reads them (s_nop 1 or two independent instructions).
 
+// This file is assembled several times (clang -x assembler-with-cpp):
+//   -DKNAME=fx_interp_lds                 register file in LDS (any size up to the LDS budget)
+//   -DKNAME=fx_interp_v64  -DRF_VGPR -DNVGPR=64    register file in VGPRs v40.. (VGPR index mode, M0),
+//   -DKNAME=fx_interp_v128 -DRF_VGPR -DNVGPR=128   no LDS traffic and no operand latency at all;
+//   -DKNAME=fx_interp_v256 -DRF_VGPR -DNVGPR=256   24 / 88 / 216 rows at 8 / 4 / 2 wavefronts per SIMD
+// In the VGPR build a "row offset" in a record is simply the row index.
+#ifndef KNAME
+#define KNAME fx_interp_lds
+#endif
+#ifndef NVGPR
+#define NVGPR 40
+#endif
+
 	.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
 	.amdhsa_code_object_version 6
 
@@ -80,13 +93,54 @@
 //  s[72:73] row table  s82 nLoad  s83 nStore  s88 cursor state row  s89 LFSR state row
 
 	.text
-	.globl	fx_interp_k1
+	.globl	KNAME
 	.p2align	8
-	.type	fx_interp_k1,@function
+	.type	KNAME,@function
 
 // ------------------------------------------------------------------------------------------ macros
-.macro NEXT
+// NEXT: go to the next record.  The record prefetch (SMEM) shares lgkmcnt with LDS and returns out of
+// order, so it must have been drained by a full lgkmcnt(0) since it was issued.  Handlers that waited
+// for LDS operands already did that and use NEXT (their own ds_write may stay in flight: LDS executes
+// a wave's accesses in order); handlers with no such wait use NEXT_W.
+.macro NEXT_W
+#ifndef RF_VGPR
 	s_waitcnt lgkmcnt(0)
+#endif
+	NEXT
+.endm
+
+// register-file access: row whose offset (LDS build) / index (VGPR build) is in \sreg
+.macro LOADV dst, sreg
+#ifdef RF_VGPR
+	s_set_gpr_idx_on \sreg, 1
+	v_mov_b32 \dst, v40
+	s_set_gpr_idx_off
+#else
+	v_add_u32 \dst, \sreg, v1
+	ds_read_b32 \dst, \dst
+#endif
+.endm
+.macro STOREV sreg, src
+#ifdef RF_VGPR
+	s_set_gpr_idx_on \sreg, 8
+	v_mov_b32 v40, \src
+	s_set_gpr_idx_off
+#else
+	v_add_u32 v5, \sreg, v1
+	ds_write_b32 v5, \src
+#endif
+.endm
+// wait for LOADV results (LDS build only; VGPR loads are plain moves)
+.macro WAITOPS
+#ifndef RF_VGPR
+	s_waitcnt lgkmcnt(0)
+#endif
+.endm
+
+.macro NEXT
+#ifdef RF_VGPR
+	s_waitcnt lgkmcnt(0)
+#endif
 	s_mov_b64 s[16:17], s[24:25]
 	s_mov_b64 s[18:19], s[26:27]
 	s_mov_b64 s[20:21], s[28:29]
@@ -143,17 +197,46 @@
 	s_and_b64 s[64:65], s[64:65], s[66:67]
 	v_cndmask_b32 v6, v6, 2.0, vcc
 	v_cndmask_b32 v6, v6, v31, s[64:65]
+#ifdef RF_VGPR
+	v_mov_b32 v40, v6
+#else
 	ds_write_b32 v1, v6
+#endif
 .endm
 
 // result in v2 -> row R
 .macro STORE_R
-	v_add_u32 v5, s17, v1
-	ds_write_b32 v5, v2
+	STOREV s17, v2
 .endm
 
 // operand fetch of the specialised handlers: \kind bit0/1/2 = A/X/Y is uniform
 .macro FETCH3 kind
+#ifdef RF_VGPR
+	.if ((\kind) & 1) == 0
+	s_set_gpr_idx_on s18, 1
+	v_mov_b32 v2, v40
+	.endif
+	.if ((\kind) & 2) == 0
+	s_set_gpr_idx_on s19, 1
+	v_mov_b32 v3, v40
+	.endif
+	.if ((\kind) & 4) == 0
+	s_set_gpr_idx_on s20, 1
+	v_mov_b32 v4, v40
+	.endif
+	.if (\kind) != 7
+	s_set_gpr_idx_off
+	.endif
+	.if ((\kind) & 1)
+	v_mov_b32 v2, s18
+	.endif
+	.if ((\kind) & 2)
+	v_mov_b32 v3, s19
+	.endif
+	.if ((\kind) & 4)
+	v_mov_b32 v4, s20
+	.endif
+#else
 	.if ((\kind) & 1) == 0
 	v_add_u32 v2, s18, v1
 	ds_read_b32 v2, v2
@@ -175,6 +258,7 @@
 	.if (\kind) != 7
 	s_waitcnt lgkmcnt(0)
 	.endif
+#endif
 .endm
 
 // operand fetch of the generic handlers: kinds from the flag word w5 (s21)
@@ -182,8 +266,7 @@
 	v_mov_b32 \reg, \sreg
 	s_bitcmp1_b32 s21, \bit
 	s_cbranch_scc1 .Lgf\@
-	v_add_u32 \reg, \sreg, v1
-	ds_read_b32 \reg, \reg
+	LOADV \reg, \sreg
 .Lgf\@:
 .endm
 
@@ -209,7 +292,11 @@
 	.if \ccr
 	CCR_FROM v2
 	.endif
+	.if (\kind) == 7
+	NEXT_W
+	.else
 	NEXT
+	.endif
 .endm
 
 .macro HOT_ACC3 kind, ccr
@@ -221,7 +308,11 @@
 	.if \ccr
 	CCR_FROM v2
 	.endif
+	.if (\kind) == 7
+	NEXT_W
+	.else
 	NEXT
+	.endif
 .endm
 
 // INTERP (FX8010.cpp:1180-1187): R = sat((float)((1.0 - (double)X) * (double)A + (double)(X*Y)))
@@ -244,13 +335,17 @@
 	.if \ccr
 	CCR_FROM v2
 	.endif
+	.if (\kind) == 7
+	NEXT_W
+	.else
 	NEXT
+	.endif
 .endm
 
 // TRAM read (FX8010.cpp:934-967): row R <- buffer[(rpos - p) % size]; rpos = (rpos+1) % size
 .macro TRAM_READ size, slots, baselo, basehi, cur
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_mov_b32 v2, 0
 	s_cmp_lt_i32 \size, 1
 	s_cbranch_scc1 .Ltr0\@
@@ -287,7 +382,7 @@
 .macro TRAM_WRITE size, slots, cap, baselo, basehi, cur
 	GFETCH v2, s18, 0
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	s_cmp_lt_i32 \size, 1
 	s_cbranch_scc1 .Ltw0\@
 	CVTT v6, v4
@@ -340,7 +435,7 @@ h_interp_\kind\()_1:
 .endm
 
 // ------------------------------------------------------------------------------------------ entry
-fx_interp_k1:
+KNAME:
 	s_load_dwordx16 s[4:19], s[0:1], KA_STEADY            // steady last rowtab state in out itram xtram
 	s_load_dwordx8  s[40:47], s[0:1], KA_LUT              // lut n npad nload nstore
 	s_load_dwordx2  s[80:81], s[0:1], KA_NSAMPLES         // nSamples channels
@@ -415,10 +510,11 @@ fx_interp_k1:
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_load_dword v2, v27, s[66:67]
+#ifndef RF_VGPR
 	s_lshl_b32 s64, s64, 8
-	v_add_u32 v5, s64, v1
+#endif
 	s_waitcnt vmcnt(0)
-	ds_write_b32 v5, v2
+	STOREV s64, v2
 	s_add_u32 s62, s62, 1
 	s_cmp_lt_u32 s62, s82
 	s_cbranch_scc1 .Lload_loop
@@ -492,29 +588,25 @@ fx_interp_k1:
 	// this sample's input -> LDS rows
 	s_cmp_lt_i32 s48, 0
 	s_cbranch_scc1 .Ls_w1
-	v_add_u32 v5, s48, v1
-	ds_write_b32 v5, v23
+	STOREV s48, v23
 .Ls_w1:
 	s_cmp_lt_i32 s44, 2
 	s_cbranch_scc1 .Ls_wdone
 	s_cmp_lt_i32 s49, 0
 	s_cbranch_scc1 .Ls_w2
-	v_add_u32 v5, s49, v1
-	ds_write_b32 v5, v24
+	STOREV s49, v24
 .Ls_w2:
 	s_cmp_lt_i32 s44, 3
 	s_cbranch_scc1 .Ls_wdone
 	s_cmp_lt_i32 s50, 0
 	s_cbranch_scc1 .Ls_w3
-	v_add_u32 v5, s50, v1
-	ds_write_b32 v5, v25
+	STOREV s50, v25
 .Ls_w3:
 	s_cmp_lt_i32 s44, 4
 	s_cbranch_scc1 .Ls_wdone
 	s_cmp_lt_i32 s51, 0
 	s_cbranch_scc1 .Ls_wdone
-	v_add_u32 v5, s51, v1
-	ds_write_b32 v5, v26
+	STOREV s51, v26
 .Ls_wdone:
 	// prefetch the next sample's input (if any); its latency hides behind this sample's program
 	s_add_u32 s62, s3, 1
@@ -605,11 +697,11 @@ jump_table:
 	.endr
 
 h_nop:
-	NEXT
+	NEXT_W
 
 h_unpred:
 	s_mov_b64 exec, -1
-	NEXT
+	NEXT_W
 
 // start of an instruction inside a SKIP shadow (FX8010.cpp:1037,1235-1241): lanes with numSkip == 0
 // execute it (EXEC), the others count their skip down
@@ -621,11 +713,11 @@ h_pred:
 	v_cndmask_b32 v5, 0, 1, vcc
 	v_add_u32 v15, v15, v5
 	s_mov_b64 exec, vcc
-	NEXT
+	NEXT_W
 
 h_mov:
 	GFETCH v2, s18, 0
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	GSTORE
 	NEXT
 
@@ -633,7 +725,7 @@ h_macw:                                                   // R = A + wrap(X*Y)  
 	GFETCH v2, s18, 0
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_mul_f32 v3, v3, v4
 	WRAP v3
 	v_add_f32 v2, v2, v3
@@ -644,7 +736,7 @@ h_macwn:                                                  // R = A - wrap(X*Y)  
 	GFETCH v2, s18, 0
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_mul_f32 v3, v3, v4
 	WRAP v3
 	v_sub_f32 v2, v2, v3
@@ -655,7 +747,7 @@ h_macintw:                                                // R = wrap(A + X*Y)  
 	GFETCH v2, s18, 0
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_mul_f32 v3, v3, v4
 	v_add_f32 v2, v2, v3
 	WRAP v2
@@ -666,7 +758,7 @@ h_andxor:                                                 // logicOps, FX8010.cp
 	GFETCH v2, s18, 0
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	CVTT v8, v2                                           // A
 	CVTT v9, v3                                           // X
 	CVTT v10, v4                                          // Y
@@ -703,7 +795,7 @@ h_tstneg:                                                 // R = A >= Y ? X : in
 	GFETCH v2, s18, 0
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_mul_f32 v6, 0x4f000000, v3                          // X * 2^31
 	CVTT v7, v6
 	v_not_b32 v7, v7
@@ -719,7 +811,7 @@ h_limit:                                                  // R = A >= Y ? X : Y 
 	GFETCH v2, s18, 0
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_cmp_ge_f32 vcc, v2, v4
 	s_nop 1
 	v_cndmask_b32 v2, v4, v3, vcc
@@ -730,7 +822,7 @@ h_limitn:                                                 // R = A < Y ? X : Y  
 	GFETCH v2, s18, 0
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_cmp_lt_f32 vcc, v2, v4
 	s_nop 1
 	v_cndmask_b32 v2, v4, v3, vcc
@@ -742,7 +834,7 @@ h_limitn:                                                 // R = A < Y ? X : Y  
 // {slope, y1} array in the blob.  idx = #{k >= 1 : t >= thr[k]}, guessed from t*31.5 and corrected.
 h_lut:
 	GFETCH v2, s18, 0
-	s_waitcnt lgkmcnt(0)
+	WAITOPS
 	v_cvt_f64_f32 v[6:7], v2                              // x
 	v_add_f64 v[8:9], v[6:7], 1.0                         // t = x - -1.0
 	v_mov_b32 v10, 0
@@ -789,8 +881,12 @@ h_lut:
 h_skip:                                                   // if ((float)(int)X == CCR) numSkip = (int)Y   :1175-1179
 	GFETCH v3, s19, 1
 	GFETCH v4, s20, 2
+#ifdef RF_VGPR
+	v_mov_b32 v6, v40                                     // CCR row
+#else
 	ds_read_b32 v6, v1                                    // CCR row
 	s_waitcnt lgkmcnt(0)
+#endif
 	CVTT v7, v3
 	v_cvt_f32_i32 v7, v7
 	CVTT v8, v4
@@ -814,7 +910,7 @@ h_noise:                                                  // whitenoise(), FX801
 	v_mul_f32 v2, 0x30000000, v2                          // * 2^-31
 	v_add_u32 v21, v21, v20
 	STORE_R
-	NEXT
+	NEXT_W
 
 	.irp kind, 0, 1, 2, 3, 4, 5, 6, 7
 	DEF_HOT \kind
@@ -823,31 +919,27 @@ h_noise:                                                  // whitenoise(), FX801
 // ---- end of the program for this sample: latch rows -> PCM out, next sample
 h_endsample:
 	s_mov_b64 exec, s[58:59]
-	v_add_u32 v5, s52, v1
-	ds_read_b32 v2, v5
+	LOADV v2, s52
 	s_mov_b64 s[62:63], s[14:15]
 	s_waitcnt lgkmcnt(0)
 	global_store_dword v27, v2, s[62:63]
 	s_cmp_lt_i32 s44, 2
 	s_cbranch_scc1 .Le_done
-	v_add_u32 v5, s53, v1
-	ds_read_b32 v2, v5
+	LOADV v2, s53
 	s_add_u32 s62, s62, s68
 	s_addc_u32 s63, s63, 0
 	s_waitcnt lgkmcnt(0)
 	global_store_dword v27, v2, s[62:63]
 	s_cmp_lt_i32 s44, 3
 	s_cbranch_scc1 .Le_done
-	v_add_u32 v5, s54, v1
-	ds_read_b32 v2, v5
+	LOADV v2, s54
 	s_add_u32 s62, s62, s68
 	s_addc_u32 s63, s63, 0
 	s_waitcnt lgkmcnt(0)
 	global_store_dword v27, v2, s[62:63]
 	s_cmp_lt_i32 s44, 4
 	s_cbranch_scc1 .Le_done
-	v_add_u32 v5, s55, v1
-	ds_read_b32 v2, v5
+	LOADV v2, s55
 	s_add_u32 s62, s62, s68
 	s_addc_u32 s63, s63, 0
 	s_waitcnt lgkmcnt(0)
@@ -876,9 +968,10 @@ h_endsample:
 	s_waitcnt lgkmcnt(0)
 	s_lshr_b32 s65, s64, 16
 	s_and_b32 s64, s64, 0xffff
+#ifndef RF_VGPR
 	s_lshl_b32 s64, s64, 8
-	v_add_u32 v5, s64, v1
-	ds_read_b32 v2, v5
+#endif
+	LOADV v2, s64
 	s_mul_i32 s66, s65, s60
 	s_mul_hi_u32 s67, s65, s60
 	s_add_u32 s66, s66, s10
@@ -946,11 +1039,11 @@ h_endsample:
 	global_store_dword v27, v4, s[74:75]
 	s_endpgm
 .Lfunc_end0:
-	.size	fx_interp_k1, .Lfunc_end0-fx_interp_k1
+	.size	KNAME, .Lfunc_end0-KNAME
 
 	.rodata
 	.p2align	6, 0x0
-	.amdhsa_kernel fx_interp_k1
+	.amdhsa_kernel KNAME
 		.amdhsa_group_segment_fixed_size 0
 		.amdhsa_private_segment_fixed_size 0
 		.amdhsa_kernarg_size KA_SIZE
@@ -958,9 +1051,9 @@ h_endsample:
 		.amdhsa_user_sgpr_kernarg_segment_ptr 1
 		.amdhsa_system_sgpr_workgroup_id_x 1
 		.amdhsa_system_vgpr_workitem_id 0
-		.amdhsa_next_free_vgpr 40
+		.amdhsa_next_free_vgpr NVGPR
 		.amdhsa_next_free_sgpr 96
-		.amdhsa_accum_offset 40
+		.amdhsa_accum_offset NVGPR
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_round_mode_32 0
 		.amdhsa_float_round_mode_16_64 0
@@ -981,11 +1074,11 @@ amdhsa.kernels:
     .kernarg_segment_align: 8
     .kernarg_segment_size: 184
     .max_flat_workgroup_size: 64
-    .name: fx_interp_k1
+    .name: KNAME
     .private_segment_fixed_size: 0
     .sgpr_count: 102
-    .symbol: fx_interp_k1.kd
-    .vgpr_count: 40
+    .symbol: KNAME.kd
+    .vgpr_count: NVGPR
     .wavefront_size: 64
 amdhsa.target: amdgcn-amd-amdhsa--gfx950
 amdhsa.version:

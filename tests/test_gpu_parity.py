@@ -13,13 +13,17 @@ from pyoracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["asm", 1, 2, 4], ids=["asm", "k1", "k2", "k4"])
+@pytest.fixture(params=["asm", "asm_v256", "asm_lds", 1, 2, 4], ids=["asm", "asm_v256", "asm_lds", "k1", "k2", "k4"])
 def k(request, monkeypatch):
-    """kernel variant: the hand-written gfx950 interpreter (default choice), or the HIP C++ kernel
+    """kernel variant: the hand-written gfx950 interpreter — default choice (register file in the
+    smallest VGPR build that fits), forced 256-VGPR build, forced LDS build — or the HIP C++ kernel
     with 1/2/4 instances per lane (FX_INST_PER_LANE pins it)"""
     monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
     if request.param == "asm":
-        monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+        pass
+    elif isinstance(request.param, str):
+        monkeypatch.setenv("FX_KERNEL", request.param)
     else:
         monkeypatch.setenv("FX_INST_PER_LANE", str(request.param))
     return request.param
@@ -79,8 +83,9 @@ def test_config_programs_bit_exact(gpu, name, k):
     regs = {"config2": ("t", "s30", "in", "out", "ccr"), "config3": ("rd", "a", "t", "ccr"), "config4": ("x", "a", "b", "o", "ccr"),
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
     b, _ = check_batch(gpu, text, x, regs=regs)
-    if k == "asm":
-        assert b.info("kernel") == 1 and b.info("inst_per_lane") == 1
+    if isinstance(k, str):
+        want = {"asm": (2, 3, 4), "asm_v256": (4,), "asm_lds": (1,)}[k]
+        assert b.info("kernel") in want and b.info("inst_per_lane") == 1
     else:
         assert b.info("kernel") == 0 and b.info("inst_per_lane") == k
 
@@ -146,7 +151,7 @@ def test_opcode_programs(gpu, name, k):
 
 
 @pytest.mark.parametrize("op,table", [("log", 1), ("log", 3), ("log", 16), ("log", 31), ("exp", 0), ("exp", 2), ("exp", 7), ("exp", 31)])
-@pytest.mark.parametrize("kern", ["asm", "hip"])
+@pytest.mark.parametrize("kern", ["asm", "asm_lds", "hip"])
 def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
     """LOG/EXP on the device use precomputed thresholds/slopes instead of the reference's two fp64
     divisions: sweep random x, every table knot and its float neighbours, the domain edges."""
@@ -167,7 +172,7 @@ def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
     x[:special.size] = special
     x = x.reshape(S, N)
     b, _ = check_batch(gpu, text, x, regs=("out", "ccr"), instances=range(0, N, 1))
-    assert b.info("kernel") == (1 if kern == "asm" else 0)
+    assert (b.info("kernel") > 0) == (kern != "hip")
 
 
 def test_delay_line_exact(gpu, k):
