@@ -33,10 +33,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5"])
-    ap.add_argument("--samples", type=int, default=64, help="sample periods per step (block length S)")
+    ap.add_argument("--samples", type=int, default=256, help="sample periods per step (block length S)")
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (0 = BASELINE.json's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only); 0 disables")
     ap.add_argument("--extra-configs", action="store_true", help="also report untimed single-launch MIPS of the other configs")
@@ -59,6 +59,19 @@ def device_stimulus(torch, n_inst, n_samples, first_instance, device):
     return (f * 0.9).contiguous()
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity, capped by the cgroup CPU quota (the GPU
+    box hands one GPU's share of a large host: 16 cores) — oversubscribing would only time the throttle."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(text, budget_s):
     """Time the reference (or, without oracle/_ref, the C port) on the host cores: bounded sample."""
     import tempfile
@@ -69,7 +82,7 @@ def cpu_baseline(text, budget_s):
     from pyoracle import Oracle, Reference
 
     cls, kind = (Reference, "reference") if Reference.available() else (Oracle, "port")
-    cores = max(1, len(os.sched_getaffinity(0)))
+    cores = usable_cores()
     fd, path = tempfile.mkstemp(suffix=".da")
     with os.fdopen(fd, "wb") as fh:
         fh.write(text.encode())
@@ -96,21 +109,14 @@ def main():
     import fx8010_amd
     import fx8010_programs as progs
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    import fx8010_shard as shard
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+    rank, local, world = shard.env_world()
+    if world == 1:
         local = 0
+    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = shard.init_process_group("nccl", dev)  # RCCL; None for a single process
 
     text = progs.CONFIGS[args.config]()
     n_inst = args.instances or progs.CONFIG_INSTANCES[args.config]
@@ -120,7 +126,8 @@ def main():
     batch = fx8010_amd.Batch(n_inst, 1, local)
     if not batch.load_text(text):
         raise RuntimeError("program failed to load: %s" % batch.errors())
-    x = device_stimulus(torch, n_inst, S, rank * n_inst, dev)  # [S, N] resident in HBM
+    first_instance, _ = shard.weak_shard(n_inst, rank)  # weak scaling: every GPU owns n_inst instances
+    x = device_stimulus(torch, n_inst, S, first_instance, dev)  # [S, N] resident in HBM
     y = torch.empty_like(x)
     torch.cuda.synchronize()
     # a non-default torch stream: the kernel is launched on it through the C ABI, so the
@@ -157,20 +164,15 @@ def main():
     executed = batch.instruction_counter() - c0  # reference counting: END/SKIP count, skipped don't
     ood = batch.ood_flags()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        e = torch.tensor([float(executed)], dtype=torch.float64, device=dev)
-        dist.all_reduce(e, op=dist.ReduceOp.SUM)
-        executed_all = float(e.item())
-    else:
-        executed_all = float(executed)
+    elapsed = shard.reduce_scalar(dist, elapsed, "max", dev)            # slowest rank
+    executed_all = shard.reduce_scalar(dist, executed, "sum", dev)      # whole job
 
     if rank == 0:
         mips = executed_all / elapsed / 1e6
         tram_ops = batch.info("tram_ops")
-        rows = batch.info("lds_bytes_per_wg") // 256
+        rows = batch.info("num_rows")
+        kernel_kind = {0: "fx_step_block (HIP C++)", 1: "fx_interp_lds (gfx950 asm, LDS register file)", 2: "fx_interp_v64 (gfx950 asm, VGPR register file)",
+                       3: "fx_interp_v128 (gfx950 asm, VGPR register file)", 4: "fx_interp_v256 (gfx950 asm, VGPR register file)"}[batch.info("kernel")]
         # algorithmic HBM bytes of ONE launch on ONE GPU: PCM in+out, every executed
         # TRAM read/write, and the once-per-block register-file spill/fill
         bytes_per_inst_sample = 4 * (1 + 1) + 4 * tram_ops
@@ -205,11 +207,11 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None,
-                "kernel": "fx_step_block",
+                "kernel": kernel_kind,
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_last_launch": round(last_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "interpreter is VALU/LDS-issue bound (>= 12 emulated instr per HBM byte); see DESIGN.md",
+                "note": "the interpreter is instruction-issue bound (>= 12 emulated instr per algorithmic HBM byte); see DESIGN.md section 5",
                 "emulated_instr_per_s_per_gpu": round(executed / (kernel_ms * 1e-3 * args.steps), 1),
             },
         }

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the UNMODIFIED reference.
+
+Runs only where /root/reference exists (the build container): it drives oracle/_ref/libfxref.so
+— the reference's own sources compiled by oracle/Makefile — through its public API and writes
+small JSON fixtures (program text written for this repo, input bits, output bits, final register
+bits, instruction counter, error/control/meta lists).  No reference source is stored.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "fx8010-emulator-core_amd", "python"))
+
+import fx8010_programs as progs  # noqa: E402
+from pyoracle import Reference  # noqa: E402
+
+HDR = "static a\nstatic b\ninput in 0\noutput out 0\nstatic noise\nstatic rd\ncontrol vol = 0.5\n"
+
+
+def hexbits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).tobytes().hex()
+
+
+def run_case(name, text, x, regs=("ccr",), channels=1, sets=None):
+    """sets: {sample_index: [(register, value), ...]} applied before that sample (slider schedule)."""
+    r = Reference(channels)
+    ok = r.load_text(text)
+    case = {"name": name, "program": text, "channels": channels, "load_ok": bool(ok), "errors": r.errors(),
+            "controls": r.controls(), "meta": r.meta()}
+    if ok:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if sets:
+            outs = []
+            cuts = sorted(set([0] + list(sets.keys()) + [x.shape[0]]))
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                for reg, val in sets.get(lo, []):
+                    r.set_register(reg, val)
+                outs.append(r.process_block(x[lo:hi]))
+            y = np.concatenate(outs, axis=0)
+            case["sets"] = {str(k): v for k, v in sets.items()}
+        else:
+            y = r.process_block(x)
+        case.update({"input": hexbits(x), "output": hexbits(y), "shape": list(x.shape),
+                     "counter": r.instruction_counter(), "registers": {k: r.get_register_bits(k) for k in regs}})
+    return case
+
+
+def ramp32():
+    return np.array([i / 16.0 for i in range(-16, 16)], dtype=np.float32)
+
+
+def ramp_ext():
+    return np.array([i / 16.0 for i in range(-16, 16)] + [1.0, -1.0, 0.0, -0.0, 1e-39, -1e-39, 0.999999, -0.999999] * 2, dtype=np.float32)
+
+
+OPCODE_PROGRAMS = {
+    "macs": "macs out, in, vol, 0.75", "macsn": "macsn out, in, vol, 0.75", "macints": "macints out, in, in, 2",
+    "acc3": "acc3 out, in, vol, 0.25", "macw": "macw out, in, 1.5, 1.0", "macwn": "macwn out, in, 1.5, in",
+    "macintw": "macintw out, in, 1.5, 1.0", "macw_ccr_as_a": "macw out, ccr, 1.5, in", "macmv": "macmv out, in, 0.5, 0.5",
+    "andxor_and": "macs a, 0, in, 100\nandxor out, a, 15, 0", "andxor_xor": "macw a, 0, in, 100\nandxor out, a, 16777215, 5",
+    "andxor_generic": "macw a, 0, in, 100\nandxor out, a, 12, 3", "andxor_literals": "andxor out, 7, 5, 2",
+    "tstneg": "tstneg out, in, 0.25, 0", "tstneg_overflow": "tstneg out, in, 1.0, 0", "limit": "limit out, in, 0.5, 0.25",
+    "limitn": "limitn out, in, 0.5, 0.25", "log3": "log a, in, 3, 0\nmacs out, 0, a, 1.0", "log0": "log a, in, 0, 0\nmacs out, 0, a, 1.0",
+    "log31": "log a, in, 31, 1\nmacs out, 0, a, 1.0", "exp7": "exp a, in, 7, 0\nmacs out, 0, a, 1.0", "exp0": "exp a, in, 0, 0\nmacs out, 0, a, 1.0",
+    "exp_unclamped_r": "exp out, in, 2, 0", "interp": "interp out, out, 0.1, in", "interp_literals": "interp out, -0.25, vol, 0.25",
+    "highpass": "interp a, a, 0.1, in\nmacsn out, in, a, 1", "skip_neg": "macs a, in, 0, 0\nskip ccr, ccr, 6, 1\nmacs out, 0, in, 1.0",
+    "skip_zero": "macs a, in, 0, 0\nskip ccr, ccr, 8, 2\nmacs out, 0, in, 1.0\nmacs out, out, 0.5, 0.5",
+    "skip_sat": "macs a, in, in, 1.0\nskip ccr, ccr, 16, 1\nmacs out, 0, a, 0.5",
+    "skip_negative_count": "macs a, in, 0, 0\nskip ccr, ccr, 6, -3\nmacs out, 0, in, 1.0\nmacs b, out, 0.5, 0.5",
+    "skip_never": "macs a, in, 0, 0\nskip ccr, ccr, 384, 1\nmacs out, 0, in, 1.0", "ccr_as_operand": "macs a, in, 0, 0\nmacs out, 0, ccr, 0.03125",
+    "noise": "macs out, 0, noise, 1.0", "noise_twice": "macs a, 0, noise, 0.5\nmacs out, a, noise, 0.5",
+    "literal_as_r": "macs 0.5, in, 0.5, 0.5\nmacs out, 0, 0.5, 1.0", "write_ccr_directly": "macs ccr, in, 0, 0\nmacs out, 0, ccr, 0.03125",
+    "out_read_back": "macs out, out, in, 0.1", "idelay_nop_r": "idelay a, in, at, 0\nmacs out, 0, in, 1.0",
+    "latch_on_skip": "macs out, 0, in, 1.0\nmacs out, out, 0.5, 0.5\nskip out, ccr, 2, 0",
+    "skip_over_end": "macs a, in, 0, 0\nmacs out, out, 0.125, 0.5\nskip ccr, ccr, 6, 2\nmacs b, in, 0.5, 0.5",
+}
+
+# loader corpus: each entry is a whole program text; only load status / error list / lists are pinned
+PARSER_CORPUS = [
+    "static a\nend", "static a\nend\n", "static a\nend\n\n", "static a\nend ", "static a\nEND", "static a ; c\nend ; x",
+    "static a12.5\nmacs a1, a1, 0, 0\nend", "static 12.5\nmacs 1, 1, 0, 0\nend", "static a = 0.5\nend", "static a=.5\nend",
+    "static a = -0.5\nend", "static a 1.\nend", "static a b\nend", "static a, 3\nend", "static a = , = 7\nend", "statics a\nend",
+    "static\nend", "static a\nstatic a\nend", "static ccr\nend", "control v = 1.0\ncontrol v = 2.0\nend", "input i 0\nend",
+    "input i 1\nend", "input i 0.9\nend", "output o 3\nend", "input i\nmacs i, i, i, i\nend", "temp t\nconst c 2\nmacs t, c, c, c\nend",
+    "itramsize 100 \nend", "itramsize 100\nend", "itramsize 100  \nend", "itramsize 100\t\nend", "xtramsize 5 \nxtramsize 7 \nend",
+    "itramsize 9000 \nitramsize 10 \nend", "xtramsize 2000000 \nxtramsize 1 \nend", " itramsize 4 \nend",
+    "static a\nmacs a,a,a,a\nend", "static a\nmacs a , a , a , a \nend", "static a\nmacs a a, a, a\nend", "static a\nmacs a, a, a\nend",
+    "static a\nmacs a, a, a, a, a\nend", "static a\nmacs a, b, a, a\nend", "static a\nmacsa, a, a, a\nend", "static a\nmacsn a, 1, -2.5, 3.\nend",
+    "static a\nmacsn a, 1, -2.5, .3\nend", "static a\nmacs a, 1e3, 0, 0\nend", "static a\nmacs a, --1, 0, 0\nend", "static a\nmacs a, 1.2.3, 0, 0\nend",
+    "static a\nfoo a, a, a, a\nend", "static a\n  MACS A, A, 0.5, A\nend", "static a\nlog a, a, 3, 0\nexp a, a, 7, 0\ninterp a, a, a, a\nend",
+    "static a\nskip a, a, a, a\nandxor a, a, a, a\ntstneg a, a, a, a\nlimit a, a, a, a\nlimitn a, a, a, a\nend",
+    "static a\nmacw a, a, a, a\nmacwn a, a, a, a\nmacints a, a, a, a\nmacintw a, a, a, a\nacc3 a, a, a, a\nmacmv a, a, a, a\nend",
+    "static a\nidelay read, a, at, 0\nidelay write, a, at, 0\nxdelay read, a, at, 0\nxdelay write, a, at, 0\nend",
+    'name "x"\nend', 'name "x" \nend', 'name  "a b c"\nend', 'name ""\nend', 'name "x\nend', 'names "x"\nend', 'guid "1-2"\ncomment "HeLLo"\nend',
+    'name "a;b"\nend', 'name "one"\nname "two"\nend', "end", "\n", "end\nstatic a\nend", "static a\nmacs a, 0, 0, 0\nend\nmacs a, 1, 1, 1\nend",
+    # (an empty file is left out: the reference itself crashes on it — lines.back() on an empty vector)
+    "static noise\noutput o 0\nmacs o, 0, noise, 1.0\nend", "input noise 0\noutput o 0\nmacs o, 0, noise, 1.0\nend",
+    "static a\r\nend\r\n", "static a\n\tmacs\ta,\ta,\ta,\ta\nend", "static a_b9\nstatic _x\nmacs a_b9, _x, 0, 0\nend", "static a.b\nend",
+    "static a\nmacs a, a.b, 0, 0\nend", "static a\nmacs a, -a, 0, 0\nend", "static a\nmacs a, 0, 0, 0 end",
+]
+
+
+def main():
+    if not Reference.available():
+        raise SystemExit("oracle/_ref/libfxref.so missing: run `make -C oracle ref` in the build container")
+    out = {}
+
+    # 1. one case per opcode / feature over the harness ramp plus edge values
+    x = ramp_ext()
+    out["opcodes.json"] = [run_case(k, HDR + v + "\nend", x, regs=("a", "b", "out", "ccr", "in")) for k, v in sorted(OPCODE_PROGRAMS.items())]
+
+    # 2. known answers quoted in SURVEY.md §8(a)
+    out["known_answers.json"] = [
+        run_case("interp_step", HDR + "interp out, out, 0.1, in\nend", np.ones(6, np.float32), regs=("out", "ccr")),
+        run_case("log3_ramp32", HDR + "log a, in, 3, 0\nmacs out, 0, a, 1.0\nend", ramp32(), regs=("a", "ccr")),
+        run_case("noise_first6", HDR + "macs out, 0, noise, 1.0\nend", np.zeros(6, np.float32), regs=("noise",)),
+        run_case("tstneg_overflow", HDR + "tstneg out, in, 1.0, 0\nend", ramp32(), regs=("out",)),
+        run_case("macw", HDR + "macw out, in, 1.5, 1.0\nend", ramp32(), regs=("out", "ccr")),
+        run_case("skip_sign", HDR + "macs a, in, 0, 0\nskip ccr, ccr, 6, 1\nmacs out, 0, in, 1.0\nend", ramp32(), regs=("out", "ccr")),
+        run_case("delay5", "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend", ramp32(), regs=("rd",)),
+    ]
+
+    # 3. the harness's slider schedule (main.cpp:80,103-122) on the shipped program shape
+    sets = {0: [("volume", 0.1)], 8: [("volume", 0.25)], 16: [("volume", 0.5)], 24: [("volume", 1.0)]}
+    out["slider.json"] = [run_case("slider_shipped", progs.config1_shipped(), ramp32(), regs=("volume", "filter_cutoff", "in_l", "out_l", "ccr"), sets=sets),
+                          run_case("logtube", progs.config1_logtube(), ramp32(), regs=("a", "out_l", "ccr"))]
+
+    # 4. LOG/EXP tables: every exponent at the 64 knots and midpoints (pins the LUT bits that reach an output)
+    knots = (-1.0 + np.arange(64, dtype=np.float64) * (2.0 / 63.0)).astype(np.float32)
+    mids = (knots[:-1].astype(np.float64) + 1.0 / 63.0).astype(np.float32)
+    xs = np.concatenate([knots, mids, np.array([1.0], np.float32)])
+    lut = []
+    for op in ("log", "exp"):
+        for e in range(32):
+            lut.append(run_case("%s%d" % (op, e), HDR + "%s out, in, %d, 0\nend" % (op, e), xs, regs=("out",)))
+    for c in lut:  # the input is the same for all 64 cases: keep it once
+        del c["program"]
+    out["lut_probe.json"] = {"input": hexbits(xs), "cases": [{"name": c["name"], "output": c["output"]} for c in lut]}
+
+    # 5. feedback delay over Dirac + noise, 3000 samples
+    fb = "itramsize 1000 \n" + HDR + "idelay read, rd, at, 0\nmacs a, in, rd, 0.5\nmacs a, a, noise, 0.01\nidelay write, a, at, 0\nmacs out, 0, a, 1.0\nend"
+    dirac = np.zeros(3000, np.float32)
+    dirac[0] = 1.0
+    out["feedback_delay.json"] = [run_case("feedback_1000", fb, dirac, regs=("rd", "a", "ccr"))]
+
+    # 6. the benchmark programs, a few instances of the synthetic PCM
+    cfg = []
+    for name in ("config2", "config3", "config4", "config5"):
+        text = progs.CONFIGS[name]()
+        for inst in (0, 1, 4095):
+            x = progs.stimulus(1, 384, first_instance=inst)[:, 0].copy()
+            c = run_case("%s_inst%d" % (name, inst), text, x, regs=("ccr", "out"))
+            del c["program"]  # regenerated from fx8010_programs at test time
+            c["config"] = name
+            c["instance"] = inst
+            cfg.append(c)
+    out["configs.json"] = cfg
+
+    # 7. loader corpus
+    corpus = []
+    for i, text in enumerate(PARSER_CORPUS):
+        r = Reference(1)
+        ok = r.load_text(text)
+        corpus.append({"program": text, "load_ok": bool(ok), "errors": r.errors(), "controls": r.controls(), "meta": r.meta(), "ready": r.ready()})
+    out["parser_corpus.json"] = corpus
+
+    for fn, data in out.items():
+        with open(os.path.join(HERE, fn), "w") as fh:
+            json.dump(data, fh, indent=0, separators=(",", ":"))
+        print(fn, os.path.getsize(os.path.join(HERE, fn)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
