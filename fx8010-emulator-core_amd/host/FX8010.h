@@ -1,0 +1,142 @@
+// FX8010.h — host-side mirror of the reference's public class, over the C ABI of libfx8010_amd.so.
+//
+// Same namespace, class name, member names, argument meaning and return conventions as the
+// reference (include/FX8010.h:47-75), so a caller written against the reference — its console
+// harness source/main.cpp, or the VST block loop it is meant for — compiles unchanged against
+// this header and runs the instruction loop on an MI355X instead of the host CPU.
+//
+//   Klangraum::FX8010       one emulated DSP, one process() call per sample period
+//   Klangraum::FX8010Batch  N independent DSPs stepping one program (the data-parallel path)
+//
+// Header-only; link with -lfx8010_amd.  Differences that remain, by design:
+//   * construction prints no banner (the reference prints ~7 lines, source/FX8010.cpp:18-24);
+//   * when no HIP device is usable the constructor throws std::runtime_error — there is no CPU path;
+//   * getInstructionCounter() is computed in 64 bits and truncated to int like the reference's field.
+#ifndef FX8010_AMD_HOST_FX8010_H
+#define FX8010_AMD_HOST_FX8010_H
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fx8010_amd.h"
+
+// the reference's compile-time settings that callers use (include/FX8010.h:37-42)
+#ifndef SAMPLERATE
+#define SAMPLERATE 48000
+#endif
+#ifndef AUDIOBLOCKSIZE
+#define AUDIOBLOCKSIZE 32
+#endif
+#ifndef MAX_IDELAY_SIZE
+#define MAX_IDELAY_SIZE 8192
+#endif
+#ifndef MAX_XDELAY_SIZE
+#define MAX_XDELAY_SIZE 1048576
+#endif
+
+namespace Klangraum {
+
+class FX8010 {
+public:
+    // reference: FX8010(int numChannels), include/FX8010.h:51
+    explicit FX8010(int numChannels) : h_(fx_create(numChannels)) {
+        if (!h_) throw std::runtime_error(std::string("FX8010: ") + fx_last_create_error());
+    }
+    ~FX8010() { fx_destroy(h_); }
+    FX8010(const FX8010&) = delete;
+    FX8010& operator=(const FX8010&) = delete;
+
+    // reference: initialize() builds the LOG/EXP tables; here they are built when the library loads
+    void initialize() {}
+
+    // reference: std::vector<float> process(const std::vector<float>&), include/FX8010.h:57
+    std::vector<float> process(const std::vector<float>& inputSamples) {
+        std::vector<float> out((size_t)fx_get_channels(h_), 0.0f);
+        if (fx_process(h_, inputSamples.data(), out.data()) < 0) throw std::runtime_error(std::string("FX8010::process: ") + fx_last_error(h_));
+        return out;
+    }
+    // extension: nSamples consecutive sample periods in one launch; in/out are [nSamples][channels]
+    std::vector<float> processBlock(const std::vector<float>& in, int nSamples) {
+        std::vector<float> out((size_t)nSamples * (size_t)fx_get_channels(h_), 0.0f);
+        if (fx_process_block(h_, in.data(), out.data(), nSamples) < 0) throw std::runtime_error(std::string("FX8010::processBlock: ") + fx_last_error(h_));
+        return out;
+    }
+
+    int getInstructionCounter() { return (int)fx_instruction_counter(h_); }
+    bool loadFile(const std::string& path) { return fx_load_file(h_, path.c_str()) == 1; }
+
+    struct MyError {
+        std::string errorDescription = "";
+        int errorRow = 1;
+    };
+    std::vector<MyError> getErrorList() {
+        std::vector<MyError> v;
+        for (int i = 0, n = fx_error_count(h_); i < n; ++i) v.push_back({fx_error_desc(h_, i), fx_error_row(h_, i)});
+        return v;
+    }
+    int setRegisterValue(const std::string& key, float value) { return fx_set_register(h_, key.c_str(), value); }
+    float getRegisterValue(const std::string& key) { return fx_get_register(h_, key.c_str()); }
+    std::vector<std::string> getControlRegisters() {
+        std::vector<std::string> v;
+        for (int i = 0, n = fx_control_count(h_); i < n; ++i) v.emplace_back(fx_control_at(h_, i));
+        return v;
+    }
+    std::unordered_map<std::string, std::string> getMetaData() {
+        std::unordered_map<std::string, std::string> m;
+        static const char* const keys[] = {"name", "copyright", "created", "engine", "comment", "guid"};
+        char buf[1024];
+        for (const char* k : keys)
+            if (fx_meta_get(h_, k, buf, (int)sizeof buf)) m[k] = buf;
+        return m;
+    }
+    inline void setChannels(int numChannels_) { fx_set_channels(h_, numChannels_); }
+    inline int getChannels() { return fx_get_channels(h_); }
+    bool getReadyStatus() { return fx_ready(h_) != 0; }
+
+private:
+    fx_handle* h_;
+};
+
+// N instances of one program on one GPU.  PCM layout: buf[(sample * channels + channel) * N + instance].
+class FX8010Batch {
+public:
+    FX8010Batch(int64_t nInstances, int numChannels, int device = -1) : n_(nInstances), ch_(numChannels), h_(fxb_create(nInstances, numChannels, device)) {
+        if (!h_) throw std::runtime_error(std::string("FX8010Batch: ") + fx_last_create_error());
+    }
+    ~FX8010Batch() { fxb_destroy(h_); }
+    FX8010Batch(const FX8010Batch&) = delete;
+    FX8010Batch& operator=(const FX8010Batch&) = delete;
+
+    bool loadFile(const std::string& path) { return fxb_load_file(h_, path.c_str()) == 1; }
+    bool loadText(const std::string& text) { return fxb_load_text(h_, text.c_str()) == 1; }
+    int setRegisterValue(const std::string& key, float value) { return fxb_set_register(h_, key.c_str(), value); }
+    int setRegisterValue(const std::string& key, int64_t instance, float value) { return fxb_set_register_i(h_, key.c_str(), instance, value); }
+    float getRegisterValue(const std::string& key, int64_t instance) { return fxb_get_register_i(h_, key.c_str(), instance); }
+    // nSamples sample periods for every instance (host buffers, synchronous)
+    void process(const float* in, float* out, int nSamples) {
+        if (fxb_process_block(h_, in, out, nSamples) < 0) throw std::runtime_error(std::string("FX8010Batch::process: ") + fxb_last_error(h_));
+    }
+    // device-resident buffers, asynchronous on `stream` (hipStream_t)
+    void processDevice(const float* dIn, float* dOut, int nSamples, void* stream = nullptr) {
+        if (fxb_process_block_dev(h_, dIn, dOut, nSamples, stream) < 0) throw std::runtime_error(std::string("FX8010Batch::processDevice: ") + fxb_last_error(h_));
+    }
+    void sync() { fxb_sync(h_); }
+    int64_t getInstructionCounter() { return fxb_instruction_counter(h_); }
+    int64_t getInstructionCounter(int64_t instance) { return fxb_instruction_counter_i(h_, instance); }
+    float lastKernelMs() { return fxb_last_kernel_ms(h_); }
+    int64_t instances() const { return n_; }
+    int channels() const { return ch_; }
+    fxb_handle* handle() { return h_; }
+
+private:
+    int64_t n_;
+    int ch_;
+    fxb_handle* h_;
+};
+
+}  // namespace Klangraum
+
+#endif

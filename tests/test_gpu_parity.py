@@ -292,3 +292,26 @@ def test_load_failure_reports_errors(gpu):
     assert b.errors()[1] == ("Variable nicht deklariert", 2)
     with pytest.raises(RuntimeError):
         b.process_block(np.zeros((4, 64), dtype=np.float32))
+
+
+def test_cpp_drop_in_class_harness(gpu):
+    """host/FX8010.h (the reference's class surface over the C ABI) through its console harness."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "fx8010-emulator-core_amd")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(pkg, "csrc"), "demo"])
+    prog = os.path.join(pkg, "programs", "config1_shipped.da")
+    out = subprocess.run([os.path.join(pkg, "host", "fx8010_demo"), prog, "4096"], stdout=subprocess.PIPE, text=True, check=True).stdout
+    lines = out.strip().split("\n")
+    pairs = [tuple(float(v) for v in l.split(",")) for l in lines[:32]]
+    o = Oracle(1)
+    assert o.load_file(prog)
+    sliders = [0.1, 0.25, 0.5, 1.0]
+    for i, (xin, yout) in enumerate(pairs):
+        if i % 8 == 0:
+            o.set_register("volume", sliders[i // 8])
+        ref = o.process_block(np.array([xin], dtype=np.float32))[0]
+        assert abs(ref - yout) <= 1e-6 * max(1.0, abs(ref)), i  # printed with 6 significant digits
+    assert "64 instructions" in out and "emulated MIPS" in out and "control: volume" in out
