@@ -36,9 +36,11 @@ bool asmEligible(const Lowered& low, std::string* why) {
 std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
     std::vector<MicroOp> out;
     out.reserve(ops.size() + ops.size() / 2 + 2);
+    // records alternate between the kernel's two register sets: odd records use the second branch table
+    auto slotWord = [&](uint32_t slot) { return (slot + ((out.size() & 1) ? (uint32_t)kAsmSlots : 0u)) * 4u; };
     auto bare = [&](uint32_t slot) {
         MicroOp r{};
-        r.w[0] = slot * 4;
+        r.w[0] = slotWord(slot);
         out.push_back(r);
     };
     bool predOpen = false;
@@ -95,7 +97,7 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
             case H_NOISE: slot = AS_NOISE; break;
             default: slot = AS_NOP; break;  // END (single pass) and NOP only count
         }
-        r.w[0] = slot * 4;
+        r.w[0] = slotWord(slot);
         out.push_back(r);
     }
     bare(AS_ENDSAMPLE);

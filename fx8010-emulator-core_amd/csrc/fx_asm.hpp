@@ -55,6 +55,8 @@ enum AsmSlot : uint32_t {
     AS_MACS = 20, AS_MACSN = 36, AS_ACC3 = 52, AS_INTERP = 68  // + kind*2 + ccr, kind = UA | UX<<1 | UY<<2
 };
 
+constexpr int kAsmSlots = 84;  // slots per branch table; the second register set's table follows the first
+
 // the builds of fx_interp_gfx950.S
 enum AsmVariant { ASM_LDS = 0, ASM_V64 = 1, ASM_V128 = 2, ASM_V256 = 3, ASM_VARIANTS = 4 };
 constexpr int kAsmVgprRows[ASM_VARIANTS] = {0, 24, 88, 216};  // register-file rows of the VGPR builds

@@ -97,19 +97,7 @@
 	.p2align	8
 	.type	KNAME,@function
 
-// ------------------------------------------------------------------------------------------ macros
-// NEXT: go to the next record.  The record prefetch (SMEM) shares lgkmcnt with LDS and returns out of
-// order, so it must have been drained by a full lgkmcnt(0) since it was issued.  Handlers that waited
-// for LDS operands already did that and use NEXT (their own ds_write may stay in flight: LDS executes
-// a wave's accesses in order); handlers with no such wait use NEXT_W.
-.macro NEXT_W
-#ifndef RF_VGPR
-	s_waitcnt lgkmcnt(0)
-#endif
-	NEXT
-.endm
-
-// register-file access: row whose offset (LDS build) / index (VGPR build) is in \sreg
+// register-file access used by the prologue / per-sample I/O / epilogue (the handler sets have their own copies)
 .macro LOADV dst, sreg
 #ifdef RF_VGPR
 	s_set_gpr_idx_on \sreg, 1
@@ -130,310 +118,12 @@
 	ds_write_b32 v5, \src
 #endif
 .endm
-// wait for LOADV results (LDS build only; VGPR loads are plain moves)
-.macro WAITOPS
-#ifndef RF_VGPR
-	s_waitcnt lgkmcnt(0)
-#endif
-.endm
 
-.macro NEXT
-#ifdef RF_VGPR
-	s_waitcnt lgkmcnt(0)
-#endif
-	s_mov_b64 s[16:17], s[24:25]
-	s_mov_b64 s[18:19], s[26:27]
-	s_mov_b64 s[20:21], s[28:29]
-	s_mov_b64 s[22:23], s[30:31]
-	s_load_dwordx8 s[24:31], s[4:5], s8
-	s_add_u32 s8, s8, 32
-	s_add_u32 s34, s32, s16
-	s_addc_u32 s35, s33, 0
-	s_setpc_b64 s[34:35]
-.endm
-
-// x86 cvttss2si: truncation, 0x80000000 for NaN and anything outside int32
-.macro CVTT dst, src
-	v_cvt_i32_f32 \dst, \src
-	v_cmp_ngt_f32 vcc, 0x4f000000, \src
-	s_nop 1
-	v_cndmask_b32 \dst, \dst, v28, vcc
-.endm
-
-// reference saturate(x, 1.0f) (FX8010.cpp:275-279); NaN passes through
-.macro SAT reg
-	v_med3_f32 v5, \reg, -1.0, 1.0
-	v_cmp_u_f32 vcc, \reg, \reg
-	s_nop 1
-	v_cndmask_b32 \reg, v5, \reg, vcc
-.endm
-
-// reference wrapAround (FX8010.cpp:299-328): v >= 1 ? v-2 : (v < -1 ? v+2 : v)
-.macro WRAP reg
-	v_add_f32 v5, -2.0, \reg
-	v_add_f32 v6, 2.0, \reg
-	v_cmp_gt_f32 vcc, -1.0, \reg
-	s_nop 1
-	v_cndmask_b32 v6, \reg, v6, vcc
-	v_cmp_le_f32 vcc, 1.0, \reg
-	s_nop 1
-	v_cndmask_b32 \reg, v6, v5, vcc
-.endm
-
-// reference setCCR (FX8010.cpp:211-232): CCR row (row 0) <- flags of \reg
-.macro CCR_FROM reg
-	v_mov_b32 v6, 0
-	v_cmp_eq_f32 vcc, -1.0, \reg
-	v_cmp_eq_f32 s[62:63], 1.0, \reg
-	v_cmp_eq_f32 s[64:65], 0, \reg
-	v_cndmask_b32 v6, v6, v29, vcc
-	v_cndmask_b32 v6, v6, v30, s[62:63]
-	v_cndmask_b32 v6, v6, v32, s[64:65]
-	v_cmp_lt_f32 vcc, 0, \reg
-	v_cmp_gt_f32 s[62:63], 1.0, \reg
-	v_cmp_gt_f32 s[64:65], 0, \reg
-	v_cmp_lt_f32 s[66:67], -1.0, \reg
-	s_and_b64 vcc, vcc, s[62:63]
-	s_and_b64 s[64:65], s[64:65], s[66:67]
-	v_cndmask_b32 v6, v6, 2.0, vcc
-	v_cndmask_b32 v6, v6, v31, s[64:65]
-#ifdef RF_VGPR
-	v_mov_b32 v40, v6
-#else
-	ds_write_b32 v1, v6
-#endif
-.endm
-
-// result in v2 -> row R
-.macro STORE_R
-	STOREV s17, v2
-.endm
-
-// operand fetch of the specialised handlers: \kind bit0/1/2 = A/X/Y is uniform
-.macro FETCH3 kind
-#ifdef RF_VGPR
-	.if ((\kind) & 1) == 0
-	s_set_gpr_idx_on s18, 1
-	v_mov_b32 v2, v40
-	.endif
-	.if ((\kind) & 2) == 0
-	s_set_gpr_idx_on s19, 1
-	v_mov_b32 v3, v40
-	.endif
-	.if ((\kind) & 4) == 0
-	s_set_gpr_idx_on s20, 1
-	v_mov_b32 v4, v40
-	.endif
-	.if (\kind) != 7
-	s_set_gpr_idx_off
-	.endif
-	.if ((\kind) & 1)
-	v_mov_b32 v2, s18
-	.endif
-	.if ((\kind) & 2)
-	v_mov_b32 v3, s19
-	.endif
-	.if ((\kind) & 4)
-	v_mov_b32 v4, s20
-	.endif
-#else
-	.if ((\kind) & 1) == 0
-	v_add_u32 v2, s18, v1
-	ds_read_b32 v2, v2
-	.else
-	v_mov_b32 v2, s18
-	.endif
-	.if ((\kind) & 2) == 0
-	v_add_u32 v3, s19, v1
-	ds_read_b32 v3, v3
-	.else
-	v_mov_b32 v3, s19
-	.endif
-	.if ((\kind) & 4) == 0
-	v_add_u32 v4, s20, v1
-	ds_read_b32 v4, v4
-	.else
-	v_mov_b32 v4, s20
-	.endif
-	.if (\kind) != 7
-	s_waitcnt lgkmcnt(0)
-	.endif
-#endif
-.endm
-
-// operand fetch of the generic handlers: kinds from the flag word w5 (s21)
-.macro GFETCH reg, sreg, bit
-	v_mov_b32 \reg, \sreg
-	s_bitcmp1_b32 s21, \bit
-	s_cbranch_scc1 .Lgf\@
-	LOADV \reg, \sreg
-.Lgf\@:
-.endm
-
-// generic result store: row R, and CCR when flag bit 3 is set
-.macro GSTORE
-	STORE_R
-	s_bitcmp0_b32 s21, 3
-	s_cbranch_scc1 .Lgs\@
-	CCR_FROM v2
-.Lgs\@:
-.endm
-
-.macro HOT_MACS kind, ccr, neg
-	FETCH3 \kind
-	v_mul_f32 v3, v3, v4
-	.if \neg
-	v_sub_f32 v2, v2, v3
-	.else
-	v_add_f32 v2, v2, v3
-	.endif
-	SAT v2
-	STORE_R
-	.if \ccr
-	CCR_FROM v2
-	.endif
-	.if (\kind) == 7
-	NEXT_W
-	.else
-	NEXT
-	.endif
-.endm
-
-.macro HOT_ACC3 kind, ccr
-	FETCH3 \kind
-	v_add_f32 v2, v2, v3
-	v_add_f32 v2, v2, v4
-	SAT v2
-	STORE_R
-	.if \ccr
-	CCR_FROM v2
-	.endif
-	.if (\kind) == 7
-	NEXT_W
-	.else
-	NEXT
-	.endif
-.endm
-
-// INTERP (FX8010.cpp:1180-1187): R = sat((float)((1.0 - (double)X) * (double)A + (double)(X*Y)))
-.macro HOT_INTERP kind, ccr
-	FETCH3 \kind
-	v_mul_f32 v4, v3, v4
-	v_cvt_f64_f32 v[8:9], v2
-	.if ((\kind) & 2)
-	v_mul_f64 v[6:7], s[22:23], v[8:9]
-	.else
-	v_cvt_f64_f32 v[6:7], v3
-	v_add_f64 v[6:7], 1.0, -v[6:7]
-	v_mul_f64 v[6:7], v[6:7], v[8:9]
-	.endif
-	v_cvt_f64_f32 v[8:9], v4
-	v_add_f64 v[6:7], v[6:7], v[8:9]
-	v_cvt_f32_f64 v2, v[6:7]
-	SAT v2
-	STORE_R
-	.if \ccr
-	CCR_FROM v2
-	.endif
-	.if (\kind) == 7
-	NEXT_W
-	.else
-	NEXT
-	.endif
-.endm
-
-// TRAM read (FX8010.cpp:934-967): row R <- buffer[(rpos - p) % size]; rpos = (rpos+1) % size
-.macro TRAM_READ size, slots, baselo, basehi, cur
-	GFETCH v4, s20, 2
-	WAITOPS
-	v_mov_b32 v2, 0
-	s_cmp_lt_i32 \size, 1
-	s_cbranch_scc1 .Ltr0\@
-	CVTT v6, v4
-	s_sub_i32 s62, \size, 1
-	v_min_i32 v6, s62, v6
-	v_max_i32 v6, 0, v6
-	v_sub_u32 v6, \cur, v6
-	v_cmp_gt_i32 vcc, 0, v6
-	v_add_u32 v7, \size, v6
-	v_add_u32 v8, 1, \cur
-	v_cndmask_b32 v6, v6, v7, vcc
-	v_cndmask_b32 v7, 0, 1, vcc
-	v_or_b32 v22, v22, v7
-	v_cmp_gt_i32 vcc, \slots, v6
-	v_lshlrev_b32 v7, 8, v6
-	v_add_u32 v7, v7, v1
-	s_and_saveexec_b64 s[64:65], vcc
-	global_load_dword v2, v7, s[\baselo:\basehi]
-	s_mov_b64 exec, s[64:65]
-	v_cmp_le_i32 vcc, \size, v8
-	s_nop 1
-	v_cndmask_b32 \cur, v8, 0, vcc
-	s_waitcnt vmcnt(0)
-	s_branch .Ltr1\@
-.Ltr0\@:
-	v_or_b32 v22, OOD_TRAM_SIZE0, v22
-.Ltr1\@:
-	STORE_R
-	NEXT
-.endm
-
-// TRAM write (FX8010.cpp:909-927): buffer[wpos + p] <- A (no modulo); wpos = (wpos+1) % size
-.macro TRAM_WRITE size, slots, cap, baselo, basehi, cur
-	GFETCH v2, s18, 0
-	GFETCH v4, s20, 2
-	WAITOPS
-	s_cmp_lt_i32 \size, 1
-	s_cbranch_scc1 .Ltw0\@
-	CVTT v6, v4
-	s_sub_i32 s62, \size, 1
-	v_min_i32 v6, s62, v6
-	v_max_i32 v6, 0, v6
-	v_add_u32 v6, \cur, v6
-	s_min_i32 s63, \slots, \cap
-	v_add_u32 v8, 1, \cur
-	v_cmp_gt_i32 vcc, s63, v6
-	v_lshlrev_b32 v7, 8, v6
-	v_add_u32 v7, v7, v1
-	v_cndmask_b32 v9, OOD_TRAM_WRITE_OOB, 0, vcc
-	v_or_b32 v22, v22, v9
-	s_and_saveexec_b64 s[64:65], vcc
-	global_store_dword v7, v2, s[\baselo:\basehi]
-	s_mov_b64 exec, s[64:65]
-	v_cmp_le_i32 vcc, \size, v8
-	s_nop 1
-	v_cndmask_b32 \cur, v8, 0, vcc
-	s_branch .Ltw1\@
-.Ltw0\@:
-	v_or_b32 v22, OOD_TRAM_SIZE0, v22
-.Ltw1\@:
-	NEXT
-.endm
-
-.macro JT2 op, kind
-	s_branch h_\op\()_\kind\()_0
-	s_branch h_\op\()_\kind\()_1
-.endm
-
-.macro DEF_HOT kind
-h_macs_\kind\()_0:
-	HOT_MACS \kind, 0, 0
-h_macs_\kind\()_1:
-	HOT_MACS \kind, 1, 0
-h_macsn_\kind\()_0:
-	HOT_MACS \kind, 0, 1
-h_macsn_\kind\()_1:
-	HOT_MACS \kind, 1, 1
-h_acc3_\kind\()_0:
-	HOT_ACC3 \kind, 0
-h_acc3_\kind\()_1:
-	HOT_ACC3 \kind, 1
-h_interp_\kind\()_0:
-	HOT_INTERP \kind, 0
-h_interp_\kind\()_1:
-	HOT_INTERP \kind, 1
-.endm
-
+// two-level cpp paste so that SFX expands
+#define FX_PASTE(a, b) a##b
+#define FX_PASTE2(a, b) FX_PASTE(a, b)
+#define H(x) FX_PASTE2(x, SFX)
+#define M(x) FX_PASTE2(x, SFX)
 // ------------------------------------------------------------------------------------------ entry
 KNAME:
 	s_load_dwordx16 s[4:19], s[0:1], KA_STEADY            // steady last rowtab state in out itram xtram
@@ -492,7 +182,7 @@ KNAME:
 	// branch table address
 	s_getpc_b64 s[32:33]
 .Lpc0:
-	s_add_u32 s32, s32, (jump_table-.Lpc0)
+	s_add_u32 s32, s32, (jump_table_a-.Lpc0)
 	s_addc_u32 s33, s33, 0
 
 	// ---- prologue: state rows -> LDS rows
@@ -660,264 +350,61 @@ KNAME:
 	s_setpc_b64 s[34:35]
 
 // ------------------------------------------------------------------------------------------ handlers
+// branch tables of the two register sets, adjacent: slot s of set B is at byte (84 + s) * 4
 	.p2align 6
-jump_table:
-	s_branch h_endsample      // 0
-	s_branch h_nop            // 1
-	s_branch h_pred           // 2
-	s_branch h_unpred         // 3
-	s_branch h_mov            // 4
-	s_branch h_macw           // 5
-	s_branch h_macwn          // 6
-	s_branch h_macintw        // 7
-	s_branch h_andxor         // 8
-	s_branch h_tstneg         // 9
-	s_branch h_limit          // 10
-	s_branch h_limitn         // 11
-	s_branch h_lut            // 12
-	s_branch h_skip           // 13
-	s_branch h_tram_ir        // 14
-	s_branch h_tram_iw        // 15
-	s_branch h_tram_xr        // 16
-	s_branch h_tram_xw        // 17
-	s_branch h_noise          // 18
-	s_branch h_nop            // 19 (reserved)
-	// 20..35 MACS, 36..51 MACSN, 52..67 ACC3, 68..83 INTERP: slot = base + kind*2 + ccr
-	.irp kind, 0, 1, 2, 3, 4, 5, 6, 7
-	JT2 macs, \kind
-	.endr
-	.irp kind, 0, 1, 2, 3, 4, 5, 6, 7
-	JT2 macsn, \kind
-	.endr
-	.irp kind, 0, 1, 2, 3, 4, 5, 6, 7
-	JT2 acc3, \kind
-	.endr
-	.irp kind, 0, 1, 2, 3, 4, 5, 6, 7
-	JT2 interp, \kind
-	.endr
+#define SFX _a
+.macro M(JT2) op, kind
+	s_branch h_\op\()_\kind\()_0\()SFX
+	s_branch h_\op\()_\kind\()_1\()SFX
+.endm
+#include "fx_interp_table.inc"
+#undef SFX
+#define SFX _b
+.macro M(JT2) op, kind
+	s_branch h_\op\()_\kind\()_0\()SFX
+	s_branch h_\op\()_\kind\()_1\()SFX
+.endm
+#include "fx_interp_table.inc"
+#undef SFX
 
-h_nop:
-	NEXT_W
-
-h_unpred:
-	s_mov_b64 exec, -1
-	NEXT_W
-
-// start of an instruction inside a SKIP shadow (FX8010.cpp:1037,1235-1241): lanes with numSkip == 0
-// execute it (EXEC), the others count their skip down
-h_pred:
-	s_mov_b64 exec, -1
-	v_cmp_eq_u32 vcc, 0, v14
-	v_max_i32 v5, 1, v14
-	v_add_u32 v14, -1, v5
-	v_cndmask_b32 v5, 0, 1, vcc
-	v_add_u32 v15, v15, v5
-	s_mov_b64 exec, vcc
-	NEXT_W
-
-h_mov:
-	GFETCH v2, s18, 0
-	WAITOPS
-	GSTORE
-	NEXT
-
-h_macw:                                                   // R = A + wrap(X*Y)   FX8010.cpp:1126-1131
-	GFETCH v2, s18, 0
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-	WAITOPS
-	v_mul_f32 v3, v3, v4
-	WRAP v3
-	v_add_f32 v2, v2, v3
-	GSTORE
-	NEXT
-
-h_macwn:                                                  // R = A - wrap(X*Y)   :1132-1137
-	GFETCH v2, s18, 0
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-	WAITOPS
-	v_mul_f32 v3, v3, v4
-	WRAP v3
-	v_sub_f32 v2, v2, v3
-	GSTORE
-	NEXT
-
-h_macintw:                                                // R = wrap(A + X*Y)   :1138-1143
-	GFETCH v2, s18, 0
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-	WAITOPS
-	v_mul_f32 v3, v3, v4
-	v_add_f32 v2, v2, v3
-	WRAP v2
-	GSTORE
-	NEXT
-
-h_andxor:                                                 // logicOps, FX8010.cpp:330-360, :1150-1154
-	GFETCH v2, s18, 0
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-	WAITOPS
-	CVTT v8, v2                                           // A
-	CVTT v9, v3                                           // X
-	CVTT v10, v4                                          // Y
-	v_and_b32 v2, v8, v9
-	v_xor_b32 v2, v2, v10                                 // (A & X) ^ Y
-	v_not_b32 v11, v8                                     // ~A
-	v_not_b32 v12, v9                                     // ~X
-	v_mov_b32 v13, 0xffffff
-	v_cmp_eq_u32 vcc, v10, v13                            // Y == 0xFFFFFF
-	v_and_b32 v33, v11, v9                                // ~A & X
-	s_nop 0
-	v_cndmask_b32 v2, v2, v33, vcc
-	v_cmp_eq_u32 s[62:63], v10, v12                       // Y == ~X
-	v_or_b32 v33, v8, v10
-	s_nop 0
-	v_cndmask_b32 v2, v2, v33, s[62:63]
-	v_mov_b32 v34, 0xfffffff
-	v_cmp_eq_u32 s[62:63], v9, v34                        // X == 0xFFFFFFF
-	s_and_b64 s[62:63], s[62:63], vcc                     //   && Y == 0xFFFFFF
-	v_cndmask_b32 v2, v2, v11, s[62:63]
-	v_cmp_eq_u32 vcc, v9, v13                             // X == 0xFFFFFF
-	v_xor_b32 v33, v8, v10
-	s_nop 0
-	v_cndmask_b32 v2, v2, v33, vcc
-	v_cmp_eq_u32 vcc, 0, v10                              // Y == 0
-	v_and_b32 v33, v8, v9
-	s_nop 0
-	v_cndmask_b32 v2, v2, v33, vcc
-	v_cvt_f32_i32 v2, v2
-	GSTORE
-	NEXT
-
-h_tstneg:                                                 // R = A >= Y ? X : intToFloat(~floatToInt(X))   :1155-1162
-	GFETCH v2, s18, 0
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-	WAITOPS
-	v_mul_f32 v6, 0x4f000000, v3                          // X * 2^31
-	CVTT v7, v6
-	v_not_b32 v7, v7
-	v_cvt_f32_i32 v7, v7
-	v_mul_f32 v7, 0x30000000, v7                          // exact / 2^31
-	v_cmp_ge_f32 vcc, v2, v4
-	s_nop 1
-	v_cndmask_b32 v2, v7, v3, vcc
-	GSTORE
-	NEXT
-
-h_limit:                                                  // R = A >= Y ? X : Y   :1163-1168
-	GFETCH v2, s18, 0
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-	WAITOPS
-	v_cmp_ge_f32 vcc, v2, v4
-	s_nop 1
-	v_cndmask_b32 v2, v4, v3, vcc
-	GSTORE
-	NEXT
-
-h_limitn:                                                 // R = A < Y ? X : Y   :1169-1174
-	GFETCH v2, s18, 0
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-	WAITOPS
-	v_cmp_lt_f32 vcc, v2, v4
-	s_nop 1
-	v_cndmask_b32 v2, v4, v3, vcc
-	GSTORE
-	NEXT
-
-// LOG / EXP with a uniform table (FX8010.cpp:1113-1125, linearInterpolate :283-296) from the
-// precomputed thresholds and segments (fx_model.hpp LutDevice): w3 = byte offset of the table's
-// {slope, y1} array in the blob.  idx = #{k >= 1 : t >= thr[k]}, guessed from t*31.5 and corrected.
-h_lut:
-	GFETCH v2, s18, 0
-	WAITOPS
-	v_cvt_f64_f32 v[6:7], v2                              // x
-	v_add_f64 v[8:9], v[6:7], 1.0                         // t = x - -1.0
-	v_mov_b32 v10, 0
-	v_mov_b32 v11, 0x403f8000                             // 31.5
-	v_mul_f64 v[10:11], v[8:9], v[10:11]
-	v_cvt_i32_f64 v12, v[10:11]                           // saturating, NaN -> 0
-	v_med3_i32 v12, v12, 0, 63
-	v_lshlrev_b32 v13, 3, v12
-	global_load_dwordx4 v[34:37], v13, s[40:41]           // thr[idx], thr[idx+1]
-	s_waitcnt vmcnt(0)
-	v_cmp_ge_f64 vcc, v[8:9], v[36:37]
-	v_cmp_lt_f64 s[62:63], v[8:9], v[34:35]
-	s_nop 0
-	v_cndmask_b32 v13, 0, 1, vcc
-	v_add_u32 v12, v12, v13
-	v_cndmask_b32 v13, 0, 1, s[62:63]
-	v_sub_u32 v12, v12, v13
-	v_med3_i32 v12, v12, 0, 63
-	// out-of-domain note: t outside [-step, 64*step) or NaN
-	v_mov_b32 v10, 0x10410410
-	v_mov_b32 v11, 0xbfa04104                             // -step = -2/63
-	v_cmp_nge_f64 vcc, v[8:9], v[10:11]
-	v_mov_b32 v10, 0x10410410
-	v_mov_b32 v11, 0x40004104                             // 64*step
-	v_cmp_nlt_f64 s[62:63], v[8:9], v[10:11]
-	s_or_b64 vcc, vcc, s[62:63]
-	v_cndmask_b32 v13, 0, OOD_LUT_INDEX, vcc
-	v_or_b32 v22, v22, v13
-	v_lshlrev_b32 v13, 3, v12
-	v_add_u32 v13, s61, v13
-	global_load_dwordx2 v[38:39], v13, s[40:41]           // x1[idx]
-	v_lshlrev_b32 v13, 4, v12
-	v_add_u32 v13, s19, v13
-	global_load_dwordx4 v[34:37], v13, s[40:41]           // slope, y1
-	s_waitcnt vmcnt(1)
-	v_add_f64 v[6:7], v[6:7], -v[38:39]                   // x - x1
-	s_waitcnt vmcnt(0)
-	v_mul_f64 v[6:7], v[34:35], v[6:7]
-	v_add_f64 v[6:7], v[6:7], v[36:37]
-	v_cvt_f32_f64 v2, v[6:7]
-	GSTORE
-	NEXT
-
-h_skip:                                                   // if ((float)(int)X == CCR) numSkip = (int)Y   :1175-1179
-	GFETCH v3, s19, 1
-	GFETCH v4, s20, 2
-#ifdef RF_VGPR
-	v_mov_b32 v6, v40                                     // CCR row
-#else
-	ds_read_b32 v6, v1                                    // CCR row
-	s_waitcnt lgkmcnt(0)
-#endif
-	CVTT v7, v3
-	v_cvt_f32_i32 v7, v7
-	CVTT v8, v4
-	v_cmp_eq_f32 vcc, v7, v6
-	s_nop 1
-	v_cndmask_b32 v14, v14, v8, vcc
-	NEXT
-
-h_tram_ir:
-	TRAM_READ s56, s46, 36, 37, v17
-h_tram_iw:
-	TRAM_WRITE s56, s46, 8192, 36, 37, v16
-h_tram_xr:
-	TRAM_READ s57, s47, 38, 39, v19
-h_tram_xw:
-	TRAM_WRITE s57, s47, 1048576, 38, 39, v18
-
-h_noise:                                                  // whitenoise(), FX8010.cpp:993-1000
-	v_xor_b32 v20, v20, v21
-	v_cvt_f32_i32 v2, v21
-	v_mul_f32 v2, 0x30000000, v2                          // * 2^-31
-	v_add_u32 v21, v21, v20
-	STORE_R
-	NEXT_W
-
-	.irp kind, 0, 1, 2, 3, 4, 5, 6, 7
-	DEF_HOT \kind
-	.endr
+// set A: even records, registers s[16:23]; the other set's w0 is s24
+#define SFX _a
+#define RW0 s16
+#define RW1 s17
+#define RA s18
+#define RX s19
+#define RY s20
+#define RFLG s21
+#define ROMX s[22:23]
+#define CURSET s[16:23]
+#define OW0 s24
+#include "fx_interp_handlers.inc"
+#undef SFX
+#undef RW0
+#undef RW1
+#undef RA
+#undef RX
+#undef RY
+#undef RFLG
+#undef ROMX
+#undef CURSET
+#undef OW0
+// set B: odd records, registers s[24:31]; the other set's w0 is s16
+#define SFX _b
+#define RW0 s24
+#define RW1 s25
+#define RA s26
+#define RX s27
+#define RY s28
+#define RFLG s29
+#define ROMX s[30:31]
+#define CURSET s[24:31]
+#define OW0 s16
+#include "fx_interp_handlers.inc"
 
 // ---- end of the program for this sample: latch rows -> PCM out, next sample
-h_endsample:
+h_endsample_a:
+h_endsample_b:
 	s_mov_b64 exec, s[58:59]
 	LOADV v2, s52
 	s_mov_b64 s[62:63], s[14:15]
