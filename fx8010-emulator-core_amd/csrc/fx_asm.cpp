@@ -36,8 +36,8 @@ bool asmEligible(const Lowered& low, std::string* why) {
 std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
     std::vector<MicroOp> out;
     out.reserve(ops.size() + ops.size() / 2 + 2);
-    // records alternate between the kernel's two register sets: odd records use the second branch table
-    auto slotWord = [&](uint32_t slot) { return (slot + ((out.size() & 1) ? (uint32_t)kAsmSlots : 0u)) * 4u; };
+    // records cycle through the kernel's four register sets, each with its own branch table
+    auto slotWord = [&](uint32_t slot) { return (slot + (uint32_t)(out.size() & 3) * (uint32_t)kAsmSlots) * 4u; };
     auto bare = [&](uint32_t slot) {
         MicroOp r{};
         r.w[0] = slotWord(slot);
@@ -101,7 +101,7 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
         out.push_back(r);
     }
     bare(AS_ENDSAMPLE);
-    bare(AS_NOP);  // pad: the fetch runs one record ahead
+    for (int k = 0; k < 4; ++k) bare(AS_NOP);  // pad: the fetch runs up to two windows (four records) ahead
     return out;
 }
 

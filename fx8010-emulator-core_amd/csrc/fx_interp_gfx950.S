@@ -90,7 +90,7 @@
 //  s44 channels  s45 bytes per sample (channels*N*4)  s46 iSlots  s47 xSlots  s[48:51] input row offsets
 //  s[52:55] latch row offsets  s56 iSize  s57 xSize  s[58:59] lanes with instance < N  s60 state row pitch (nPad*4)
 //  s61 byte offset of x1[] in the LUT blob  s62-s67 temporaries  s68 bytes per channel-sample (N*4)
-//  s[72:73] row table  s82 nLoad  s83 nStore  s88 cursor state row  s89 LFSR state row
+//  s[72:73] row table  s96 nLoad  s97 nStore  s100 cursor state row  s101 LFSR state row
 
 	.text
 	.globl	KNAME
@@ -128,7 +128,7 @@
 KNAME:
 	s_load_dwordx16 s[4:19], s[0:1], KA_STEADY            // steady last rowtab state in out itram xtram
 	s_load_dwordx8  s[40:47], s[0:1], KA_LUT              // lut n npad nload nstore
-	s_load_dwordx2  s[80:81], s[0:1], KA_NSAMPLES         // nSamples channels
+	s_load_dwordx2  s[98:99], s[0:1], KA_NSAMPLES         // nSamples channels
 	v_lshlrev_b32 v1, 2, v0
 	s_lshl_b32 s62, s2, 6
 	v_add_u32 v27, s62, v0                                // instance
@@ -152,22 +152,22 @@ KNAME:
 	s_lshl_b32 s60, s44, 2                                // state row pitch in bytes
 	s_lshl_b32 s68, s42, 2                                // bytes of one channel of one sample (N*4)
 	v_lshlrev_b32 v27, 2, v27                             // instance*4
-	s_mov_b32 s9, s80                                     // nSamples
-	s_mov_b32 s82, s46                                    // nLoad
-	s_mov_b32 s83, s47                                    // nStore
-	s_mov_b32 s44, s81                                    // channels
+	s_mov_b32 s9, s98                                     // nSamples
+	s_mov_b32 s96, s46                                    // nLoad
+	s_mov_b32 s97, s47                                    // nStore
+	s_mov_b32 s44, s99                                    // channels
 	s_mul_i32 s45, s42, s44
 	s_lshl_b32 s45, s45, 2                                // bytes per sample of PCM = channels * N * 4
 	s_mov_b64 s[42:43], s[70:71]                          // last-sample stream
 	s_load_dwordx8  s[48:55], s[0:1], KA_INOFF            // inOff[4] latchOff[4]
-	s_load_dwordx4  s[84:87], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
-	s_load_dwordx2  s[88:89], s[0:1], KA_CURSORROW        // cursorRow noiseRow
+	s_load_dwordx4  s[64:67], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
+	s_load_dwordx2  s[100:101], s[0:1], KA_CURSORROW      // cursorRow noiseRow
 	s_load_dword    s61, s[0:1], KA_LUTX1OFF
 	s_waitcnt lgkmcnt(0)
-	s_mov_b32 s46, s84
-	s_mov_b32 s47, s85
-	s_mov_b32 s56, s86
-	s_mov_b32 s57, s87
+	s_mov_b32 s46, s64
+	s_mov_b32 s47, s65
+	s_mov_b32 s56, s66
+	s_mov_b32 s57, s67
 	// TRAM base of this wave: base + wave * slots * 256
 	s_mul_i32 s62, s2, s46
 	s_mul_hi_u32 s63, s2, s46
@@ -187,7 +187,7 @@ KNAME:
 
 	// ---- prologue: state rows -> LDS rows
 	s_mov_b32 s62, 0
-	s_cmp_eq_u32 s82, 0
+	s_cmp_eq_u32 s96, 0
 	s_cbranch_scc1 .Lload_done
 .Lload_loop:
 	s_lshl_b32 s63, s62, 2
@@ -206,12 +206,12 @@ KNAME:
 	s_waitcnt vmcnt(0)
 	STOREV s64, v2
 	s_add_u32 s62, s62, 1
-	s_cmp_lt_u32 s62, s82
+	s_cmp_lt_u32 s62, s96
 	s_cbranch_scc1 .Lload_loop
 .Lload_done:
 	// cursors and LFSR words straight into VGPRs
-	s_mul_i32 s66, s88, s60
-	s_mul_hi_u32 s67, s88, s60
+	s_mul_i32 s66, s100, s60
+	s_mul_hi_u32 s67, s100, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_load_dword v16, v27, s[66:67]
@@ -224,8 +224,8 @@ KNAME:
 	s_add_u32 s66, s66, s60
 	s_addc_u32 s67, s67, 0
 	global_load_dword v19, v27, s[66:67]
-	s_mul_i32 s66, s89, s60
-	s_mul_hi_u32 s67, s89, s60
+	s_mul_i32 s66, s101, s60
+	s_mul_hi_u32 s67, s101, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_load_dword v20, v27, s[66:67]
@@ -341,16 +341,16 @@ KNAME:
 	s_cselect_b32 s4, s42, s6
 	s_cselect_b32 s5, s43, s7
 	v_mov_b32 v14, 0                                      // numSkip is local to process() (FX8010.cpp:1030)
-	s_load_dwordx8 s[16:23], s[4:5], 0x0
-	s_load_dwordx8 s[24:31], s[4:5], 0x20
-	s_mov_b32 s8, 64
+	s_load_dwordx16 s[16:31], s[4:5], 0x0                 // records 0, 1
+	s_load_dwordx16 s[80:95], s[4:5], 0x40                // records 2, 3
+	s_mov_b32 s8, 128
 	s_waitcnt lgkmcnt(0)
 	s_add_u32 s34, s32, s16
 	s_addc_u32 s35, s33, 0
 	s_setpc_b64 s[34:35]
 
 // ------------------------------------------------------------------------------------------ handlers
-// branch tables of the two register sets, adjacent: slot s of set B is at byte (84 + s) * 4
+// branch tables of the four register sets, adjacent: slot s of set k is at byte (84*k + s) * 4
 	.p2align 6
 #define SFX _a
 .macro M(JT2) op, kind
@@ -366,8 +366,22 @@ KNAME:
 .endm
 #include "fx_interp_table.inc"
 #undef SFX
+#define SFX _c
+.macro M(JT2) op, kind
+	s_branch h_\op\()_\kind\()_0\()SFX
+	s_branch h_\op\()_\kind\()_1\()SFX
+.endm
+#include "fx_interp_table.inc"
+#undef SFX
+#define SFX _d
+.macro M(JT2) op, kind
+	s_branch h_\op\()_\kind\()_0\()SFX
+	s_branch h_\op\()_\kind\()_1\()SFX
+.endm
+#include "fx_interp_table.inc"
+#undef SFX
 
-// set A: even records, registers s[16:23]; the other set's w0 is s24
+// records 4n, 4n+1 live in window s[16:31], records 4n+2, 4n+3 in window s[80:95]
 #define SFX _a
 #define RW0 s16
 #define RW1 s17
@@ -376,8 +390,9 @@ KNAME:
 #define RY s20
 #define RFLG s21
 #define ROMX s[22:23]
-#define CURSET s[16:23]
 #define OW0 s24
+#define WINDOW s[16:31]
+#define NEXT_LOADS 0
 #include "fx_interp_handlers.inc"
 #undef SFX
 #undef RW0
@@ -387,9 +402,9 @@ KNAME:
 #undef RY
 #undef RFLG
 #undef ROMX
-#undef CURSET
 #undef OW0
-// set B: odd records, registers s[24:31]; the other set's w0 is s16
+#undef WINDOW
+#undef NEXT_LOADS
 #define SFX _b
 #define RW0 s24
 #define RW1 s25
@@ -398,13 +413,73 @@ KNAME:
 #define RY s28
 #define RFLG s29
 #define ROMX s[30:31]
-#define CURSET s[24:31]
-#define OW0 s16
+#define OW0 s80
+#define WINDOW s[16:31]
+#define NEXT_LOADS 1
 #include "fx_interp_handlers.inc"
+#undef SFX
+#undef RW0
+#undef RW1
+#undef RA
+#undef RX
+#undef RY
+#undef RFLG
+#undef ROMX
+#undef OW0
+#undef WINDOW
+#undef NEXT_LOADS
+#define SFX _c
+#define RW0 s80
+#define RW1 s81
+#define RA s82
+#define RX s83
+#define RY s84
+#define RFLG s85
+#define ROMX s[86:87]
+#define OW0 s88
+#define WINDOW s[80:95]
+#define NEXT_LOADS 0
+#include "fx_interp_handlers.inc"
+#undef SFX
+#undef RW0
+#undef RW1
+#undef RA
+#undef RX
+#undef RY
+#undef RFLG
+#undef ROMX
+#undef OW0
+#undef WINDOW
+#undef NEXT_LOADS
+#define SFX _d
+#define RW0 s88
+#define RW1 s89
+#define RA s90
+#define RX s91
+#define RY s92
+#define RFLG s93
+#define ROMX s[94:95]
+#define OW0 s16
+#define WINDOW s[80:95]
+#define NEXT_LOADS 1
+#include "fx_interp_handlers.inc"
+#undef SFX
+#undef RW0
+#undef RW1
+#undef RA
+#undef RX
+#undef RY
+#undef RFLG
+#undef ROMX
+#undef OW0
+#undef WINDOW
+#undef NEXT_LOADS
 
 // ---- end of the program for this sample: latch rows -> PCM out, next sample
 h_endsample_a:
 h_endsample_b:
+h_endsample_c:
+h_endsample_d:
 	s_mov_b64 exec, s[58:59]
 	LOADV v2, s52
 	s_mov_b64 s[62:63], s[14:15]
@@ -446,10 +521,10 @@ h_endsample_b:
 .Lepilogue:
 	s_waitcnt vmcnt(0) lgkmcnt(0)
 	s_mov_b32 s62, 0
-	s_cmp_eq_u32 s83, 0
+	s_cmp_eq_u32 s97, 0
 	s_cbranch_scc1 .Lstore_done
 .Lstore_loop:
-	s_add_u32 s63, s62, s82
+	s_add_u32 s63, s62, s96
 	s_lshl_b32 s63, s63, 2
 	s_load_dword s64, s[72:73], s63
 	s_waitcnt lgkmcnt(0)
@@ -466,11 +541,11 @@ h_endsample_b:
 	s_waitcnt lgkmcnt(0)
 	global_store_dword v27, v2, s[66:67]
 	s_add_u32 s62, s62, 1
-	s_cmp_lt_u32 s62, s83
+	s_cmp_lt_u32 s62, s97
 	s_cbranch_scc1 .Lstore_loop
 .Lstore_done:
-	s_mul_i32 s66, s88, s60
-	s_mul_hi_u32 s67, s88, s60
+	s_mul_i32 s66, s100, s60
+	s_mul_hi_u32 s67, s100, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_store_dword v27, v16, s[66:67]
@@ -483,8 +558,8 @@ h_endsample_b:
 	s_add_u32 s66, s66, s60
 	s_addc_u32 s67, s67, 0
 	global_store_dword v27, v19, s[66:67]
-	s_mul_i32 s66, s89, s60
-	s_mul_hi_u32 s67, s89, s60
+	s_mul_i32 s66, s101, s60
+	s_mul_hi_u32 s67, s101, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_store_dword v27, v20, s[66:67]
@@ -539,7 +614,7 @@ h_endsample_b:
 		.amdhsa_system_sgpr_workgroup_id_x 1
 		.amdhsa_system_vgpr_workitem_id 0
 		.amdhsa_next_free_vgpr NVGPR
-		.amdhsa_next_free_sgpr 96
+		.amdhsa_next_free_sgpr 102
 		.amdhsa_accum_offset NVGPR
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_round_mode_32 0
