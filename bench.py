@@ -72,6 +72,22 @@ def usable_cores():
     return max(1, min(n, 16))
 
 
+def measured_traffic(config, n_inst, n_samples):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/*hbm_traffic*.json: FETCH_SIZE and
+    WRITE_SIZE in their own passes, gfx950 read correction applied) when one exists for exactly this workload."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json"))):
+        try:
+            d = json.load(open(f))
+            w = d["workload"]
+            if w["config"] == config and w["instances"] == n_inst and w["samples"] == n_samples:
+                return float(d["hbm_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
+
+
 def cpu_baseline(text, budget_s):
     """Time the reference (or, without oracle/_ref, the C port) on the host cores: bounded sample."""
     import tempfile
@@ -171,8 +187,9 @@ def main():
         mips = executed_all / elapsed / 1e6
         tram_ops = batch.info("tram_ops")
         rows = batch.info("num_rows")
-        kernel_kind = {0: "fx_step_block (HIP C++)", 1: "fx_interp_lds (gfx950 asm, LDS register file)", 2: "fx_interp_v64 (gfx950 asm, VGPR register file)",
-                       3: "fx_interp_v128 (gfx950 asm, VGPR register file)", 4: "fx_interp_v256 (gfx950 asm, VGPR register file)"}[batch.info("kernel")]
+        kid = batch.info("kernel")
+        kernel_kind = ("fx_step_block (HIP C++)" if kid == 0 else "fx_interp_lds (gfx950 asm, LDS register file)" if kid == 1 else
+                       "fx_interp_v%d (gfx950 asm, VGPR register file)" % (0, 0, 64, 72, 80, 96, 128, 168, 256)[kid])
         # algorithmic HBM bytes of ONE launch on ONE GPU: PCM in+out, every executed
         # TRAM read/write, and the once-per-block register-file spill/fill
         bytes_per_inst_sample = 4 * (1 + 1) + 4 * tram_ops
@@ -206,7 +223,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": measured_traffic(args.config, n_inst, S),
                 "kernel": kernel_kind,
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_last_launch": round(last_ms, 4),

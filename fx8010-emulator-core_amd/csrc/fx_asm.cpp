@@ -25,7 +25,7 @@ bool asmEligible(const Lowered& low, std::string* why) {
     if (low.instPerLane != 1) return no("more than one instance per lane");
     if (low.multipass) return no("END can be skipped (multi-pass program)");
     if (low.rowPitch != 1 && (size_t)low.nRows * 256 > 64 * 1024) return no("register file above 64 KiB of LDS");
-    if (low.rowPitch == 1 && low.nRows > kAsmVgprRows[ASM_V256]) return no("register file above 216 VGPR rows");
+    if (low.rowPitch == 1 && low.nRows > kAsmVgprRows[ASM_V256]) return no("register file above 224 VGPR rows");
     for (const MicroOp& m : low.steady) {
         const uint32_t h = handlerOf(m);
         if ((h == H_LOG || h == H_EXP) && (!has(m, F_UX) || has(m, F_STATIC_OOD))) return no("LOG/EXP with a per-instance or out-of-range table");
@@ -109,7 +109,8 @@ hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBy
     static std::mutex mu;
     static hipModule_t modules[64] = {};
     static hipFunction_t funcs[64][ASM_VARIANTS] = {};
-    static const char* const names[ASM_VARIANTS] = {"fx_interp_lds", "fx_interp_v64", "fx_interp_v128", "fx_interp_v256"};
+    static const char* const names[ASM_VARIANTS] = {"fx_interp_lds", "fx_interp_v64", "fx_interp_v72", "fx_interp_v80", "fx_interp_v96",
+                                                    "fx_interp_v128", "fx_interp_v168", "fx_interp_v256"};
     if (device < 0 || device >= 64) return hipErrorInvalidDevice;
     {
         std::lock_guard<std::mutex> lock(mu);

@@ -58,8 +58,10 @@ enum AsmSlot : uint32_t {
 constexpr int kAsmSlots = 84;  // slots per branch table; the second register set's table follows the first
 
 // the builds of fx_interp_gfx950.S
-enum AsmVariant { ASM_LDS = 0, ASM_V64 = 1, ASM_V128 = 2, ASM_V256 = 3, ASM_VARIANTS = 4 };
-constexpr int kAsmVgprRows[ASM_VARIANTS] = {0, 24, 88, 216};  // register-file rows of the VGPR builds
+enum AsmVariant { ASM_LDS = 0, ASM_V64, ASM_V72, ASM_V80, ASM_V96, ASM_V128, ASM_V168, ASM_V256, ASM_VARIANTS };
+// register-file rows of the VGPR builds (VGPRs - 32) and the wavefronts per SIMD their VGPR count allows
+constexpr int kAsmVgprRows[ASM_VARIANTS] = {0, 32, 40, 48, 64, 96, 136, 224};
+constexpr int kAsmWavesPerSimd[ASM_VARIANTS] = {0, 8, 7, 6, 5, 4, 3, 2};
 
 // Can this lowering (K = 1, bookkeeping in VGPRs) run on the assembly kernel?  `why` says why not.
 bool asmEligible(const Lowered& low, std::string* why);

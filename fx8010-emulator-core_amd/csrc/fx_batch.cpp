@@ -217,9 +217,17 @@ int Batch::ensureLowered() {
         if (tryVgpr) {
             fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false, 1);
             asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
-            if (asmOk) asmVariant_ = fresh.nRows <= kAsmVgprRows[ASM_V64] ? ASM_V64 : (fresh.nRows <= kAsmVgprRows[ASM_V128] ? ASM_V128 : ASM_V256);
-            if (asmOk && forceHip && std::strcmp(forceHip, "asm_v256") == 0) asmVariant_ = ASM_V256;
-            if (asmOk && forceHip && std::strcmp(forceHip, "asm_v128") == 0 && fresh.nRows <= kAsmVgprRows[ASM_V128]) asmVariant_ = ASM_V128;
+            if (asmOk) {
+                // smallest VGPR build that holds the register file = most wavefronts per SIMD
+                int v = ASM_V64;
+                while (v < ASM_V256 && fresh.nRows > kAsmVgprRows[v]) ++v;
+                if (forceHip && std::strncmp(forceHip, "asm_v", 5) == 0) {  // diagnostics: pin a (large enough) build
+                    static const char* const tags[ASM_VARIANTS] = {"", "asm_v64", "asm_v72", "asm_v80", "asm_v96", "asm_v128", "asm_v168", "asm_v256"};
+                    for (int q = v; q < ASM_VARIANTS; ++q)
+                        if (std::strcmp(forceHip, tags[q]) == 0) v = q;
+                }
+                asmVariant_ = (AsmVariant)v;
+            }
         }
         if (!asmOk) {
             fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false);

@@ -26,16 +26,17 @@
 
 // This file is assembled several times (clang -x assembler-with-cpp):
 //   -DKNAME=fx_interp_lds                 register file in LDS (any size up to the LDS budget)
-//   -DKNAME=fx_interp_v64  -DRF_VGPR -DNVGPR=64    register file in VGPRs v40.. (VGPR index mode, M0),
-//   -DKNAME=fx_interp_v128 -DRF_VGPR -DNVGPR=128   no LDS traffic and no operand latency at all;
-//   -DKNAME=fx_interp_v256 -DRF_VGPR -DNVGPR=256   24 / 88 / 216 rows at 8 / 4 / 2 wavefronts per SIMD
+//   -DKNAME=fx_interp_vNN -DRF_VGPR -DNVGPR=NN    register file in VGPRs v32.. (VGPR index mode, M0): no LDS
+//        traffic and no operand latency at all.  NN = 64 / 72 / 80 / 96 / 128 / 168 / 256 gives
+//        32 / 40 / 48 / 64 / 96 / 136 / 224 rows at 8 / 7 / 6 / 5 / 4 / 3 / 2 wavefronts per SIMD.
 // In the VGPR build a "row offset" in a record is simply the row index.
 #ifndef KNAME
 #define KNAME fx_interp_lds
 #endif
 #ifndef NVGPR
-#define NVGPR 40
+#define NVGPR 32
 #endif
+#define RF v32   /* first register of the VGPR register file; v0..v31 belong to the interpreter */
 
 	.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
 	.amdhsa_code_object_version 6
@@ -81,7 +82,7 @@
 //  v0 lane  v1 lane*4  v2 a/result  v3 x  v4 y  v5 address  v6-v13 temporaries
 //  v14 numSkip  v15 executed-shadowed count  v16 iw  v17 ir  v18 xw  v19 xr  v20 g1  v21 g2  v22 ood
 //  v23-v26 prefetched input of channel 0-3   v27 instance*4 (byte offset into a PCM / state row)
-//  v28 0x80000000  v29 20.0  v30 16.0  v31 6.0  v32 8.0   v33-v39 temporaries
+//  v28 0x80000000   (v29-v31 spare)   v32.. register file of the VGPR builds
 // ---- SGPRs ----
 //  s[0:1] kernarg  s2 wave index  s3 sample  s[4:5] stream of this sample  s[6:7] steady  s8 fetch offset
 //  s9 nSamples  s[10:11] state  s[12:13] in (this sample)  s[14:15] out (this sample)
@@ -101,7 +102,7 @@
 .macro LOADV dst, sreg
 #ifdef RF_VGPR
 	s_set_gpr_idx_on \sreg, 1
-	v_mov_b32 \dst, v40
+	v_mov_b32 \dst, RF
 	s_set_gpr_idx_off
 #else
 	v_add_u32 \dst, \sreg, v1
@@ -111,7 +112,7 @@
 .macro STOREV sreg, src
 #ifdef RF_VGPR
 	s_set_gpr_idx_on \sreg, 8
-	v_mov_b32 v40, \src
+	v_mov_b32 RF, \src
 	s_set_gpr_idx_off
 #else
 	v_add_u32 v5, \sreg, v1
@@ -133,10 +134,6 @@ KNAME:
 	s_lshl_b32 s62, s2, 6
 	v_add_u32 v27, s62, v0                                // instance
 	v_mov_b32 v28, 0x80000000
-	v_mov_b32 v29, 0x41a00000                             // 20.0
-	v_mov_b32 v30, 0x41800000                             // 16.0
-	v_mov_b32 v31, 0x40c00000                             // 6.0
-	v_mov_b32 v32, 0x41000000                             // 8.0
 	v_mov_b32 v14, 0
 	v_mov_b32 v15, 0
 	v_mov_b32 v22, 0

@@ -146,7 +146,7 @@ enum {
     FXB_INFO_GRID = 14,            /* workgroups of the last launch                       */
     FXB_INFO_INST_PER_LANE = 15,   /* instances one lane steps (kernel variant)           */
     FXB_INFO_KERNEL = 16,          /* 0 = HIP C++ kernel; hand-written gfx950 assembly: 1 = register file in LDS,
-                                      2/3/4 = register file in VGPRs (64/128/256-VGPR build) */
+                                      2..8 = register file in VGPRs (64/72/80/96/128/168/256-VGPR build) */
     FXB_INFO_NUM_ROWS = 17         /* rows of the per-instance register file               */
 };
 int64_t fxb_info(fxb_handle* h, int what);

@@ -84,7 +84,7 @@ def test_config_programs_bit_exact(gpu, name, k):
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
     b, _ = check_batch(gpu, text, x, regs=regs)
     if isinstance(k, str):
-        want = {"asm": (2, 3, 4), "asm_v256": (4,), "asm_lds": (1,)}[k]
+        want = {"asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
         assert b.info("kernel") in want and b.info("inst_per_lane") == 1
     else:
         assert b.info("kernel") == 0 and b.info("inst_per_lane") == k
