@@ -33,14 +33,24 @@ bool asmEligible(const Lowered& low, std::string* why) {
     return true;
 }
 
-std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
+namespace {
+inline float asFloat(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint32_t asBits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float sat1(float v) { return (v >= 1.0f) ? 1.0f : ((v <= -1.0f) ? -1.0f : v); }  // reference saturate()
+}  // namespace
+
+std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint64_t* handlers, bool foldUniform) {
     std::vector<MicroOp> out;
-    out.reserve(ops.size() + ops.size() / 2 + 2);
-    // records cycle through the kernel's four register sets, each with its own branch table
-    auto slotWord = [&](uint32_t slot) { return (slot + (uint32_t)(out.size() & 3) * (uint32_t)kAsmSlots) * 4u; };
+    out.reserve(ops.size() + ops.size() / 2 + 8);
+    // records cycle through the kernel's four register sets; each set has its own copy of every handler
+    auto setAddress = [&](MicroOp& r, uint32_t slot) {
+        const uint64_t a = handlers[(out.size() % kAsmSets) * kAsmSlots + slot];
+        r.w[0] = (uint32_t)a;
+        r.w[1] = (uint32_t)(a >> 32);
+    };
     auto bare = [&](uint32_t slot) {
         MicroOp r{};
-        r.w[0] = slotWord(slot);
+        setAddress(r, slot);
         out.push_back(r);
     };
     bool predOpen = false;
@@ -56,23 +66,45 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
         const uint32_t kind = (has(m, F_UA) ? 1u : 0u) | (has(m, F_UX) ? 2u : 0u) | (has(m, F_UY) ? 4u : 0u);
         const uint32_t ccr = has(m, F_CCR) ? 1u : 0u;
         MicroOp r{};
-        r.w[1] = m.w[1];
         r.w[2] = m.w[2];
         r.w[3] = m.w[3];
         r.w[4] = m.w[4];
-        r.w[5] = kind | (ccr << 3);
+        r.w[5] = m.w[1];               // destination row
+        r.w[6] = kind | (ccr << 3);    // flags of the generic handlers
         uint32_t slot = AS_NOP;
         switch (h) {
-            case H_MACS: slot = AS_MACS + kind * 2 + ccr; break;
-            case H_MACSN: slot = AS_MACSN + kind * 2 + ccr; break;
-            case H_ACC3: slot = AS_ACC3 + kind * 2 + ccr; break;
+            case H_MACS:
+            case H_MACSN: {
+                slot = (h == H_MACS ? AS_MACS : AS_MACSN) + kind * 2 + ccr;
+                if (foldUniform && (kind & 6u) == 6u) {  // uniform X and Y: p = X*Y once, here
+                    const float prod = asFloat(m.w[3]) * asFloat(m.w[4]);
+                    r.w[3] = asBits(prod);
+                    if (kind == 7u) {
+                        const float a = asFloat(m.w[2]);
+                        r.w[2] = asBits(sat1(h == H_MACS ? a + prod : a - prod));
+                    }
+                }
+                break;
+            }
+            case H_ACC3:
+                slot = AS_ACC3 + kind * 2 + ccr;
+                if (foldUniform && (kind & 3u) == 3u) {  // uniform A and X: t = A + X once, here
+                    const float t = asFloat(m.w[2]) + asFloat(m.w[3]);
+                    r.w[2] = asBits(kind == 7u ? sat1(t + asFloat(m.w[4])) : t);
+                }
+                break;
             case H_INTERP: {
                 slot = AS_INTERP + kind * 2 + ccr;
-                if (kind & 2u) {  // uniform X: (1.0 - (double)X) is the same for every instance
-                    float x;
-                    std::memcpy(&x, &m.w[3], 4);
-                    const double omx = 1.0 - (double)x;
-                    std::memcpy(&r.w[6], &omx, 8);
+                const float x = asFloat(m.w[3]);
+                const double omx = 1.0 - (double)x;
+                if (kind & 2u) std::memcpy(&r.w[6], &omx, 8);  // uniform X: (1.0 - (double)X) is the same for every instance
+                if (foldUniform && (kind & 6u) == 6u) {
+                    const float prod = x * asFloat(m.w[4]);
+                    r.w[3] = asBits(prod);
+                    if (kind == 7u) {
+                        const double d = omx * (double)asFloat(m.w[2]) + (double)prod;
+                        r.w[2] = asBits(sat1((float)d));
+                    }
                 }
                 break;
             }
@@ -97,7 +129,7 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
             case H_NOISE: slot = AS_NOISE; break;
             default: slot = AS_NOP; break;  // END (single pass) and NOP only count
         }
-        r.w[0] = slotWord(slot);
+        setAddress(r, slot);
         out.push_back(r);
     }
     bare(AS_ENDSAMPLE);
@@ -105,29 +137,73 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops) {
     return out;
 }
 
-hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream) {
-    static std::mutex mu;
-    static hipModule_t modules[64] = {};
-    static hipFunction_t funcs[64][ASM_VARIANTS] = {};
-    static const char* const names[ASM_VARIANTS] = {"fx_interp_lds", "fx_interp_v64", "fx_interp_v72", "fx_interp_v80", "fx_interp_v96",
-                                                    "fx_interp_v128", "fx_interp_v168", "fx_interp_v256"};
+namespace {
+std::mutex g_mu;
+hipModule_t g_modules[64] = {};
+hipFunction_t g_funcs[64][ASM_VARIANTS] = {};
+uint64_t* g_tables[64][ASM_VARIANTS] = {};
+const char* const kVariantNames[ASM_VARIANTS] = {"fx_interp_lds", "fx_interp_v64", "fx_interp_v72", "fx_interp_v80", "fx_interp_v96",
+                                                 "fx_interp_v128", "fx_interp_v168", "fx_interp_v256"};
+
+hipError_t functionFor(AsmVariant variant, int device, hipFunction_t* fn) {
     if (device < 0 || device >= 64) return hipErrorInvalidDevice;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!modules[device]) {
-            hipError_t e = hipModuleLoadData(&modules[device], kInterpBlob);
-            if (e != hipSuccess) return e;
-        }
-        if (!funcs[device][variant]) {
-            hipError_t e = hipModuleGetFunction(&funcs[device][variant], modules[device], names[variant]);
-            if (e != hipSuccess) return e;
-        }
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_modules[device]) {
+        hipError_t e = hipModuleLoadData(&g_modules[device], kInterpBlob);
+        if (e != hipSuccess) return e;
     }
+    if (!g_funcs[device][variant]) {
+        hipError_t e = hipModuleGetFunction(&g_funcs[device][variant], g_modules[device], kVariantNames[variant]);
+        if (e != hipSuccess) return e;
+    }
+    *fn = g_funcs[device][variant];
+    return hipSuccess;
+}
+
+hipError_t launchRaw(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream) {
     AsmArgs a = args;
     size_t size = sizeof(a);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    const unsigned grid = (unsigned)((args.n + 63) / 64);
-    return hipModuleLaunchKernel(funcs[device][variant], grid, 1, 1, 64, 1, 1, (unsigned)ldsBytes, stream, nullptr, config);
+    return hipModuleLaunchKernel(fn, grid, 1, 1, 64, 1, 1, (unsigned)ldsBytes, stream, nullptr, config);
+}
+}  // namespace
+
+// One wavefront of the build runs in probe mode and writes the absolute address of each of its
+// kAsmSets * kAsmSlots handlers; they stay valid for as long as the module is loaded.
+const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err) {
+    hipFunction_t fn;
+    hipError_t e = functionFor(variant, device, &fn);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!g_tables[device][variant]) {
+            const size_t bytes = sizeof(uint64_t) * kAsmSets * kAsmSlots;
+            uint64_t* dbuf = nullptr;
+            e = hipMalloc(reinterpret_cast<void**>(&dbuf), bytes);
+            if (e == hipSuccess) {
+                AsmArgs a{};
+                a.out = reinterpret_cast<float*>(dbuf);
+                a.nSamples = (int)kAsmProbeMagic;
+                a.n = 64;
+                a.nPad = 256;
+                e = launchRaw(fn, a, 1, 0, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                uint64_t* host = new uint64_t[kAsmSets * kAsmSlots];
+                if (e == hipSuccess) e = hipMemcpy(host, dbuf, bytes, hipMemcpyDeviceToHost);
+                (void)hipFree(dbuf);
+                if (e == hipSuccess) g_tables[device][variant] = host;
+                else delete[] host;
+            }
+        }
+    }
+    if (err) *err = e;
+    return e == hipSuccess ? g_tables[device][variant] : nullptr;
+}
+
+hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream) {
+    hipFunction_t fn;
+    hipError_t e = functionFor(variant, device, &fn);
+    if (e != hipSuccess) return e;
+    return launchRaw(fn, args, (unsigned)((args.n + 63) / 64), ldsBytes, stream);
 }
 
 }  // namespace fx

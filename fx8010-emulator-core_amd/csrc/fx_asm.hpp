@@ -47,7 +47,7 @@ static_assert(offsetof(AsmArgs, oodRow) == 0xa0, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, lutX1Off) == 0xb0, "AsmArgs layout");
 static_assert(sizeof(AsmArgs) == 0xb8, "AsmArgs layout");
 
-// branch-table slots of fx_interp_gfx950.s (jump_table)
+// handler slots of fx_interp_gfx950.S (fx_interp_table.inc)
 enum AsmSlot : uint32_t {
     AS_ENDSAMPLE = 0, AS_NOP = 1, AS_PRED = 2, AS_UNPRED = 3, AS_MOV = 4, AS_MACW = 5, AS_MACWN = 6, AS_MACINTW = 7,
     AS_ANDXOR = 8, AS_TSTNEG = 9, AS_LIMIT = 10, AS_LIMITN = 11, AS_LUT = 12, AS_SKIP = 13, AS_TRAM_IR = 14,
@@ -66,9 +66,18 @@ constexpr int kAsmWavesPerSimd[ASM_VARIANTS] = {0, 8, 7, 6, 5, 4, 3, 2};
 // Can this lowering (K = 1, bookkeeping in VGPRs) run on the assembly kernel?  `why` says why not.
 bool asmEligible(const Lowered& low, std::string* why);
 
-// Translate one lowered stream into the assembly kernel's records (SKIP shadows become PRED/UNPRED
-// brackets, the stream ends with ENDSAMPLE plus one pad record for the fetch-ahead).
-std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops);
+constexpr int kAsmSets = 4;            // record register sets of the kernel (records cycle through them)
+constexpr uint32_t kAsmProbeMagic = 0x7ffffff0u;  // nSamples value that makes the kernel dump its handler addresses
+
+// Absolute addresses of a build's handlers on a device: [set][slot], obtained once by a probe launch.
+const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err);
+
+// Translate one lowered stream into the assembly kernel's records: w0:w1 = handler address, w2..w4 = A/X/Y,
+// w5 = R, w6 = flags or w6:w7 = (1-X) for INTERP (SKIP shadows become PRED/UNPRED brackets, the stream ends
+// with ENDSAMPLE plus pad records for the fetch-ahead).
+// foldUniform (VGPR builds): products / sums / whole expressions of uniform operands are evaluated here, with
+// the same IEEE operations, and the handlers of those operand kinds expect the folded value (see the .S).
+std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint64_t* handlers, bool foldUniform);
 
 // Loads the embedded code object on the device (once per device) and launches the chosen build
 // with ceil(n/64) single-wavefront workgroups and ldsBytes of dynamic LDS (0 for the VGPR builds).

@@ -256,8 +256,12 @@ int Batch::ensureLowered() {
 
     // upload: steady | last | row table
     if (useAsm_) {
-        low_.steady = encodeAsmStream(low_.steady);
-        low_.last = encodeAsmStream(low_.last);
+        hipError_t pe = hipSuccess;
+        const uint64_t* handlers = asmHandlerTable(asmVariant_, device_, &pe);
+        if (!handlers) return hipFail(pe, "probe of the assembly interpreter");
+        const bool fold = asmVariant_ != ASM_LDS;
+        low_.steady = encodeAsmStream(low_.steady, handlers, fold);
+        low_.last = encodeAsmStream(low_.last, handlers, fold);
     }
     const size_t nOps = low_.steady.size();
     const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size();

@@ -4,15 +4,15 @@
 // decoder (fx_asm_stream.cpp) turns the program into 32-byte records; this kernel is a
 // direct-threaded interpreter over them:
 //
-//   record  w0 = handler slot * 4 (byte offset into the branch table below)
-//           w1 = LDS byte offset of the destination row R
-//           w2/w3/w4 = operand A/X/Y: LDS byte offset of its row, or the IEEE bits of a uniform value
-//           w5 = flags for the generic handlers (bit0 A uniform, bit1 X uniform, bit2 Y uniform, bit3 write CCR)
-//                / byte offset of the LOG/EXP segment table
+//   record  w0:w1 = absolute address of the handler (patched in by the host from the probe launch)
+//           w2/w3/w4 = operand A/X/Y: offset (LDS build) or index (VGPR builds) of its row, or the IEEE
+//                      bits of a uniform value; LOG/EXP: w3 = byte offset of the segment table
+//           w5 = destination row R (offset / index)
+//           w6 = flags for the generic handlers (bit0 A uniform, bit1 X uniform, bit2 Y uniform, bit3 write CCR)
 //           w6:w7 = (1.0 - X) as a double for INTERP with a uniform X
 //
 //   fetch    one s_load_dwordx8 per record, issued one record ahead (s[24:31]) while s[16:23] executes
-//   dispatch s_setpc_b64 into a table of s_branch — no compare chain, the record names its handler;
+//   dispatch one s_setpc_b64 to the address in the record — no compare chain, no table hop;
 //            MACS/MACSN/ACC3/INTERP have one handler per (operand kinds x CCR) so they test nothing
 //   state    per-lane register file in LDS (row r at r*256 + lane*4, conflict-free); CCR = row 0;
 //            skip counter, TRAM cursors, LFSR, flags in VGPRs; SKIP shadows run under EXEC
@@ -71,6 +71,7 @@
 	.set KA_STATICCNT,0xac
 	.set KA_LUTX1OFF, 0xb0      // byte offset of x1[] inside the LUT blob
 	.set KA_SIZE,     0xb8
+	.set PROBE_MAGIC, 0x7ffffff0
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
 	.set OOD_TRAM_READ_NEG, 1
@@ -91,7 +92,7 @@
 //  s44 channels  s45 bytes per sample (channels*N*4)  s46 iSlots  s47 xSlots  s[48:51] input row offsets
 //  s[52:55] latch row offsets  s56 iSize  s57 xSize  s[58:59] lanes with instance < N  s60 state row pitch (nPad*4)
 //  s61 byte offset of x1[] in the LUT blob  s62-s67 temporaries  s68 bytes per channel-sample (N*4)
-//  s[72:73] row table  s96 nLoad  s97 nStore  s100 cursor state row  s101 LFSR state row
+//  s[72:73] row table  s74 nLoad  s75 nStore  s76 cursor state row  s77 LFSR state row
 
 	.text
 	.globl	KNAME
@@ -129,7 +130,38 @@
 KNAME:
 	s_load_dwordx16 s[4:19], s[0:1], KA_STEADY            // steady last rowtab state in out itram xtram
 	s_load_dwordx8  s[40:47], s[0:1], KA_LUT              // lut n npad nload nstore
-	s_load_dwordx2  s[98:99], s[0:1], KA_NSAMPLES         // nSamples channels
+	s_load_dwordx2  s[64:65], s[0:1], KA_NSAMPLES         // nSamples channels
+	// probe mode (nSamples == PROBE_MAGIC): write the absolute address of every handler (4 sets x 84 slots,
+	// 64-bit each) to `out` and leave; the host patches these into the records it encodes
+	s_waitcnt lgkmcnt(0)
+	s_cmp_lg_u32 s64, PROBE_MAGIC
+	s_cbranch_scc1 .Lnot_probe
+	s_getpc_b64 s[62:63]
+.Lpc1:
+	s_sub_u32 s62, s62, (.Lpc1-KNAME)                     // address of the kernel entry
+	s_subb_u32 s63, s63, 0
+	s_add_u32 s64, s62, (offset_table-KNAME)
+	s_addc_u32 s65, s63, 0
+	v_mov_b32 v4, v0                                      // slot index handled by this lane
+.Lprobe_loop:
+	v_cmp_gt_u32 vcc, 336, v4
+	s_and_saveexec_b64 s[66:67], vcc
+	s_cbranch_execz .Lprobe_done
+	v_lshlrev_b32 v5, 2, v4
+	global_load_dword v2, v5, s[64:65]
+	v_mov_b32 v3, s63
+	s_waitcnt vmcnt(0)
+	v_add_co_u32 v2, vcc, s62, v2
+	s_nop 1
+	v_addc_co_u32 v3, vcc, 0, v3, vcc
+	v_lshlrev_b32 v5, 3, v4
+	global_store_dwordx2 v5, v[2:3], s[14:15]
+	v_add_u32 v4, 64, v4
+	s_branch .Lprobe_loop
+.Lprobe_done:
+	s_waitcnt vmcnt(0)
+	s_endpgm
+.Lnot_probe:
 	v_lshlrev_b32 v1, 2, v0
 	s_lshl_b32 s62, s2, 6
 	v_add_u32 v27, s62, v0                                // instance
@@ -149,16 +181,16 @@ KNAME:
 	s_lshl_b32 s60, s44, 2                                // state row pitch in bytes
 	s_lshl_b32 s68, s42, 2                                // bytes of one channel of one sample (N*4)
 	v_lshlrev_b32 v27, 2, v27                             // instance*4
-	s_mov_b32 s9, s98                                     // nSamples
-	s_mov_b32 s96, s46                                    // nLoad
-	s_mov_b32 s97, s47                                    // nStore
-	s_mov_b32 s44, s99                                    // channels
+	s_mov_b32 s9, s64                                     // nSamples
+	s_mov_b32 s74, s46                                    // nLoad
+	s_mov_b32 s75, s47                                    // nStore
+	s_mov_b32 s44, s65                                    // channels
 	s_mul_i32 s45, s42, s44
 	s_lshl_b32 s45, s45, 2                                // bytes per sample of PCM = channels * N * 4
 	s_mov_b64 s[42:43], s[70:71]                          // last-sample stream
 	s_load_dwordx8  s[48:55], s[0:1], KA_INOFF            // inOff[4] latchOff[4]
 	s_load_dwordx4  s[64:67], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
-	s_load_dwordx2  s[100:101], s[0:1], KA_CURSORROW      // cursorRow noiseRow
+	s_load_dwordx2  s[76:77], s[0:1], KA_CURSORROW      // cursorRow noiseRow
 	s_load_dword    s61, s[0:1], KA_LUTX1OFF
 	s_waitcnt lgkmcnt(0)
 	s_mov_b32 s46, s64
@@ -176,15 +208,10 @@ KNAME:
 	s_lshl_b64 s[62:63], s[62:63], 8
 	s_add_u32 s38, s38, s62
 	s_addc_u32 s39, s39, s63
-	// branch table address
-	s_getpc_b64 s[32:33]
-.Lpc0:
-	s_add_u32 s32, s32, (jump_table_a-.Lpc0)
-	s_addc_u32 s33, s33, 0
 
 	// ---- prologue: state rows -> LDS rows
 	s_mov_b32 s62, 0
-	s_cmp_eq_u32 s96, 0
+	s_cmp_eq_u32 s74, 0
 	s_cbranch_scc1 .Lload_done
 .Lload_loop:
 	s_lshl_b32 s63, s62, 2
@@ -203,12 +230,12 @@ KNAME:
 	s_waitcnt vmcnt(0)
 	STOREV s64, v2
 	s_add_u32 s62, s62, 1
-	s_cmp_lt_u32 s62, s96
+	s_cmp_lt_u32 s62, s74
 	s_cbranch_scc1 .Lload_loop
 .Lload_done:
 	// cursors and LFSR words straight into VGPRs
-	s_mul_i32 s66, s100, s60
-	s_mul_hi_u32 s67, s100, s60
+	s_mul_i32 s66, s76, s60
+	s_mul_hi_u32 s67, s76, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_load_dword v16, v27, s[66:67]
@@ -221,8 +248,8 @@ KNAME:
 	s_add_u32 s66, s66, s60
 	s_addc_u32 s67, s67, 0
 	global_load_dword v19, v27, s[66:67]
-	s_mul_i32 s66, s101, s60
-	s_mul_hi_u32 s67, s101, s60
+	s_mul_i32 s66, s77, s60
+	s_mul_hi_u32 s67, s77, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_load_dword v20, v27, s[66:67]
@@ -342,133 +369,125 @@ KNAME:
 	s_load_dwordx16 s[80:95], s[4:5], 0x40                // records 2, 3
 	s_mov_b32 s8, 128
 	s_waitcnt lgkmcnt(0)
-	s_add_u32 s34, s32, s16
-	s_addc_u32 s35, s33, 0
-	s_setpc_b64 s[34:35]
+	s_setpc_b64 s[16:17]
 
 // ------------------------------------------------------------------------------------------ handlers
-// branch tables of the four register sets, adjacent: slot s of set k is at byte (84*k + s) * 4
+// handler offsets (bytes from the kernel entry) of the four register sets, 84 slots each; read only by the
+// probe mode, which turns them into absolute addresses for the host to put into the records
 	.p2align 6
+offset_table:
 #define SFX _a
 .macro M(JT2) op, kind
-	s_branch h_\op\()_\kind\()_0\()SFX
-	s_branch h_\op\()_\kind\()_1\()SFX
+	.long h_\op\()_\kind\()_0\()SFX - KNAME
+	.long h_\op\()_\kind\()_1\()SFX - KNAME
 .endm
 #include "fx_interp_table.inc"
 #undef SFX
 #define SFX _b
 .macro M(JT2) op, kind
-	s_branch h_\op\()_\kind\()_0\()SFX
-	s_branch h_\op\()_\kind\()_1\()SFX
+	.long h_\op\()_\kind\()_0\()SFX - KNAME
+	.long h_\op\()_\kind\()_1\()SFX - KNAME
 .endm
 #include "fx_interp_table.inc"
 #undef SFX
 #define SFX _c
 .macro M(JT2) op, kind
-	s_branch h_\op\()_\kind\()_0\()SFX
-	s_branch h_\op\()_\kind\()_1\()SFX
+	.long h_\op\()_\kind\()_0\()SFX - KNAME
+	.long h_\op\()_\kind\()_1\()SFX - KNAME
 .endm
 #include "fx_interp_table.inc"
 #undef SFX
 #define SFX _d
 .macro M(JT2) op, kind
-	s_branch h_\op\()_\kind\()_0\()SFX
-	s_branch h_\op\()_\kind\()_1\()SFX
+	.long h_\op\()_\kind\()_0\()SFX - KNAME
+	.long h_\op\()_\kind\()_1\()SFX - KNAME
 .endm
 #include "fx_interp_table.inc"
 #undef SFX
 
 // records 4n, 4n+1 live in window s[16:31], records 4n+2, 4n+3 in window s[80:95]
 #define SFX _a
-#define RW0 s16
-#define RW1 s17
 #define RA s18
 #define RX s19
 #define RY s20
-#define RFLG s21
+#define RW1 s21
+#define RFLG s22
 #define ROMX s[22:23]
-#define OW0 s24
+#define OWPC s[24:25]
 #define WINDOW s[16:31]
 #define NEXT_LOADS 0
 #include "fx_interp_handlers.inc"
 #undef SFX
-#undef RW0
-#undef RW1
 #undef RA
 #undef RX
 #undef RY
+#undef RW1
 #undef RFLG
 #undef ROMX
-#undef OW0
+#undef OWPC
 #undef WINDOW
 #undef NEXT_LOADS
 #define SFX _b
-#define RW0 s24
-#define RW1 s25
 #define RA s26
 #define RX s27
 #define RY s28
-#define RFLG s29
+#define RW1 s29
+#define RFLG s30
 #define ROMX s[30:31]
-#define OW0 s80
+#define OWPC s[80:81]
 #define WINDOW s[16:31]
 #define NEXT_LOADS 1
 #include "fx_interp_handlers.inc"
 #undef SFX
-#undef RW0
-#undef RW1
 #undef RA
 #undef RX
 #undef RY
+#undef RW1
 #undef RFLG
 #undef ROMX
-#undef OW0
+#undef OWPC
 #undef WINDOW
 #undef NEXT_LOADS
 #define SFX _c
-#define RW0 s80
-#define RW1 s81
 #define RA s82
 #define RX s83
 #define RY s84
-#define RFLG s85
+#define RW1 s85
+#define RFLG s86
 #define ROMX s[86:87]
-#define OW0 s88
+#define OWPC s[88:89]
 #define WINDOW s[80:95]
 #define NEXT_LOADS 0
 #include "fx_interp_handlers.inc"
 #undef SFX
-#undef RW0
-#undef RW1
 #undef RA
 #undef RX
 #undef RY
+#undef RW1
 #undef RFLG
 #undef ROMX
-#undef OW0
+#undef OWPC
 #undef WINDOW
 #undef NEXT_LOADS
 #define SFX _d
-#define RW0 s88
-#define RW1 s89
 #define RA s90
 #define RX s91
 #define RY s92
-#define RFLG s93
+#define RW1 s93
+#define RFLG s94
 #define ROMX s[94:95]
-#define OW0 s16
+#define OWPC s[16:17]
 #define WINDOW s[80:95]
 #define NEXT_LOADS 1
 #include "fx_interp_handlers.inc"
 #undef SFX
-#undef RW0
-#undef RW1
 #undef RA
 #undef RX
 #undef RY
+#undef RW1
 #undef RFLG
 #undef ROMX
-#undef OW0
+#undef OWPC
 #undef WINDOW
 #undef NEXT_LOADS
 
@@ -518,10 +537,10 @@ h_endsample_d:
 .Lepilogue:
 	s_waitcnt vmcnt(0) lgkmcnt(0)
 	s_mov_b32 s62, 0
-	s_cmp_eq_u32 s97, 0
+	s_cmp_eq_u32 s75, 0
 	s_cbranch_scc1 .Lstore_done
 .Lstore_loop:
-	s_add_u32 s63, s62, s96
+	s_add_u32 s63, s62, s74
 	s_lshl_b32 s63, s63, 2
 	s_load_dword s64, s[72:73], s63
 	s_waitcnt lgkmcnt(0)
@@ -538,11 +557,11 @@ h_endsample_d:
 	s_waitcnt lgkmcnt(0)
 	global_store_dword v27, v2, s[66:67]
 	s_add_u32 s62, s62, 1
-	s_cmp_lt_u32 s62, s97
+	s_cmp_lt_u32 s62, s75
 	s_cbranch_scc1 .Lstore_loop
 .Lstore_done:
-	s_mul_i32 s66, s100, s60
-	s_mul_hi_u32 s67, s100, s60
+	s_mul_i32 s66, s76, s60
+	s_mul_hi_u32 s67, s76, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_store_dword v27, v16, s[66:67]
@@ -555,8 +574,8 @@ h_endsample_d:
 	s_add_u32 s66, s66, s60
 	s_addc_u32 s67, s67, 0
 	global_store_dword v27, v19, s[66:67]
-	s_mul_i32 s66, s101, s60
-	s_mul_hi_u32 s67, s101, s60
+	s_mul_i32 s66, s77, s60
+	s_mul_hi_u32 s67, s77, s60
 	s_add_u32 s66, s66, s10
 	s_addc_u32 s67, s67, s11
 	global_store_dword v27, v20, s[66:67]
@@ -576,26 +595,26 @@ h_endsample_d:
 	s_add_u32 s70, s70, s10
 	s_addc_u32 s71, s71, s11
 	global_load_dword v3, v27, s[70:71]
-	s_mul_i32 s74, s66, s60
-	s_mul_hi_u32 s75, s66, s60
-	s_add_u32 s74, s74, s10
-	s_addc_u32 s75, s75, s11
-	global_load_dword v4, v27, s[74:75]
-	s_mul_i32 s76, s67, s9                                // staticCount * nSamples (low)
-	s_mul_hi_u32 s77, s67, s9
+	s_mul_i32 s20, s66, s60
+	s_mul_hi_u32 s21, s66, s60
+	s_add_u32 s20, s20, s10
+	s_addc_u32 s21, s21, s11
+	global_load_dword v4, v27, s[20:21]
+	s_mul_i32 s22, s67, s9                                // staticCount * nSamples (low)
+	s_mul_hi_u32 s23, s67, s9
 	s_waitcnt vmcnt(2)
 	v_or_b32 v2, v2, v22
 	global_store_dword v27, v2, s[68:69]
-	v_mov_b32 v6, s77
+	v_mov_b32 v6, s23
 	s_waitcnt vmcnt(1)
-	v_add_co_u32 v3, vcc, s76, v3
+	v_add_co_u32 v3, vcc, s22, v3
 	s_nop 1
 	v_addc_co_u32 v4, vcc, v4, v6, vcc
 	v_add_co_u32 v3, vcc, v3, v15
 	s_nop 1
 	v_addc_co_u32 v4, vcc, 0, v4, vcc
 	global_store_dword v27, v3, s[70:71]
-	global_store_dword v27, v4, s[74:75]
+	global_store_dword v27, v4, s[20:21]
 	s_endpgm
 .Lfunc_end0:
 	.size	KNAME, .Lfunc_end0-KNAME
@@ -611,7 +630,7 @@ h_endsample_d:
 		.amdhsa_system_sgpr_workgroup_id_x 1
 		.amdhsa_system_vgpr_workitem_id 0
 		.amdhsa_next_free_vgpr NVGPR
-		.amdhsa_next_free_sgpr 102
+		.amdhsa_next_free_sgpr 96
 		.amdhsa_accum_offset NVGPR
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_round_mode_32 0
