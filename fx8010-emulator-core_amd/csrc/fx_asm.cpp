@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "fx_kernel.hpp"
 #include "fx_model.hpp"
@@ -168,21 +169,24 @@ hipError_t launchRaw(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_
 }
 }  // namespace
 
-// One wavefront of the build runs in probe mode and writes the absolute address of each of its
-// kAsmSets * kAsmSlots handlers; they stay valid for as long as the module is loaded.
+// One wavefront of the build's probe kernel (<name>_probe, same code object) writes the absolute address of
+// each of the build's kAsmSets * kAsmSlots handlers; they stay valid for as long as the module is loaded.
 const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err) {
     hipFunction_t fn;
-    hipError_t e = functionFor(variant, device, &fn);
+    hipError_t e = functionFor(variant, device, &fn);  // loads the module
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lock(g_mu);
         if (!g_tables[device][variant]) {
+            const std::string probeName = std::string(kVariantNames[variant]) + "_probe";
+            e = hipModuleGetFunction(&fn, g_modules[device], probeName.c_str());
+        }
+        if (e == hipSuccess && !g_tables[device][variant]) {
             const size_t bytes = sizeof(uint64_t) * kAsmSets * kAsmSlots;
             uint64_t* dbuf = nullptr;
             e = hipMalloc(reinterpret_cast<void**>(&dbuf), bytes);
             if (e == hipSuccess) {
                 AsmArgs a{};
                 a.out = reinterpret_cast<float*>(dbuf);
-                a.nSamples = (int)kAsmProbeMagic;
                 a.n = 64;
                 a.nPad = 256;
                 e = launchRaw(fn, a, 1, 0, nullptr);

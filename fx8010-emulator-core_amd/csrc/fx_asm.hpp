@@ -67,7 +67,6 @@ constexpr int kAsmWavesPerSimd[ASM_VARIANTS] = {0, 8, 7, 6, 5, 4, 3, 2};
 bool asmEligible(const Lowered& low, std::string* why);
 
 constexpr int kAsmSets = 4;            // record register sets of the kernel (records cycle through them)
-constexpr uint32_t kAsmProbeMagic = 0x7ffffff0u;  // nSamples value that makes the kernel dump its handler addresses
 
 // Absolute addresses of a build's handlers on a device: [set][slot], obtained once by a probe launch.
 const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err);

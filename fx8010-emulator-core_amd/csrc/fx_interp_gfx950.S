@@ -33,6 +33,9 @@
 #ifndef KNAME
 #define KNAME fx_interp_lds
 #endif
+#define PNAME_PASTE(a) a##_probe
+#define PNAME_PASTE2(a) PNAME_PASTE(a)
+#define PNAME PNAME_PASTE2(KNAME)
 #ifndef NVGPR
 #define NVGPR 32
 #endif
@@ -71,7 +74,6 @@
 	.set KA_STATICCNT,0xac
 	.set KA_LUTX1OFF, 0xb0      // byte offset of x1[] inside the LUT blob
 	.set KA_SIZE,     0xb8
-	.set PROBE_MAGIC, 0x7ffffff0
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
 	.set OOD_TRAM_READ_NEG, 1
@@ -131,37 +133,6 @@ KNAME:
 	s_load_dwordx16 s[4:19], s[0:1], KA_STEADY            // steady last rowtab state in out itram xtram
 	s_load_dwordx8  s[40:47], s[0:1], KA_LUT              // lut n npad nload nstore
 	s_load_dwordx2  s[64:65], s[0:1], KA_NSAMPLES         // nSamples channels
-	// probe mode (nSamples == PROBE_MAGIC): write the absolute address of every handler (4 sets x 84 slots,
-	// 64-bit each) to `out` and leave; the host patches these into the records it encodes
-	s_waitcnt lgkmcnt(0)
-	s_cmp_lg_u32 s64, PROBE_MAGIC
-	s_cbranch_scc1 .Lnot_probe
-	s_getpc_b64 s[62:63]
-.Lpc1:
-	s_sub_u32 s62, s62, (.Lpc1-KNAME)                     // address of the kernel entry
-	s_subb_u32 s63, s63, 0
-	s_add_u32 s64, s62, (offset_table-KNAME)
-	s_addc_u32 s65, s63, 0
-	v_mov_b32 v4, v0                                      // slot index handled by this lane
-.Lprobe_loop:
-	v_cmp_gt_u32 vcc, 336, v4
-	s_and_saveexec_b64 s[66:67], vcc
-	s_cbranch_execz .Lprobe_done
-	v_lshlrev_b32 v5, 2, v4
-	global_load_dword v2, v5, s[64:65]
-	v_mov_b32 v3, s63
-	s_waitcnt vmcnt(0)
-	v_add_co_u32 v2, vcc, s62, v2
-	s_nop 1
-	v_addc_co_u32 v3, vcc, 0, v3, vcc
-	v_lshlrev_b32 v5, 3, v4
-	global_store_dwordx2 v5, v[2:3], s[14:15]
-	v_add_u32 v4, 64, v4
-	s_branch .Lprobe_loop
-.Lprobe_done:
-	s_waitcnt vmcnt(0)
-	s_endpgm
-.Lnot_probe:
 	v_lshlrev_b32 v1, 2, v0
 	s_lshl_b32 s62, s2, 6
 	v_add_u32 v27, s62, v0                                // instance
@@ -619,6 +590,44 @@ h_endsample_d:
 .Lfunc_end0:
 	.size	KNAME, .Lfunc_end0-KNAME
 
+// ------------------------------------------------------------------------------------------ probe kernel
+// One wavefront: writes the absolute address of every handler of this build (4 sets x 84 slots, 64-bit
+// each) to `out`; the host puts these into the records it encodes (fx_asm.cpp asmHandlerTable). A kernel
+// of its own so that it does not show up among the interpreter's launches in a kernel trace.
+	.globl	PNAME
+	.p2align	8
+	.type	PNAME,@function
+PNAME:
+	s_load_dwordx2 s[14:15], s[0:1], KA_OUT
+	s_getpc_b64 s[62:63]
+.Lpc1:
+	s_sub_u32 s62, s62, (.Lpc1-KNAME)                     // address of the interpreter's entry
+	s_subb_u32 s63, s63, 0
+	s_add_u32 s64, s62, (offset_table-KNAME)
+	s_addc_u32 s65, s63, 0
+	v_mov_b32 v4, v0                                      // slot index handled by this lane
+	s_waitcnt lgkmcnt(0)
+.Lprobe_loop:
+	v_cmp_gt_u32 vcc, 336, v4
+	s_and_saveexec_b64 s[66:67], vcc
+	s_cbranch_execz .Lprobe_done
+	v_lshlrev_b32 v5, 2, v4
+	global_load_dword v2, v5, s[64:65]
+	v_mov_b32 v3, s63
+	s_waitcnt vmcnt(0)
+	v_add_co_u32 v2, vcc, s62, v2
+	s_nop 1
+	v_addc_co_u32 v3, vcc, 0, v3, vcc
+	v_lshlrev_b32 v5, 3, v4
+	global_store_dwordx2 v5, v[2:3], s[14:15]
+	v_add_u32 v4, 64, v4
+	s_branch .Lprobe_loop
+.Lprobe_done:
+	s_waitcnt vmcnt(0)
+	s_endpgm
+.Lfunc_end1:
+	.size	PNAME, .Lfunc_end1-PNAME
+
 	.rodata
 	.p2align	6, 0x0
 	.amdhsa_kernel KNAME
@@ -640,6 +649,20 @@ h_endsample_d:
 		.amdhsa_dx10_clamp 1
 		.amdhsa_ieee_mode 1
 	.end_amdhsa_kernel
+	.p2align	6, 0x0
+	.amdhsa_kernel PNAME
+		.amdhsa_group_segment_fixed_size 0
+		.amdhsa_private_segment_fixed_size 0
+		.amdhsa_kernarg_size KA_SIZE
+		.amdhsa_user_sgpr_count 2
+		.amdhsa_user_sgpr_kernarg_segment_ptr 1
+		.amdhsa_system_sgpr_workgroup_id_x 1
+		.amdhsa_system_vgpr_workitem_id 0
+		.amdhsa_next_free_vgpr 8
+		.amdhsa_next_free_sgpr 72
+		.amdhsa_accum_offset 8
+		.amdhsa_reserve_vcc 1
+	.end_amdhsa_kernel
 
 	.amdgpu_metadata
 ---
@@ -657,6 +680,20 @@ amdhsa.kernels:
     .sgpr_count: 102
     .symbol: KNAME.kd
     .vgpr_count: NVGPR
+    .wavefront_size: 64
+  - .args:
+      - .offset: 0
+        .size: 184
+        .value_kind: by_value
+    .group_segment_fixed_size: 0
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 184
+    .max_flat_workgroup_size: 64
+    .name: PNAME
+    .private_segment_fixed_size: 0
+    .sgpr_count: 80
+    .symbol: PNAME.kd
+    .vgpr_count: 8
     .wavefront_size: 64
 amdhsa.target: amdgcn-amd-amdhsa--gfx950
 amdhsa.version:
