@@ -188,8 +188,11 @@ def main():
         tram_ops = batch.info("tram_ops")
         rows = batch.info("num_rows")
         kid = batch.info("kernel")
-        kernel_kind = ("fx_step_block (HIP C++)" if kid == 0 else "fx_interp_lds (gfx950 asm, LDS register file)" if kid == 1 else
-                       "fx_interp_v%d (gfx950 asm, VGPR register file)" % (0, 0, 64, 72, 80, 96, 128, 168, 256)[kid])
+        vg = (0, 0, 64, 72, 80, 96, 128, 168, 256)
+        kernel_kind = ("fx_step_block (HIP C++)" if kid == 0 else "fx_interp_lds (gfx950 asm interpreter, LDS register file)" if kid == 1 else
+                       "fx_interp_v%d (gfx950 asm interpreter, VGPR register file)" % vg[kid] if kid <= 8 else
+                       "fx_xlate_v%d (program translated to gfx950 code: %d records inline, %d handler calls, %d code bytes)"
+                       % (vg[kid - 7], batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_code_bytes")))
         # algorithmic HBM bytes of ONE launch on ONE GPU: PCM in+out, every executed
         # TRAM read/write, and the once-per-block register-file spill/fill
         bytes_per_inst_sample = 4 * (1 + 1) + 4 * tram_ops

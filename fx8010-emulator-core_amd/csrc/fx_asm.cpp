@@ -45,7 +45,7 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
     out.reserve(ops.size() + ops.size() / 2 + 8);
     // records cycle through the kernel's four register sets; each set has its own copy of every handler
     auto setAddress = [&](MicroOp& r, uint32_t slot) {
-        const uint64_t a = handlers[(out.size() % kAsmSets) * kAsmSlots + slot];
+        const uint64_t a = handlers ? handlers[(out.size() % kAsmSets) * kAsmSlots + slot] : (uint64_t)slot;
         r.w[0] = (uint32_t)a;
         r.w[1] = (uint32_t)(a >> 32);
     };
@@ -201,6 +201,10 @@ const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err)
     }
     if (err) *err = e;
     return e == hipSuccess ? g_tables[device][variant] : nullptr;
+}
+
+hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, hipStream_t stream) {
+    return launchRaw(fn, args, (unsigned)((args.n + 63) / 64), 0, stream);
 }
 
 hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream) {

@@ -82,4 +82,8 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
 // with ceil(n/64) single-wavefront workgroups and ldsBytes of dynamic LDS (0 for the VGPR builds).
 hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream);
 
+// Launches a kernel with the interpreter's argument block from another module (a translated program, fx_xlate.hpp):
+// ceil(n/64) single-wavefront workgroups, no LDS.
+hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, hipStream_t stream);
+
 }  // namespace fx

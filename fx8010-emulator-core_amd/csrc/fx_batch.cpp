@@ -66,6 +66,7 @@ Batch::~Batch() {
     (void)hipFree(dScratch_);
     (void)hipFree(dIn_);
     (void)hipFree(dOut_);
+    if (xlateModule_) (void)hipModuleUnload(xlateModule_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -221,10 +222,12 @@ int Batch::ensureLowered() {
                 // smallest VGPR build that holds the register file = most wavefronts per SIMD
                 int v = ASM_V64;
                 while (v < ASM_V256 && fresh.nRows > kAsmVgprRows[v]) ++v;
-                if (forceHip && std::strncmp(forceHip, "asm_v", 5) == 0) {  // diagnostics: pin a (large enough) build
-                    static const char* const tags[ASM_VARIANTS] = {"", "asm_v64", "asm_v72", "asm_v80", "asm_v96", "asm_v128", "asm_v168", "asm_v256"};
+                const char* pin = forceHip ? std::strstr(forceHip, "_v") : nullptr;
+                if (pin && (std::strncmp(forceHip, "asm_v", 5) == 0 || std::strncmp(forceHip, "xlate_v", 7) == 0)) {
+                    // diagnostics: pin a (large enough) build of the interpreter (asm_vNN) or of the translator (xlate_vNN)
+                    static const char* const tags[ASM_VARIANTS] = {"", "_v64", "_v72", "_v80", "_v96", "_v128", "_v168", "_v256"};
                     for (int q = v; q < ASM_VARIANTS; ++q)
-                        if (std::strcmp(forceHip, tags[q]) == 0) v = q;
+                        if (std::strcmp(pin, tags[q]) == 0) v = q;
                 }
                 asmVariant_ = (AsmVariant)v;
             }
@@ -255,7 +258,29 @@ int Batch::ensureLowered() {
     if ((rc = ensureTram()) != 0) return rc;
 
     // upload: steady | last | row table
-    if (useAsm_) {
+    useXlate_ = false;
+    if (useAsm_ && asmVariant_ != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
+        // first choice for a VGPR build: translate the program into gfx950 code (FX_KERNEL=asm* pins the interpreter)
+        const XlateTemplate* tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
+        XlateImage image;
+        if (tmpl && buildXlateImage(encodeAsmStream(low_.steady, nullptr, true), encodeAsmStream(low_.last, nullptr, true), *tmpl, &image,
+                                    &xlateWhyNot_)) {
+            if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still run the old code
+            if (xlateModule_) (void)hipModuleUnload(xlateModule_);
+            xlateModule_ = nullptr;
+            xlateFn_ = nullptr;
+            hipError_t me = hipModuleLoadData(&xlateModule_, image.elf.data());
+            if (me == hipSuccess) me = hipModuleGetFunction(&xlateFn_, xlateModule_, tmpl->kernelName.c_str());
+            if (me != hipSuccess) return hipFail(me, "loading the translated program");
+            xlateSteadyOff_ = image.steadyOff;
+            xlateLastOff_ = image.lastOff;
+            xlateCodeBytes_ = image.codeBytes;
+            xlateInlined_ = image.steady.inlined;
+            xlateCalled_ = image.steady.called;
+            useXlate_ = true;
+        }
+    }
+    if (useAsm_ && !useXlate_) {
         hipError_t pe = hipSuccess;
         const uint64_t* handlers = asmHandlerTable(asmVariant_, device_, &pe);
         if (!handlers) return hipFail(pe, "probe of the assembly interpreter");
@@ -406,7 +431,14 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             g.cursorRow = stateLayout_.cursorBase; g.noiseRow = stateLayout_.noiseBase;
             g.oodRow = a.oodRow; g.countLo = a.countLo; g.countHi = a.countHi; g.staticCount = a.staticCount;
             g.lutX1Off = kLutX1Off * 8;
-            e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
+            if (useXlate_) {
+                // the two code streams are named by their byte offset from the kernel entry
+                g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteadyOff_);
+                g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLastOff_);
+                e = launchAsmFunction(xlateFn_, g, s);
+            } else {
+                e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
+            }
         } else {
             e = launchStepBlock(a, low_.multipass, s);
         }
@@ -511,7 +543,10 @@ int64_t Batch::info(int what) {
     if (ensureLowered() != 0) return -1;
     switch (what) {
         case FXB_INFO_INST_PER_LANE: return instPerLane_;
-        case FXB_INFO_KERNEL: return useAsm_ ? 1 + (int)asmVariant_ : 0;
+        case FXB_INFO_KERNEL: return useAsm_ ? (useXlate_ ? 8 : 1) + (int)asmVariant_ : 0;
+        case FXB_INFO_XLATE_CODE_BYTES: return useXlate_ ? (int64_t)xlateCodeBytes_ : 0;
+        case FXB_INFO_XLATE_INLINED: return useXlate_ ? xlateInlined_ : 0;
+        case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
         case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? 0 : (int64_t)low_.nRows * 256 * instPerLane_;

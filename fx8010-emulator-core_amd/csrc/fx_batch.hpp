@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "fx_asm.hpp"
+#include "fx_xlate.hpp"
 #include "fx_decode.hpp"
 #include "fx_kernel.hpp"
 #include "fx_model.hpp"
@@ -82,6 +83,13 @@ private:
     bool useAsm_ = false;          // the current lowering runs on the hand-written gfx950 kernel
     AsmVariant asmVariant_ = ASM_LDS;
     std::string asmWhyNot_;
+    // translated program (fx_xlate.hpp): a code object of its own per lowering
+    bool useXlate_ = false;
+    hipModule_t xlateModule_ = nullptr;
+    hipFunction_t xlateFn_ = nullptr;
+    uint32_t xlateSteadyOff_ = 0, xlateLastOff_ = 0, xlateCodeBytes_ = 0;
+    int xlateInlined_ = 0, xlateCalled_ = 0;
+    std::string xlateWhyNot_;
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;
     size_t streamCap_ = 0;

@@ -1,4 +1,5 @@
 // fx_capi.cpp — extern "C" surface declared in include/fx8010_amd.h.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -9,6 +10,7 @@
 #include <vector>
 
 #include "fx_batch.hpp"
+#include "fx_xlate.hpp"
 
 struct fxb_handle {
     fx::Batch batch;
@@ -188,6 +190,49 @@ int64_t fxp_lower_info(fxp_handle* h, int what) {
         case FXB_INFO_NUM_CCR_LIVE: return h->low.nCcrLive;
         default: return -1;
     }
+}
+int64_t fxp_translate(fxp_handle* h, int vgprs, int last_sample, void* code, int64_t cap, char* listing, int64_t listing_cap) {
+    if (!h) return FX_E_ARG;
+    if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
+    if (listing && listing_cap > 0) listing[0] = 0;
+    std::vector<float> values(h->prog.regs.size());
+    for (size_t r = 0; r < values.size(); ++r) values[r] = h->prog.regs[r].value;
+    // the lowering of the VGPR builds: one instance per lane, bookkeeping in VGPRs, rows are plain indices
+    fx::Lowered low = fx::lowerProgram(h->prog, values, std::vector<uint8_t>(values.size(), 0), 1, false, 1);
+    if (!low.error.empty()) { h->err = low.error; return FX_E_PROGRAM; }
+    std::string why;
+    if (!fx::asmEligible(low, &why)) { h->err = "not eligible: " + why; return FX_E_PROGRAM; }
+    int v = fx::ASM_V64;
+    while (v < fx::ASM_V256 && low.nRows > fx::kAsmVgprRows[v]) ++v;
+    if (vgprs != 0) {
+        int want = -1;
+        for (int q = fx::ASM_V64; q < fx::ASM_VARIANTS; ++q)
+            if (fx::kAsmVgprRows[q] + 32 == vgprs) want = q;
+        if (want < v) { h->err = "no such VGPR build, or too small for the program"; return FX_E_ARG; }
+        v = want;
+    }
+    const fx::XlateTemplate* tmpl = fx::xlateTemplate((fx::AsmVariant)v, &h->err);
+    if (!tmpl) return FX_E_PROGRAM;
+    // same stream placement as buildXlateImage: steady at the hole, last on the next cache line after it
+    std::vector<uint32_t> words, steadyWords;
+    std::string text;
+    fx::XlateStats st;
+    const std::vector<fx::MicroOp> steady = fx::encodeAsmStream(low.steady, nullptr, true);
+    if (!fx::translateStream(steady, *tmpl, tmpl->holeOff, &steadyWords, last_sample ? nullptr : &text, &st, &h->err)) return FX_E_PROGRAM;
+    if (last_sample) {
+        const uint32_t base = tmpl->holeOff + (uint32_t)((steadyWords.size() * 4 + 63) & ~(size_t)63);
+        if (!fx::translateStream(fx::encodeAsmStream(low.last, nullptr, true), *tmpl, base, &words, &text, &st, &h->err)) return FX_E_PROGRAM;
+    } else {
+        words.swap(steadyWords);
+    }
+    const int64_t bytes = (int64_t)words.size() * 4;
+    if (code && cap > 0) std::memcpy(code, words.data(), (size_t)std::min<int64_t>(cap, bytes));
+    if (listing && listing_cap > 0) {
+        const size_t n = std::min<size_t>(text.size(), (size_t)listing_cap - 1);
+        std::memcpy(listing, text.data(), n);
+        listing[n] = 0;
+    }
+    return bytes;
 }
 const char* fxp_last_error(fxp_handle* h) { return h ? h->err.c_str() : "null handle"; }
 

@@ -36,6 +36,15 @@
 #define PNAME_PASTE(a) a##_probe
 #define PNAME_PASTE2(a) PNAME_PASTE(a)
 #define PNAME PNAME_PASTE2(KNAME)
+#define HOLE FX_HOLE_PASTE2(KNAME)
+#define OTABLE FX_TAB_PASTE2(KNAME)
+#define FX_TAB_PASTE(a) a##_table
+#define FX_TAB_PASTE2(a) FX_TAB_PASTE(a)
+#define FX_HOLE_PASTE(a) a##_hole
+#define FX_HOLE_PASTE2(a) FX_HOLE_PASTE(a)
+#ifndef HOLE_BYTES
+#define HOLE_BYTES 262144
+#endif
 #ifndef NVGPR
 #define NVGPR 32
 #endif
@@ -130,6 +139,9 @@
 #define M(x) FX_PASTE2(x, SFX)
 // ------------------------------------------------------------------------------------------ entry
 KNAME:
+#ifdef XLATE
+	s_getpc_b64 s[32:33]                                  // KNAME + 4
+#endif
 	s_load_dwordx16 s[4:19], s[0:1], KA_STEADY            // steady last rowtab state in out itram xtram
 	s_load_dwordx8  s[40:47], s[0:1], KA_LUT              // lut n npad nload nstore
 	s_load_dwordx2  s[64:65], s[0:1], KA_NSAMPLES         // nSamples channels
@@ -159,6 +171,17 @@ KNAME:
 	s_mul_i32 s45, s42, s44
 	s_lshl_b32 s45, s45, 2                                // bytes per sample of PCM = channels * N * 4
 	s_mov_b64 s[42:43], s[70:71]                          // last-sample stream
+#ifdef XLATE
+	// translated programs: `steady` / `last` are byte offsets of the two code streams from the kernel entry
+	s_sub_u32 s32, s32, 4
+	s_subb_u32 s33, s33, 0                                // s[32:33] = address of the kernel entry
+	s_add_u32 s6, s6, s32
+	s_addc_u32 s7, s7, s33
+	s_add_u32 s42, s42, s32
+	s_addc_u32 s43, s43, s33
+	s_add_u32 s34, s32, (h_endsample_a-KNAME)
+	s_addc_u32 s35, s33, 0                                // s[34:35] = end-of-sample code (translated streams end with s_setpc_b64 s[34:35])
+#endif
 	s_load_dwordx8  s[48:55], s[0:1], KA_INOFF            // inOff[4] latchOff[4]
 	s_load_dwordx4  s[64:67], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
 	s_load_dwordx2  s[76:77], s[0:1], KA_CURSORROW      // cursorRow noiseRow
@@ -336,17 +359,22 @@ KNAME:
 	s_cselect_b32 s4, s42, s6
 	s_cselect_b32 s5, s43, s7
 	v_mov_b32 v14, 0                                      // numSkip is local to process() (FX8010.cpp:1030)
+#ifdef XLATE
+	s_setpc_b64 s[4:5]                                    // the translated program of this sample
+#else
 	s_load_dwordx16 s[16:31], s[4:5], 0x0                 // records 0, 1
 	s_load_dwordx16 s[80:95], s[4:5], 0x40                // records 2, 3
 	s_mov_b32 s8, 128
 	s_waitcnt lgkmcnt(0)
 	s_setpc_b64 s[16:17]
+#endif
 
 // ------------------------------------------------------------------------------------------ handlers
 // handler offsets (bytes from the kernel entry) of the four register sets, 84 slots each; read only by the
 // probe mode, which turns them into absolute addresses for the host to put into the records
 	.p2align 6
-offset_table:
+	.globl	OTABLE
+OTABLE:
 #define SFX _a
 .macro M(JT2) op, kind
 	.long h_\op\()_\kind\()_0\()SFX - KNAME
@@ -354,6 +382,10 @@ offset_table:
 .endm
 #include "fx_interp_table.inc"
 #undef SFX
+#ifdef XLATE
+	.long HOLE - KNAME                                    // [84] the code hole the host fills (fx_xlate.cpp)
+	.long HOLE_BYTES                                      // [85]
+#else
 #define SFX _b
 .macro M(JT2) op, kind
 	.long h_\op\()_\kind\()_0\()SFX - KNAME
@@ -375,6 +407,8 @@ offset_table:
 .endm
 #include "fx_interp_table.inc"
 #undef SFX
+
+#endif
 
 // records 4n, 4n+1 live in window s[16:31], records 4n+2, 4n+3 in window s[80:95]
 #define SFX _a
@@ -398,6 +432,7 @@ offset_table:
 #undef OWPC
 #undef WINDOW
 #undef NEXT_LOADS
+#ifndef XLATE
 #define SFX _b
 #define RA s26
 #define RX s27
@@ -461,6 +496,8 @@ offset_table:
 #undef OWPC
 #undef WINDOW
 #undef NEXT_LOADS
+
+#endif
 
 // ---- end of the program for this sample: latch rows -> PCM out, next sample
 h_endsample_a:
@@ -590,6 +627,17 @@ h_endsample_d:
 .Lfunc_end0:
 	.size	KNAME, .Lfunc_end0-KNAME
 
+
+#ifdef XLATE
+// ------------------------------------------------------------------------------------------ code hole
+// The host writes the translated program (two streams of plain gfx950 code, fx_xlate.cpp) over this filler in
+// its copy of the code object before loading it.
+	.p2align	8
+	.globl	HOLE
+HOLE:
+	.fill	(HOLE_BYTES / 4), 4, 0xbf800000                 // s_nop 0
+	s_endpgm
+#else
 // ------------------------------------------------------------------------------------------ probe kernel
 // One wavefront: writes the absolute address of every handler of this build (4 sets x 84 slots, 64-bit
 // each) to `out`; the host puts these into the records it encodes (fx_asm.cpp asmHandlerTable). A kernel
@@ -603,7 +651,7 @@ PNAME:
 .Lpc1:
 	s_sub_u32 s62, s62, (.Lpc1-KNAME)                     // address of the interpreter's entry
 	s_subb_u32 s63, s63, 0
-	s_add_u32 s64, s62, (offset_table-KNAME)
+	s_add_u32 s64, s62, (OTABLE-KNAME)
 	s_addc_u32 s65, s63, 0
 	v_mov_b32 v4, v0                                      // slot index handled by this lane
 	s_waitcnt lgkmcnt(0)
@@ -627,6 +675,7 @@ PNAME:
 	s_endpgm
 .Lfunc_end1:
 	.size	PNAME, .Lfunc_end1-PNAME
+#endif
 
 	.rodata
 	.p2align	6, 0x0
@@ -649,6 +698,7 @@ PNAME:
 		.amdhsa_dx10_clamp 1
 		.amdhsa_ieee_mode 1
 	.end_amdhsa_kernel
+#ifndef XLATE
 	.p2align	6, 0x0
 	.amdhsa_kernel PNAME
 		.amdhsa_group_segment_fixed_size 0
@@ -663,6 +713,7 @@ PNAME:
 		.amdhsa_accum_offset 8
 		.amdhsa_reserve_vcc 1
 	.end_amdhsa_kernel
+#endif
 
 	.amdgpu_metadata
 ---
@@ -681,6 +732,7 @@ amdhsa.kernels:
     .symbol: KNAME.kd
     .vgpr_count: NVGPR
     .wavefront_size: 64
+#ifndef XLATE
   - .args:
       - .offset: 0
         .size: 184
@@ -695,6 +747,7 @@ amdhsa.kernels:
     .symbol: PNAME.kd
     .vgpr_count: 8
     .wavefront_size: 64
+#endif
 amdhsa.target: amdgcn-amd-amdhsa--gfx950
 amdhsa.version:
   - 1

@@ -1,0 +1,565 @@
+// fx_xlate.cpp — FX8010 program -> gfx950 machine code (see fx_xlate.hpp).
+#include "fx_xlate.hpp"
+
+#include <elf.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace fx {
+namespace {
+
+// the template code objects (XLATE flavour of fx_interp_gfx950.S, one per VGPR build), embedded by the Makefile
+const unsigned char kBlobV64[] = {
+#include "build/fx_xlate_v64_blob.inc"
+};
+const unsigned char kBlobV72[] = {
+#include "build/fx_xlate_v72_blob.inc"
+};
+const unsigned char kBlobV80[] = {
+#include "build/fx_xlate_v80_blob.inc"
+};
+const unsigned char kBlobV96[] = {
+#include "build/fx_xlate_v96_blob.inc"
+};
+const unsigned char kBlobV128[] = {
+#include "build/fx_xlate_v128_blob.inc"
+};
+const unsigned char kBlobV168[] = {
+#include "build/fx_xlate_v168_blob.inc"
+};
+const unsigned char kBlobV256[] = {
+#include "build/fx_xlate_v256_blob.inc"
+};
+
+struct BlobRef { const unsigned char* p; size_t n; const char* kernel; int vgprs; };
+const BlobRef kBlobs[ASM_VARIANTS] = {
+    {nullptr, 0, "", 0},
+    {kBlobV64, sizeof(kBlobV64), "fx_xlate_v64", 64},
+    {kBlobV72, sizeof(kBlobV72), "fx_xlate_v72", 72},
+    {kBlobV80, sizeof(kBlobV80), "fx_xlate_v80", 80},
+    {kBlobV96, sizeof(kBlobV96), "fx_xlate_v96", 96},
+    {kBlobV128, sizeof(kBlobV128), "fx_xlate_v128", 128},
+    {kBlobV168, sizeof(kBlobV168), "fx_xlate_v168", 168},
+    {kBlobV256, sizeof(kBlobV256), "fx_xlate_v256", 256},
+};
+
+// ---- ELF: value and file offset of a named symbol ------------------------------------------------------
+struct SymbolAt { uint64_t value = 0; size_t fileOff = 0; bool found = false; };
+
+SymbolAt findSymbol(const unsigned char* img, size_t n, const std::string& name) {
+    SymbolAt r;
+    if (n < sizeof(Elf64_Ehdr)) return r;
+    Elf64_Ehdr eh;
+    std::memcpy(&eh, img, sizeof(eh));
+    if (std::memcmp(eh.e_ident, ELFMAG, SELFMAG) != 0 || eh.e_ident[EI_CLASS] != ELFCLASS64) return r;
+    if (eh.e_shoff == 0 || eh.e_shentsize != sizeof(Elf64_Shdr) || eh.e_shoff + (uint64_t)eh.e_shnum * sizeof(Elf64_Shdr) > n) return r;
+    std::vector<Elf64_Shdr> sh(eh.e_shnum);
+    std::memcpy(sh.data(), img + eh.e_shoff, sh.size() * sizeof(Elf64_Shdr));
+    for (const Elf64_Shdr& s : sh) {
+        if (s.sh_type != SHT_SYMTAB && s.sh_type != SHT_DYNSYM) continue;
+        if (s.sh_link >= sh.size() || s.sh_entsize != sizeof(Elf64_Sym) || s.sh_offset + s.sh_size > n) continue;
+        const Elf64_Shdr& str = sh[s.sh_link];
+        if (str.sh_offset + str.sh_size > n) continue;
+        const size_t count = s.sh_size / sizeof(Elf64_Sym);
+        for (size_t i = 0; i < count; ++i) {
+            Elf64_Sym sym;
+            std::memcpy(&sym, img + s.sh_offset + i * sizeof(Elf64_Sym), sizeof(sym));
+            if (sym.st_name >= str.sh_size) continue;
+            const char* nm = reinterpret_cast<const char*>(img + str.sh_offset + sym.st_name);
+            const size_t maxLen = str.sh_size - sym.st_name;
+            if (strnlen(nm, maxLen) == maxLen || name != nm) continue;
+            if (sym.st_shndx == SHN_UNDEF || sym.st_shndx >= sh.size()) continue;
+            const Elf64_Shdr& sec = sh[sym.st_shndx];
+            if (sym.st_value < sec.sh_addr || sym.st_value > sec.sh_addr + sec.sh_size) continue;
+            r.value = sym.st_value;
+            r.fileOff = (size_t)(sec.sh_offset + (sym.st_value - sec.sh_addr));
+            r.found = true;
+            return r;
+        }
+    }
+    return r;
+}
+
+std::mutex g_mu;
+XlateTemplate g_templates[ASM_VARIANTS];
+bool g_parsed[ASM_VARIANTS] = {};
+std::string g_parseErr[ASM_VARIANTS];
+
+// ---- operands --------------------------------------------------------------------------------------------
+struct Src {
+    uint32_t code = 0;  // 9-bit source operand
+    uint32_t lit = 0;
+    bool hasLit = false;
+    std::string text;
+};
+
+Src vreg(int n) {
+    Src s;
+    s.code = 256u + (uint32_t)n;
+    s.text = "v" + std::to_string(n);
+    return s;
+}
+Src vreg64(int n) {
+    Src s;
+    s.code = 256u + (uint32_t)n;
+    s.text = "v[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
+    return s;
+}
+Src sreg(int n) {
+    Src s;
+    s.code = (uint32_t)n;
+    s.text = "s" + std::to_string(n);
+    return s;
+}
+Src sreg64(int n) {
+    Src s;
+    s.code = (uint32_t)n;
+    s.text = "s[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
+    return s;
+}
+Src named(uint32_t code, const char* text) {
+    Src s;
+    s.code = code;
+    s.text = text;
+    return s;
+}
+
+struct InlineF { uint32_t bits; uint32_t code; const char* text; };
+const InlineF kInlineF32[] = {
+    {0x3f000000u, 240, "0.5"}, {0xbf000000u, 241, "-0.5"}, {0x3f800000u, 242, "1.0"},  {0xbf800000u, 243, "-1.0"},      {0x40000000u, 244, "2.0"},
+    {0xc0000000u, 245, "-2.0"}, {0x40800000u, 246, "4.0"},  {0xc0800000u, 247, "-4.0"}, {0x3e22f983u, 248, "0.15915494"},
+};
+struct InlineD { uint64_t bits; uint32_t code; const char* text; };
+const InlineD kInlineF64[] = {
+    {0x0000000000000000ull, 128, "0"},   {0x3fe0000000000000ull, 240, "0.5"}, {0xbfe0000000000000ull, 241, "-0.5"},
+    {0x3ff0000000000000ull, 242, "1.0"}, {0xbff0000000000000ull, 243, "-1.0"}, {0x4000000000000000ull, 244, "2.0"},
+    {0xc000000000000000ull, 245, "-2.0"}, {0x4010000000000000ull, 246, "4.0"},  {0xc010000000000000ull, 247, "-4.0"},
+};
+
+// a 32-bit value as a source operand: inline constant when the bit pattern has one, else a literal
+Src imm32(uint32_t bits, bool forceLiteral = false) {
+    Src s;
+    const int32_t iv = (int32_t)bits;
+    if (!forceLiteral) {
+        if (iv >= 0 && iv <= 64) { s.code = 128u + (uint32_t)iv; s.text = std::to_string(iv); return s; }
+        if (iv >= -16 && iv <= -1) { s.code = 192u + (uint32_t)(-iv); s.text = std::to_string(iv); return s; }
+        for (const InlineF& k : kInlineF32)
+            if (k.bits == bits) { s.code = k.code; s.text = k.text; return s; }
+    }
+    char buf[16];
+    std::snprintf(buf, sizeof(buf), "0x%x", bits);
+    s.code = 255;
+    s.lit = bits;
+    s.hasLit = true;
+    s.text = buf;
+    return s;
+}
+
+// ---- instruction emitter -----------------------------------------------------------------------------------
+class Emitter {
+  public:
+    Emitter(std::vector<uint32_t>* words, std::string* listing) : w_(*words), text_(listing) {}
+
+    size_t bytes() const { return w_.size() * 4; }
+    int count() const { return count_; }
+
+    void vop2(uint32_t op, const char* name, int vdst, const Src& src0, int vsrc1, const char* tail = "") {
+        put((op << 25) | ((uint32_t)vdst << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
+        line(std::string(name) + " v" + std::to_string(vdst) + ", " + src0.text + ", v" + std::to_string(vsrc1) + tail);
+    }
+    void vop1(uint32_t op, const char* name, const Src& vdst, const Src& src0) {
+        put(0x7e000000u | ((vdst.code & 0xffu) << 17) | (op << 9) | src0.code, src0);
+        line(std::string(name) + " " + vdst.text + ", " + src0.text);
+    }
+    void vopc(uint32_t op, const char* name, const Src& src0, int vsrc1) {
+        put(0x7c000000u | (op << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
+        line(std::string(name) + " vcc, " + src0.text + ", v" + std::to_string(vsrc1));
+    }
+    // VOP3A: no literals on gfx9; neg = per-source negate bits
+    void vop3(uint32_t op, const char* name, const Src& vdst, const Src& s0, const Src& s1, const Src* s2, uint32_t neg = 0) {
+        w_.push_back(0xd0000000u | (op << 16) | (vdst.code & 0xffu));
+        w_.push_back(s0.code | (s1.code << 9) | ((s2 ? s2->code : 0u) << 18) | (neg << 29));
+        ++count_;
+        std::string t = std::string(name) + " " + vdst.text + ", " + ((neg & 1) ? "-" : "") + s0.text + ", " + ((neg & 2) ? "-" : "") + s1.text;
+        if (s2) t += std::string(", ") + ((neg & 4) ? "-" : "") + s2->text;
+        line(t);
+    }
+    void sop1(uint32_t op, const char* name, const Src& sdst, const Src& ssrc) {
+        put(0xbe800000u | ((sdst.code & 0x7fu) << 16) | (op << 8) | ssrc.code, ssrc);
+        line(std::string(name) + " " + sdst.text + ", " + ssrc.text);
+    }
+    void sop1NoDst(uint32_t op, const char* name, const Src& ssrc) {
+        put(0xbe800000u | (op << 8) | ssrc.code, ssrc);
+        line(std::string(name) + " " + ssrc.text);
+    }
+    void sop2(uint32_t op, const char* name, const Src& sdst, const Src& s0, const Src& s1) {
+        // at most one literal, which then follows the instruction word
+        const Src& l = s1.hasLit ? s1 : s0;
+        put(0x80000000u | (op << 23) | ((sdst.code & 0x7fu) << 16) | (s1.code << 8) | s0.code, l);
+        line(std::string(name) + " " + sdst.text + ", " + s0.text + ", " + s1.text);
+    }
+    void sopp(uint32_t op, const char* name, uint32_t simm, bool showImm) {
+        w_.push_back(0xbf800000u | (op << 16) | (simm & 0xffffu));
+        ++count_;
+        line(showImm ? std::string(name) + " " + std::to_string(simm) : std::string(name));
+    }
+
+  private:
+    void put(uint32_t word, const Src& maybeLit) {
+        w_.push_back(word);
+        if (maybeLit.hasLit) w_.push_back(maybeLit.lit);
+        ++count_;
+    }
+    void line(const std::string& t) {
+        if (text_) { *text_ += t; *text_ += '\n'; }
+    }
+    std::vector<uint32_t>& w_;
+    std::string* text_;
+    int count_ = 0;
+};
+
+// gfx950 opcodes used (checked against llvm-mc by tests/test_xlate.py, which re-assembles the listing)
+enum : uint32_t {
+    VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
+    VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
+    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
+    VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
+    SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
+    SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
+    SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
+};
+
+// register conventions shared with fx_interp_gfx950.S
+constexpr int kRegFileBase = 32;  // v32 = row 0
+constexpr int kVNumSkip = 14, kVShadowCount = 15;
+constexpr int kSRecord = 16;      // s16.. = record window of handler set _a: s18..s23 = w2..w7
+constexpr int kSReturn = 24;      // s[24:25] = where a handler of set _a continues
+constexpr int kSEntry = 32;       // s[32:33] = address of the kernel entry
+constexpr int kSEndSample = 34;   // s[34:35] = end-of-sample frame
+constexpr int kSTemp = 62;        // s[62:63] scratch of the handlers, free between them
+
+class Translator {
+  public:
+    Translator(const XlateTemplate& t, uint32_t codeBase, std::vector<uint32_t>* code, std::string* listing)
+        : tmpl_(t), base_(codeBase), e_(code, listing) {}
+
+    bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::string* err) {
+        bool ended = false;
+        for (const MicroOp& r : records) {
+            const uint32_t slot = r.w[0];
+            if (slot == AS_ENDSAMPLE) { ended = true; break; }
+            if (!one(r, slot)) { if (err) *err = err_; return false; }
+        }
+        if (!ended) { if (err) *err = "record stream without ENDSAMPLE"; return false; }
+        // the end-of-sample frame sets up its own index mode; EXEC is reset there as well
+        e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSEndSample));
+        if (stats) { *stats = stats_; stats->instructions = e_.count(); }
+        return true;
+    }
+
+  private:
+    bool fail(const std::string& m) { err_ = m; return false; }
+
+    bool row(uint32_t r, int* v) {
+        if (r >= (uint32_t)(tmpl_.vgprs - kRegFileBase)) return fail("register-file row beyond the VGPR budget of the build");
+        *v = kRegFileBase + (int)r;
+        return true;
+    }
+    // operand word -> source: a register-file row (VGPR) or the uniform's bit pattern
+    bool operand(uint32_t word, bool uniform, Src* s) {
+        if (uniform) { *s = imm32(word); return true; }
+        int v;
+        if (!row(word, &v)) return false;
+        *s = vreg(v);
+        return true;
+    }
+
+    // plain VALU code follows: leave the VGPR index mode a handler may have left on
+    void plainMode() {
+        if (!indexModeUnknown_) return;
+        e_.sopp(SOPP_IDX_OFF, "s_set_gpr_idx_off", 0, false);
+        e_.sopp(SOPP_NOP, "s_nop", 3, true);
+        indexModeUnknown_ = false;
+    }
+
+    // v2 -> saturate (NaN passes, FX8010.cpp:275-279) -> row R
+    void satStore(int vR) {
+        e_.vopc(VOPC_CMP_U_F32, "v_cmp_u_f32_e32", vreg(2), 2);
+        Src m1 = imm32(0xbf800000u), p1 = imm32(0x3f800000u);
+        e_.vop3(VOP3_MED3_F32, "v_med3_f32", vreg(5), vreg(2), m1, &p1);
+        e_.sopp(SOPP_NOP, "s_nop", 0, true);  // 2 wait states between the VALU write of VCC and its VALU read
+        e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", vR, vreg(5), 2, ", vcc");
+    }
+
+    // p = X * Y into v3 unless both are uniform (then the record's X word holds the folded product)
+    bool product(const MicroOp& r, uint32_t kind, bool* inV3) {
+        const bool uX = kind & 2, uY = kind & 4;
+        *inV3 = !(uX && uY);
+        if (uX && uY) return true;
+        Src a;
+        int b;
+        if (!uX && !uY) {
+            if (!operand(r.w[3], false, &a) || !row(r.w[4], &b)) return false;
+        } else if (uX) {
+            a = imm32(r.w[3]);
+            if (!row(r.w[4], &b)) return false;
+        } else {
+            a = imm32(r.w[4]);
+            if (!row(r.w[3], &b)) return false;
+        }
+        e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 3, a, b);
+        return true;
+    }
+
+    bool macs(const MicroOp& r, uint32_t kind, bool neg) {
+        int vR;
+        if (!row(r.w[5], &vR)) return false;
+        plainMode();
+        if (kind == 7) {  // folded on the host: the A word is the saturated result
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(r.w[2]));
+            return true;
+        }
+        bool inV3;
+        if (!product(r, kind, &inV3)) return false;
+        if (inV3) {
+            Src a;
+            if (!operand(r.w[2], kind & 1, &a)) return false;
+            e_.vop2(neg ? VOP2_SUB_F32 : VOP2_ADD_F32, neg ? "v_sub_f32_e32" : "v_add_f32_e32", 2, a, 3);
+        } else {
+            int vA;
+            if (!row(r.w[2], &vA)) return false;
+            e_.vop2(neg ? VOP2_SUBREV_F32 : VOP2_ADD_F32, neg ? "v_subrev_f32_e32" : "v_add_f32_e32", 2, imm32(r.w[3]), vA);
+        }
+        satStore(vR);
+        return true;
+    }
+
+    bool acc3(const MicroOp& r, uint32_t kind) {
+        int vR;
+        if (!row(r.w[5], &vR)) return false;
+        plainMode();
+        if (kind == 7) {
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(r.w[2]));
+            return true;
+        }
+        const bool uA = kind & 1, uX = kind & 2, uY = kind & 4;
+        if (uA && uX) {  // t = A + X folded into the A word
+            int vY;
+            if (!row(r.w[4], &vY)) return false;
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, imm32(r.w[2]), vY);
+        } else {
+            Src a;
+            int b;
+            if (uA) {
+                a = imm32(r.w[2]);
+                if (!row(r.w[3], &b)) return false;
+            } else if (uX) {
+                a = imm32(r.w[3]);
+                if (!row(r.w[2], &b)) return false;
+            } else {
+                if (!operand(r.w[2], false, &a) || !row(r.w[3], &b)) return false;
+            }
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, a, b);
+            Src y;
+            if (!operand(r.w[4], uY, &y)) return false;
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, y, 2);
+        }
+        satStore(vR);
+        return true;
+    }
+
+    // INTERP (FX8010.cpp:1180-1187): R = sat((float)((1.0 - (double)X) * (double)A + (double)(X*Y)))
+    bool interp(const MicroOp& r, uint32_t kind) {
+        int vR;
+        if (!row(r.w[5], &vR)) return false;
+        plainMode();
+        if (kind == 7) {
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(r.w[2]));
+            return true;
+        }
+        bool inV3;
+        if (!product(r, kind, &inV3)) return false;
+        Src a;
+        if (!operand(r.w[2], kind & 1, &a)) return false;
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), a);
+        if (kind & 2) {  // uniform X: the record carries (1.0 - (double)X)
+            const uint64_t omx = (uint64_t)r.w[6] | ((uint64_t)r.w[7] << 32);
+            const InlineD* inl = nullptr;
+            for (const InlineD& k : kInlineF64)
+                if (k.bits == omx) inl = &k;
+            if (inl) {
+                e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), named(inl->code, inl->text), vreg64(8), nullptr);
+            } else {
+                setRecordWord(6, r.w[6]);
+                setRecordWord(7, r.w[7]);
+                e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), sreg64(kSRecord + 6), vreg64(8), nullptr);
+            }
+        } else {
+            Src x;
+            if (!operand(r.w[3], false, &x)) return false;
+            e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(6), x);
+            e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), named(242, "1.0"), vreg64(6), nullptr, 2);
+            e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
+        }
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), inV3 ? vreg(3) : imm32(r.w[3]));
+        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
+        e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(2), vreg64(6));
+        satStore(vR);
+        return true;
+    }
+
+    // s(16+k) = word k of the record, unless it holds that value already
+    void setRecordWord(int k, uint32_t value) {
+        if (known_[k] && value_[k] == value) return;
+        e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSRecord + k), imm32(value));
+        known_[k] = true;
+        value_[k] = value;
+    }
+
+    // run the interpreter's handler for this record: operands in s18..s23, return address in s[24:25]
+    bool call(const MicroOp& r, uint32_t slot, uint32_t wordMask) {
+        if (slot >= (uint32_t)kAsmSlots) return fail("record with an unknown handler slot");
+        for (int k = 2; k < 8; ++k)
+            if (wordMask & (1u << k)) setRecordWord(k, r.w[k]);
+        const uint32_t at = base_ + (uint32_t)e_.bytes();
+        const uint32_t ret = at + 28;  // 8 + 4 + 8 + 4 + 4 bytes below
+        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSReturn), sreg(kSEntry), imm32(ret, true));
+        e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSReturn + 1), sreg(kSEntry + 1), imm32(0));
+        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSEntry), imm32(tmpl_.handlerOff[slot], true));
+        e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSTemp + 1), sreg(kSEntry + 1), imm32(0));
+        e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSTemp));
+        if (base_ + (uint32_t)e_.bytes() != ret) return fail("internal: call sequence length");
+        indexModeUnknown_ = true;
+        ++stats_.called;
+        return true;
+    }
+
+    bool one(const MicroOp& r, uint32_t slot) {
+        const uint32_t ccrLive = (r.w[6] >> 3) & 1u;
+        if (slot == AS_NOP) return true;  // END / NOP only count (staticCount)
+        if (slot == AS_UNPRED) {
+            e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+            ++stats_.inlined;
+            return true;
+        }
+        if (slot == AS_PRED) {
+            // instruction inside a SKIP shadow (FX8010.cpp:1037,1235-1241): lanes with numSkip == 0 execute it,
+            // the others count their skip down; v15 counts the executed ones
+            plainMode();
+            e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+            e_.vopc(VOPC_CMP_EQ_U32, "v_cmp_eq_u32_e32", imm32(0), kVNumSkip);
+            e_.vop2(VOP2_MAX_I32, "v_max_i32_e32", 5, imm32(1), kVNumSkip);
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVNumSkip, imm32(0xffffffffu), 5);
+            Src one1 = imm32(1), vcc = named(106, "vcc");
+            e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(5), imm32(0), one1, &vcc);
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVShadowCount, vreg(kVShadowCount), 5);
+            e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(106, "vcc"));
+            ++stats_.inlined;
+            return true;
+        }
+        if (slot >= AS_MACS && slot < (uint32_t)kAsmSlots) {
+            const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2, ccr = rel & 1u;
+            if (!ccr) {
+                ++stats_.inlined;
+                switch (family) {
+                    case 0: return macs(r, kind, false);
+                    case 1: return macs(r, kind, true);
+                    case 2: return acc3(r, kind);
+                    default: return interp(r, kind);
+                }
+            }
+            // a live CCR: the interpreter's handler derives it (w6:w7 matter to INTERP only)
+            return call(r, slot, family == 3 ? 0xfcu : 0x3cu);
+        }
+        if (slot == AS_MOV && !ccrLive) {
+            int vR;
+            Src a;
+            if (!row(r.w[5], &vR) || !operand(r.w[2], r.w[6] & 1u, &a)) return false;
+            plainMode();
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), a);
+            ++stats_.inlined;
+            return true;
+        }
+        return call(r, slot, 0x7cu);  // generic handlers read w2..w6
+    }
+
+    const XlateTemplate& tmpl_;
+    uint32_t base_;
+    Emitter e_;
+    XlateStats stats_;
+    std::string err_;
+    bool indexModeUnknown_ = false;  // the per-sample frame enters the stream with index mode off
+    bool known_[8] = {};
+    uint32_t value_[8] = {};
+};
+
+}  // namespace
+
+const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
+    if (variant <= ASM_LDS || variant >= ASM_VARIANTS) {
+        if (err) *err = "no translation template for this build";
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_parsed[variant]) {
+        g_parsed[variant] = true;
+        const BlobRef& b = kBlobs[variant];
+        XlateTemplate t;
+        t.image = b.p;
+        t.imageBytes = b.n;
+        t.kernelName = b.kernel;
+        t.vgprs = b.vgprs;
+        const SymbolAt k = findSymbol(b.p, b.n, t.kernelName);
+        const SymbolAt tab = findSymbol(b.p, b.n, t.kernelName + "_table");
+        const SymbolAt hole = findSymbol(b.p, b.n, t.kernelName + "_hole");
+        if (!k.found || !tab.found || !hole.found || tab.fileOff + (kAsmSlots + 2) * 4 > b.n) {
+            g_parseErr[variant] = "translation template " + t.kernelName + ": symbols not found in the code object";
+        } else {
+            uint32_t table[kAsmSlots + 2];
+            std::memcpy(table, b.p + tab.fileOff, sizeof(table));
+            std::memcpy(t.handlerOff, table, sizeof(t.handlerOff));
+            t.holeOff = table[kAsmSlots];
+            t.holeBytes = table[kAsmSlots + 1];
+            t.holeFileOff = hole.fileOff;
+            if ((uint64_t)t.holeOff != hole.value - k.value || t.holeFileOff + t.holeBytes > b.n || (t.holeBytes & 3u))
+                g_parseErr[variant] = "translation template " + t.kernelName + ": inconsistent hole";
+            else
+                g_templates[variant] = t;
+        }
+    }
+    if (!g_parseErr[variant].empty()) {
+        if (err) *err = g_parseErr[variant];
+        return nullptr;
+    }
+    return &g_templates[variant];
+}
+
+bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, uint32_t codeBase,
+                     std::vector<uint32_t>* code, std::string* listing, XlateStats* stats, std::string* err) {
+    code->clear();
+    Translator t(tmpl, codeBase, code, listing);
+    return t.run(records, stats, err);
+}
+
+bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
+                     const XlateTemplate& tmpl, XlateImage* out, std::string* err) {
+    std::vector<uint32_t> steady, last;
+    out->steadyOff = tmpl.holeOff;
+    if (!translateStream(steadyRecords, tmpl, out->steadyOff, &steady, nullptr, &out->steady, err)) return false;
+    const uint32_t steadyBytes = (uint32_t)((steady.size() * 4 + 63) & ~(size_t)63);  // streams start on a cache line
+    out->lastOff = tmpl.holeOff + steadyBytes;
+    if (!translateStream(lastRecords, tmpl, out->lastOff, &last, nullptr, &out->last, err)) return false;
+    out->codeBytes = steadyBytes + (uint32_t)(last.size() * 4);
+    if (out->codeBytes + 4 > tmpl.holeBytes) {
+        if (err) *err = "translated program larger than the code hole of the template";
+        return false;
+    }
+    out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
+    std::memcpy(out->elf.data() + tmpl.holeFileOff, steady.data(), steady.size() * 4);
+    std::memcpy(out->elf.data() + tmpl.holeFileOff + steadyBytes, last.data(), last.size() * 4);
+    return true;
+}
+
+}  // namespace fx

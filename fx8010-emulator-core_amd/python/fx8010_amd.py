@@ -20,6 +20,7 @@ INFO = {
     "num_instructions": 0, "num_registers": 1, "num_lane_regs": 2, "num_uniform_regs": 3, "lds_bytes_per_wg": 4,
     "waves_per_wg": 5, "num_microops": 6, "itram_slots": 7, "xtram_slots": 8, "tram_ops": 9, "multipass": 10,
     "num_shadowed": 11, "num_ccr_live": 12, "device": 13, "grid": 14, "inst_per_lane": 15, "kernel": 16, "num_rows": 17,
+    "xlate_code_bytes": 18, "xlate_inlined": 19, "xlate_called": 20,
 }
 
 # every symbol include/fx8010_amd.h declares (tests check that the library exports them all)
@@ -35,7 +36,7 @@ SYMBOLS = [
     "fxp_create", "fxp_destroy", "fxp_load_file", "fxp_load_text", "fxp_num_registers", "fxp_register_name",
     "fxp_register_type", "fxp_register_ioindex", "fxp_register_value", "fxp_num_instructions", "fxp_instruction",
     "fxp_itram_size", "fxp_xtram_size", "fxp_error_count", "fxp_error_desc", "fxp_error_row", "fxp_control_count",
-    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_last_error",
+    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_translate", "fxp_last_error",
 ]
 
 
@@ -83,6 +84,7 @@ def load():
     sig("fxp_itram_size", i32, vp); sig("fxp_xtram_size", i32, vp); sig("fxp_ready", i32, vp)
     sig("fxp_lut", C.POINTER(C.c_double), i32, i32); sig("fxp_lower", i32, vp); sig("fxp_lower_info", i64, vp, i32)
     sig("fxp_last_error", cp, vp)
+    sig("fxp_translate", i64, vp, i32, i32, vp, i64, C.c_char_p, i64)
     _lib = lib
     return lib
 
@@ -159,6 +161,16 @@ class FrontEnd(_Reports):
 
     def lower_info(self, what):
         return int(self._lib.fxp_lower_info(self._h, INFO[what]))
+
+    def translate(self, vgprs=0, last_sample=False):
+        """gfx950 machine code of the program as the batch path generates it: (code bytes, assembler listing)."""
+        cap, tcap = 1 << 20, 1 << 23
+        code = C.create_string_buffer(cap)
+        text = C.create_string_buffer(tcap)
+        n = int(self._lib.fxp_translate(self._h, int(vgprs), int(bool(last_sample)), code, cap, text, tcap))
+        if n < 0:
+            raise RuntimeError("fxp_translate: %d %s" % (n, self.last_error()))
+        return code.raw[:n], text.value.decode("ascii")
 
     def last_error(self):
         return self._lib.fxp_last_error(self._h).decode("latin-1")

@@ -145,9 +145,13 @@ enum {
     FXB_INFO_DEVICE = 13,
     FXB_INFO_GRID = 14,            /* workgroups of the last launch                       */
     FXB_INFO_INST_PER_LANE = 15,   /* instances one lane steps (kernel variant)           */
-    FXB_INFO_KERNEL = 16,          /* 0 = HIP C++ kernel; hand-written gfx950 assembly: 1 = register file in LDS,
-                                      2..8 = register file in VGPRs (64/72/80/96/128/168/256-VGPR build) */
-    FXB_INFO_NUM_ROWS = 17         /* rows of the per-instance register file               */
+    FXB_INFO_KERNEL = 16,          /* 0 = HIP C++ kernel; hand-written gfx950 interpreter: 1 = register file in LDS,
+                                      2..8 = register file in VGPRs (64/72/80/96/128/168/256-VGPR build);
+                                      9..15 = program translated to gfx950 code, same seven VGPR builds */
+    FXB_INFO_NUM_ROWS = 17,        /* rows of the per-instance register file               */
+    FXB_INFO_XLATE_CODE_BYTES = 18,/* translated program: bytes of machine code (both streams), else 0 */
+    FXB_INFO_XLATE_INLINED = 19,   /* records of the steady stream turned into straight-line code */
+    FXB_INFO_XLATE_CALLED = 20     /* records of the steady stream that call an interpreter handler */
 };
 int64_t fxb_info(fxb_handle* h, int what);
 
@@ -183,6 +187,12 @@ const double* fxp_lut(int kind, int exponent);
  * takes the FXB_INFO_* selectors that describe the lowering. */
 int fxp_lower(fxp_handle* h);
 int64_t fxp_lower_info(fxp_handle* h, int what);
+/* Translate the loaded program to gfx950 machine code as the batch path would (no device needed): the
+ * steady stream (last_sample = 0) or the last-sample stream of the VGPR build with `vgprs` registers
+ * (64/72/80/96/128/168/256; 0 = the smallest build that holds the program).  Returns the code size in bytes
+ * (negative FX_E_* when the program cannot be translated, see fxp_last_error) and copies at most `cap` bytes of
+ * code and at most listing_cap-1 characters of the assembler listing (one instruction per line). */
+int64_t fxp_translate(fxp_handle* h, int vgprs, int last_sample, void* code, int64_t cap, char* listing, int64_t listing_cap);
 const char* fxp_last_error(fxp_handle* h);
 
 /* library / device probe: number of HIP devices visible (0 if none), never throws */

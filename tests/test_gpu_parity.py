@@ -13,14 +13,16 @@ from pyoracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["asm", "asm_v256", "asm_lds", 1, 2, 4], ids=["asm", "asm_v256", "asm_lds", "k1", "k2", "k4"])
+@pytest.fixture(params=["default", "xlate_v256", "asm", "asm_v256", "asm_lds", 1, 2, 4],
+                ids=["xlate", "xlate_v256", "asm", "asm_v256", "asm_lds", "k1", "k2", "k4"])
 def k(request, monkeypatch):
-    """kernel variant: the hand-written gfx950 interpreter — default choice (register file in the
-    smallest VGPR build that fits), forced 256-VGPR build, forced LDS build — or the HIP C++ kernel
-    with 1/2/4 instances per lane (FX_INST_PER_LANE pins it)"""
+    """kernel variant: the default choice (program translated to gfx950 code in the smallest VGPR build that
+    fits), the translation forced into the 256-VGPR build, the hand-written interpreter (smallest VGPR build,
+    forced 256-VGPR build, forced LDS build), or the HIP C++ kernel with 1/2/4 instances per lane
+    (FX_INST_PER_LANE pins it)"""
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
-    if request.param == "asm":
+    if request.param == "default":
         pass
     elif isinstance(request.param, str):
         monkeypatch.setenv("FX_KERNEL", request.param)
@@ -84,7 +86,7 @@ def test_config_programs_bit_exact(gpu, name, k):
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
     b, _ = check_batch(gpu, text, x, regs=regs)
     if isinstance(k, str):
-        want = {"asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
+        want = {"default": tuple(range(9, 16)), "xlate_v256": (15,), "asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
         assert b.info("kernel") in want and b.info("inst_per_lane") == 1
     else:
         assert b.info("kernel") == 0 and b.info("inst_per_lane") == k
@@ -151,7 +153,7 @@ def test_opcode_programs(gpu, name, k):
 
 
 @pytest.mark.parametrize("op,table", [("log", 1), ("log", 3), ("log", 16), ("log", 31), ("exp", 0), ("exp", 2), ("exp", 7), ("exp", 31)])
-@pytest.mark.parametrize("kern", ["asm", "asm_lds", "hip"])
+@pytest.mark.parametrize("kern", ["xlate", "asm", "asm_lds", "hip"])
 def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
     """LOG/EXP on the device use precomputed thresholds/slopes instead of the reference's two fp64
     divisions: sweep random x, every table knot and its float neighbours, the domain edges."""
