@@ -272,8 +272,8 @@ int Batch::ensureLowered() {
             hipError_t me = hipModuleLoadData(&xlateModule_, image.elf.data());
             if (me == hipSuccess) me = hipModuleGetFunction(&xlateFn_, xlateModule_, tmpl->kernelName.c_str());
             if (me != hipSuccess) return hipFail(me, "loading the translated program");
-            xlateSteadyOff_ = image.steadyOff;
-            xlateLastOff_ = image.lastOff;
+            xlateSteady_ = (uint64_t)image.steadyFastOff | ((uint64_t)image.steadyOff << 32);
+            xlateLast_ = (uint64_t)image.lastFastOff | ((uint64_t)image.lastOff << 32);
             xlateCodeBytes_ = image.codeBytes;
             xlateInlined_ = image.steady.inlined;
             xlateCalled_ = image.steady.called;
@@ -432,9 +432,9 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             g.oodRow = a.oodRow; g.countLo = a.countLo; g.countHi = a.countHi; g.staticCount = a.staticCount;
             g.lutX1Off = kLutX1Off * 8;
             if (useXlate_) {
-                // the two code streams are named by their byte offset from the kernel entry
-                g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteadyOff_);
-                g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLastOff_);
+                // code streams are named by their byte offset from the kernel entry: {fast, exact} per argument
+                g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteady_);
+                g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLast_);
                 e = launchAsmFunction(xlateFn_, g, s);
             } else {
                 e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);

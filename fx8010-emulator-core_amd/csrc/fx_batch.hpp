@@ -87,7 +87,8 @@ private:
     bool useXlate_ = false;
     hipModule_t xlateModule_ = nullptr;
     hipFunction_t xlateFn_ = nullptr;
-    uint32_t xlateSteadyOff_ = 0, xlateLastOff_ = 0, xlateCodeBytes_ = 0;
+    uint64_t xlateSteady_ = 0, xlateLast_ = 0;  // {fast, exact} stream offsets as the kernel takes them
+    uint32_t xlateCodeBytes_ = 0;
     int xlateInlined_ = 0, xlateCalled_ = 0;
     std::string xlateWhyNot_;
     double* dLut_ = nullptr;

@@ -191,7 +191,7 @@ int64_t fxp_lower_info(fxp_handle* h, int what) {
         default: return -1;
     }
 }
-int64_t fxp_translate(fxp_handle* h, int vgprs, int last_sample, void* code, int64_t cap, char* listing, int64_t listing_cap) {
+int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap) {
     if (!h) return FX_E_ARG;
     if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
     if (listing && listing_cap > 0) listing[0] = 0;
@@ -213,18 +213,14 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int last_sample, void* code, int
     }
     const fx::XlateTemplate* tmpl = fx::xlateTemplate((fx::AsmVariant)v, &h->err);
     if (!tmpl) return FX_E_PROGRAM;
-    // same stream placement as buildXlateImage: steady at the hole, last on the next cache line after it
-    std::vector<uint32_t> words, steadyWords;
-    std::string text;
-    fx::XlateStats st;
-    const std::vector<fx::MicroOp> steady = fx::encodeAsmStream(low.steady, nullptr, true);
-    if (!fx::translateStream(steady, *tmpl, tmpl->holeOff, &steadyWords, last_sample ? nullptr : &text, &st, &h->err)) return FX_E_PROGRAM;
-    if (last_sample) {
-        const uint32_t base = tmpl->holeOff + (uint32_t)((steadyWords.size() * 4 + 63) & ~(size_t)63);
-        if (!fx::translateStream(fx::encodeAsmStream(low.last, nullptr, true), *tmpl, base, &words, &text, &st, &h->err)) return FX_E_PROGRAM;
-    } else {
-        words.swap(steadyWords);
-    }
+    if (stream < 0 || stream > 3) { h->err = "stream: 0 steady fast, 1 steady exact, 2 last fast, 3 last exact"; return FX_E_ARG; }
+    std::vector<uint32_t> code4[4];
+    std::string text4[4];
+    fx::XlateImage plan;
+    if (!fx::planXlate(fx::encodeAsmStream(low.steady, nullptr, true), fx::encodeAsmStream(low.last, nullptr, true), *tmpl, &plan, code4, text4, &h->err))
+        return FX_E_PROGRAM;
+    const std::vector<uint32_t>& words = code4[stream];
+    const std::string& text = text4[stream];
     const int64_t bytes = (int64_t)words.size() * 4;
     if (code && cap > 0) std::memcpy(code, words.data(), (size_t)std::min<int64_t>(cap, bytes));
     if (listing && listing_cap > 0) {

@@ -173,12 +173,16 @@ KNAME:
 	s_mov_b64 s[42:43], s[70:71]                          // last-sample stream
 #ifdef XLATE
 	// translated programs: `steady` / `last` are byte offsets of the two code streams from the kernel entry
+	// (each as two dwords: {fast stream, exact stream}, see "taint" below)
 	s_sub_u32 s32, s32, 4
 	s_subb_u32 s33, s33, 0                                // s[32:33] = address of the kernel entry
-	s_add_u32 s6, s6, s32
-	s_addc_u32 s7, s7, s33
-	s_add_u32 s42, s42, s32
-	s_addc_u32 s43, s43, s33
+	// taint: lanes into whose register file a non-finite value (NaN, +-Inf) has come - from the state rows, the
+	// PCM input, a TRAM read or a non-saturating instruction.  While no lane of the wave is tainted, no
+	// saturating instruction can see a NaN, and the wave runs the fast stream, whose saturation is a bare
+	// v_med3_f32; from the first tainted lane on it runs the exact stream (NaN passes the saturation,
+	// FX8010.cpp:275-279).
+	s_mov_b64 s[78:79], 0
+	v_mov_b32 v29, 0x207                                  // v_cmp_class mask: sNaN | qNaN | -Inf | +Inf
 	s_add_u32 s34, s32, (h_endsample_a-KNAME)
 	s_addc_u32 s35, s33, 0                                // s[34:35] = end-of-sample code (translated streams end with s_setpc_b64 s[34:35])
 #endif
@@ -222,6 +226,10 @@ KNAME:
 	s_lshl_b32 s64, s64, 8
 #endif
 	s_waitcnt vmcnt(0)
+#ifdef XLATE
+	v_cmp_class_f32 vcc, v2, v29
+	s_or_b64 s[78:79], s[78:79], vcc
+#endif
 	STOREV s64, v2
 	s_add_u32 s62, s62, 1
 	s_cmp_lt_u32 s62, s74
@@ -293,6 +301,16 @@ KNAME:
 
 	// ---- one sample period
 .Lsample:
+#ifdef XLATE
+	v_cmp_class_f32 vcc, v23, v29                         // non-finite PCM input taints (unused channels hold 0)
+	s_or_b64 s[78:79], s[78:79], vcc
+	v_cmp_class_f32 vcc, v24, v29
+	s_or_b64 s[78:79], s[78:79], vcc
+	v_cmp_class_f32 vcc, v25, v29
+	s_or_b64 s[78:79], s[78:79], vcc
+	v_cmp_class_f32 vcc, v26, v29
+	s_or_b64 s[78:79], s[78:79], vcc
+#endif
 	// this sample's input -> LDS rows
 	s_cmp_lt_i32 s48, 0
 	s_cbranch_scc1 .Ls_w1
@@ -360,6 +378,10 @@ KNAME:
 	s_cselect_b32 s5, s43, s7
 	v_mov_b32 v14, 0                                      // numSkip is local to process() (FX8010.cpp:1030)
 #ifdef XLATE
+	s_cmp_lg_u64 s[78:79], 0                              // tainted wave: exact stream (high dword), else fast stream
+	s_cselect_b32 s4, s5, s4
+	s_add_u32 s4, s4, s32
+	s_addc_u32 s5, s33, 0
 	s_setpc_b64 s[4:5]                                    // the translated program of this sample
 #else
 	s_load_dwordx16 s[16:31], s[4:5], 0x0                 // records 0, 1

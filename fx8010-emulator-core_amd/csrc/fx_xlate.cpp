@@ -200,6 +200,11 @@ class Emitter {
         put(0x80000000u | (op << 23) | ((sdst.code & 0x7fu) << 16) | (s1.code << 8) | s0.code, l);
         line(std::string(name) + " " + sdst.text + ", " + s0.text + ", " + s1.text);
     }
+    void sopc(uint32_t op, const char* name, const Src& s0, const Src& s1) {
+        w_.push_back(0xbf000000u | (op << 16) | (s1.code << 8) | s0.code);
+        ++count_;
+        line(std::string(name) + " " + s0.text + ", " + s1.text);
+    }
     void sopp(uint32_t op, const char* name, uint32_t simm, bool showImm) {
         w_.push_back(0xbf800000u | (op << 16) | (simm & 0xffffu));
         ++count_;
@@ -225,6 +230,7 @@ enum : uint32_t {
     VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
+    SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
@@ -239,23 +245,32 @@ constexpr int kSReturn = 24;      // s[24:25] = where a handler of set _a contin
 constexpr int kSEntry = 32;       // s[32:33] = address of the kernel entry
 constexpr int kSEndSample = 34;   // s[34:35] = end-of-sample frame
 constexpr int kSTemp = 62;        // s[62:63] scratch of the handlers, free between them
+constexpr int kSTaint = 78;       // s[78:79] lanes that hold a non-finite value (template prologue)
 
 class Translator {
   public:
-    Translator(const XlateTemplate& t, uint32_t codeBase, std::vector<uint32_t>* code, std::string* listing)
-        : tmpl_(t), base_(codeBase), e_(code, listing) {}
+    // exactReturns == nullptr: the exact stream (NaN passes every saturation).  Otherwise the fast stream, which
+    // assumes finite register contents and leaves for the exact stream - at the return address of the same
+    // call there, exactReturns[i] for record i - as soon as a handler has tainted the wave.
+    Translator(const XlateTemplate& t, uint32_t codeBase, std::vector<uint32_t>* code, std::string* listing,
+               const std::vector<uint32_t>* exactReturns)
+        : tmpl_(t), base_(codeBase), e_(code, listing), fast_(exactReturns != nullptr), exactReturns_(exactReturns) {}
 
-    bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::string* err) {
+    bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::vector<uint32_t>* returns, std::string* err) {
         bool ended = false;
-        for (const MicroOp& r : records) {
+        returns_.assign(records.size(), 0);
+        for (size_t i = 0; i < records.size(); ++i) {
+            const MicroOp& r = records[i];
             const uint32_t slot = r.w[0];
             if (slot == AS_ENDSAMPLE) { ended = true; break; }
+            index_ = i;
             if (!one(r, slot)) { if (err) *err = err_; return false; }
         }
+        if (returns) *returns = returns_;
         if (!ended) { if (err) *err = "record stream without ENDSAMPLE"; return false; }
         // the end-of-sample frame sets up its own index mode; EXEC is reset there as well
         e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSEndSample));
-        if (stats) { *stats = stats_; stats->instructions = e_.count(); }
+        if (stats) { *stats = stats_; stats->instructions = e_.count(); stats->nonFiniteImmediate = nonFinite_; }
         return true;
     }
 
@@ -269,11 +284,17 @@ class Translator {
     }
     // operand word -> source: a register-file row (VGPR) or the uniform's bit pattern
     bool operand(uint32_t word, bool uniform, Src* s) {
-        if (uniform) { *s = imm32(word); return true; }
+        if (uniform) { *s = value(word); return true; }
         int v;
         if (!row(word, &v)) return false;
         *s = vreg(v);
         return true;
+    }
+
+    // a uniform operand's bit pattern; a NaN or Inf among them rules the fast stream out
+    Src value(uint32_t bits) {
+        if ((bits & 0x7f800000u) == 0x7f800000u) nonFinite_ = true;
+        return imm32(bits);
     }
 
     // plain VALU code follows: leave the VGPR index mode a handler may have left on
@@ -286,8 +307,12 @@ class Translator {
 
     // v2 -> saturate (NaN passes, FX8010.cpp:275-279) -> row R
     void satStore(int vR) {
-        e_.vopc(VOPC_CMP_U_F32, "v_cmp_u_f32_e32", vreg(2), 2);
         Src m1 = imm32(0xbf800000u), p1 = imm32(0x3f800000u);
+        if (fast_) {  // no NaN can be here (taint discipline): the median is the saturation
+            e_.vop3(VOP3_MED3_F32, "v_med3_f32", vreg(vR), vreg(2), m1, &p1);
+            return;
+        }
+        e_.vopc(VOPC_CMP_U_F32, "v_cmp_u_f32_e32", vreg(2), 2);
         e_.vop3(VOP3_MED3_F32, "v_med3_f32", vreg(5), vreg(2), m1, &p1);
         e_.sopp(SOPP_NOP, "s_nop", 0, true);  // 2 wait states between the VALU write of VCC and its VALU read
         e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", vR, vreg(5), 2, ", vcc");
@@ -303,10 +328,10 @@ class Translator {
         if (!uX && !uY) {
             if (!operand(r.w[3], false, &a) || !row(r.w[4], &b)) return false;
         } else if (uX) {
-            a = imm32(r.w[3]);
+            a = value(r.w[3]);
             if (!row(r.w[4], &b)) return false;
         } else {
-            a = imm32(r.w[4]);
+            a = value(r.w[4]);
             if (!row(r.w[3], &b)) return false;
         }
         e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 3, a, b);
@@ -318,7 +343,7 @@ class Translator {
         if (!row(r.w[5], &vR)) return false;
         plainMode();
         if (kind == 7) {  // folded on the host: the A word is the saturated result
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(r.w[2]));
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), value(r.w[2]));
             return true;
         }
         bool inV3;
@@ -330,7 +355,7 @@ class Translator {
         } else {
             int vA;
             if (!row(r.w[2], &vA)) return false;
-            e_.vop2(neg ? VOP2_SUBREV_F32 : VOP2_ADD_F32, neg ? "v_subrev_f32_e32" : "v_add_f32_e32", 2, imm32(r.w[3]), vA);
+            e_.vop2(neg ? VOP2_SUBREV_F32 : VOP2_ADD_F32, neg ? "v_subrev_f32_e32" : "v_add_f32_e32", 2, value(r.w[3]), vA);
         }
         satStore(vR);
         return true;
@@ -341,22 +366,22 @@ class Translator {
         if (!row(r.w[5], &vR)) return false;
         plainMode();
         if (kind == 7) {
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(r.w[2]));
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), value(r.w[2]));
             return true;
         }
         const bool uA = kind & 1, uX = kind & 2, uY = kind & 4;
         if (uA && uX) {  // t = A + X folded into the A word
             int vY;
             if (!row(r.w[4], &vY)) return false;
-            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, imm32(r.w[2]), vY);
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, value(r.w[2]), vY);
         } else {
             Src a;
             int b;
             if (uA) {
-                a = imm32(r.w[2]);
+                a = value(r.w[2]);
                 if (!row(r.w[3], &b)) return false;
             } else if (uX) {
-                a = imm32(r.w[3]);
+                a = value(r.w[3]);
                 if (!row(r.w[2], &b)) return false;
             } else {
                 if (!operand(r.w[2], false, &a) || !row(r.w[3], &b)) return false;
@@ -376,7 +401,7 @@ class Translator {
         if (!row(r.w[5], &vR)) return false;
         plainMode();
         if (kind == 7) {
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(r.w[2]));
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), value(r.w[2]));
             return true;
         }
         bool inV3;
@@ -403,7 +428,7 @@ class Translator {
             e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), named(242, "1.0"), vreg64(6), nullptr, 2);
             e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
         }
-        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), inV3 ? vreg(3) : imm32(r.w[3]));
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), inV3 ? vreg(3) : value(r.w[3]));
         e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
         e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(2), vreg64(6));
         satStore(vR);
@@ -431,8 +456,19 @@ class Translator {
         e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSTemp + 1), sreg(kSEntry + 1), imm32(0));
         e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSTemp));
         if (base_ + (uint32_t)e_.bytes() != ret) return fail("internal: call sequence length");
+        returns_[index_] = ret;
         indexModeUnknown_ = true;
         ++stats_.called;
+        const bool canTaint = slot == AS_MACW || slot == AS_MACWN || slot == AS_MACINTW || slot == AS_LUT || slot == AS_TRAM_IR || slot == AS_TRAM_XR;
+        if (fast_ && canTaint) {
+            // the handler may have met a non-finite value: continue in the exact stream, after the same call there
+            const uint32_t target = (*exactReturns_)[index_];
+            if (target == 0) return fail("internal: fast and exact streams differ in their calls");
+            e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTaint), imm32(0));
+            const int64_t delta = ((int64_t)target - ((int64_t)base_ + (int64_t)e_.bytes() + 4)) / 4;
+            if (delta < -32768 || delta > 32767) return fail("exact stream out of branch range of the fast stream");
+            e_.sopp(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", (uint32_t)delta & 0xffffu, true);
+        }
         return true;
     }
 
@@ -490,6 +526,11 @@ class Translator {
     Emitter e_;
     XlateStats stats_;
     std::string err_;
+    bool fast_;
+    const std::vector<uint32_t>* exactReturns_;
+    std::vector<uint32_t> returns_;  // per record: offset of the return address of its handler call (0 = no call)
+    size_t index_ = 0;
+    bool nonFinite_ = false;
     bool indexModeUnknown_ = false;  // the per-sample frame enters the stream with index mode off
     bool known_[8] = {};
     uint32_t value_[8] = {};
@@ -537,28 +578,61 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
 }
 
 bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, uint32_t codeBase,
-                     std::vector<uint32_t>* code, std::string* listing, XlateStats* stats, std::string* err) {
+                     const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code, std::string* listing,
+                     XlateStats* stats, std::vector<uint32_t>* returns, std::string* err) {
     code->clear();
-    Translator t(tmpl, codeBase, code, listing);
-    return t.run(records, stats, err);
+    Translator t(tmpl, codeBase, code, listing, exactReturns);
+    return t.run(records, stats, returns, err);
 }
 
-bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
-                     const XlateTemplate& tmpl, XlateImage* out, std::string* err) {
-    std::vector<uint32_t> steady, last;
-    out->steadyOff = tmpl.holeOff;
-    if (!translateStream(steadyRecords, tmpl, out->steadyOff, &steady, nullptr, &out->steady, err)) return false;
-    const uint32_t steadyBytes = (uint32_t)((steady.size() * 4 + 63) & ~(size_t)63);  // streams start on a cache line
-    out->lastOff = tmpl.holeOff + steadyBytes;
-    if (!translateStream(lastRecords, tmpl, out->lastOff, &last, nullptr, &out->last, err)) return false;
-    out->codeBytes = steadyBytes + (uint32_t)(last.size() * 4);
+namespace {
+inline uint32_t align64(uint32_t v) { return (v + 63u) & ~63u; }
+}
+
+bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
+               XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err) {
+    // hole: [steady fast][steady exact][last fast][last exact], each on a cache line.  The exact stream of a pair
+    // is translated first (its call return addresses are the fast stream's escape targets); its position depends
+    // on the fast stream's size, which does not depend on the targets - so: size the fast stream with dummy targets.
+    const std::vector<MicroOp>* recs[2] = {&steadyRecords, &lastRecords};
+    uint32_t at = tmpl.holeOff;
+    for (int k = 0; k < 2; ++k) {
+        std::vector<uint32_t> exactRet, scratch, dummy(recs[k]->size(), at);
+        XlateStats fastStats, exactStats;
+        // pass 1: size of the fast stream (targets = its own base: in range, value irrelevant)
+        if (!translateStream(*recs[k], tmpl, at, &dummy, &scratch, nullptr, &fastStats, nullptr, err)) return false;
+        const uint32_t fastBytes = align64((uint32_t)scratch.size() * 4);
+        const bool fastOk = !fastStats.nonFiniteImmediate;
+        const uint32_t exactAt = fastOk ? at + fastBytes : at;
+        if (!translateStream(*recs[k], tmpl, exactAt, nullptr, &code[2 * k + 1], listing ? &listing[2 * k + 1] : nullptr, &exactStats, &exactRet, err))
+            return false;
+        if (fastOk) {
+            if (!translateStream(*recs[k], tmpl, at, &exactRet, &code[2 * k], listing ? &listing[2 * k] : nullptr, &fastStats, nullptr, err)) return false;
+            if (align64((uint32_t)code[2 * k].size() * 4) != fastBytes) { if (err) *err = "internal: fast stream changed size"; return false; }
+        } else {
+            code[2 * k].clear();  // a non-finite uniform operand: every wave runs the exact stream
+        }
+        (k == 0 ? out->steadyFastOff : out->lastFastOff) = fastOk ? at : exactAt;
+        (k == 0 ? out->steadyOff : out->lastOff) = exactAt;
+        (k == 0 ? out->steady : out->last) = fastOk ? fastStats : exactStats;
+        at = exactAt + align64((uint32_t)code[2 * k + 1].size() * 4);
+    }
+    out->codeBytes = at - tmpl.holeOff;
     if (out->codeBytes + 4 > tmpl.holeBytes) {
         if (err) *err = "translated program larger than the code hole of the template";
         return false;
     }
+    return true;
+}
+
+bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
+                     const XlateTemplate& tmpl, XlateImage* out, std::string* err) {
+    std::vector<uint32_t> code[4];
+    if (!planXlate(steadyRecords, lastRecords, tmpl, out, code, nullptr, err)) return false;
     out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
-    std::memcpy(out->elf.data() + tmpl.holeFileOff, steady.data(), steady.size() * 4);
-    std::memcpy(out->elf.data() + tmpl.holeFileOff + steadyBytes, last.data(), last.size() * 4);
+    const uint32_t offs[4] = {out->steadyFastOff, out->steadyOff, out->lastFastOff, out->lastOff};
+    for (int k = 0; k < 4; ++k)
+        if (!code[k].empty()) std::memcpy(out->elf.data() + tmpl.holeFileOff + (offs[k] - tmpl.holeOff), code[k].data(), code[k].size() * 4);
     return true;
 }
 

@@ -42,21 +42,37 @@ struct XlateStats {
     int inlined = 0;     // records translated to straight-line code
     int called = 0;      // records executed by a call to the interpreter's handler
     int instructions = 0;
+    bool nonFiniteImmediate = false;  // a NaN / Inf among the uniform operands: no fast stream for this program
 };
 
 // Translate one stream of records (encodeAsmStream(ops, nullptr, true): w0 = handler slot) into code that
 // starts `codeBase` bytes after the kernel entry.  The code ends with the jump to the end-of-sample frame.
+//
+// Two flavours.  exactReturns == nullptr: the EXACT stream, whose saturation lets a NaN pass as the reference's
+// does (FX8010.cpp:275-279: 3 VALU instructions).  exactReturns != nullptr: the FAST stream, whose saturation is
+// one v_med3_f32 - valid while the register file holds only finite values, which the template tracks ("taint":
+// state rows, PCM input, TRAM reads and results of non-saturating instructions are checked where they enter).
+// After each handler call that can taint, the fast stream tests the taint mask and continues in the exact
+// stream at the return address of the same call there (exactReturns[record], produced by the exact translation
+// through `returns`).  A wave thus runs fast code until the first non-finite value shows up, exact code after.
 // listing (optional) receives one assembler line per instruction, in llvm-mc syntax.
 bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, uint32_t codeBase,
-                     std::vector<uint32_t>* code, std::string* listing, XlateStats* stats, std::string* err);
+                     const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code, std::string* listing,
+                     XlateStats* stats, std::vector<uint32_t>* returns, std::string* err);
 
-// A loadable code object: the template with both streams in its hole.
+// A loadable code object: the template with the four streams in its hole.
 struct XlateImage {
     std::vector<unsigned char> elf;
-    uint32_t steadyOff = 0, lastOff = 0;  // entry offsets from the kernel entry (passed as AsmArgs.steady/.last)
+    // entry offsets from the kernel entry; AsmArgs.steady = steadyFastOff | steadyOff << 32, .last likewise
+    uint32_t steadyFastOff = 0, steadyOff = 0, lastFastOff = 0, lastOff = 0;
     uint32_t codeBytes = 0;
-    XlateStats steady, last;
+    XlateStats steady, last;  // of the stream a finite wave runs
 };
+// Lays the four streams out ([steady fast][steady exact][last fast][last exact]) and translates them; code[k] /
+// listing[k] in that order (listing may be nullptr).  Without a fast stream (non-finite uniform operand) the
+// fast offsets equal the exact ones.
+bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
+               XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err);
 bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
                      const XlateTemplate& tmpl, XlateImage* out, std::string* err);
 

@@ -162,12 +162,13 @@ class FrontEnd(_Reports):
     def lower_info(self, what):
         return int(self._lib.fxp_lower_info(self._h, INFO[what]))
 
-    def translate(self, vgprs=0, last_sample=False):
-        """gfx950 machine code of the program as the batch path generates it: (code bytes, assembler listing)."""
+    def translate(self, vgprs=0, stream=0):
+        """gfx950 machine code of the program as the batch path generates it: (code bytes, assembler listing).
+        stream: 0 steady fast, 1 steady exact, 2 last-sample fast, 3 last-sample exact."""
         cap, tcap = 1 << 20, 1 << 23
         code = C.create_string_buffer(cap)
         text = C.create_string_buffer(tcap)
-        n = int(self._lib.fxp_translate(self._h, int(vgprs), int(bool(last_sample)), code, cap, text, tcap))
+        n = int(self._lib.fxp_translate(self._h, int(vgprs), int(stream), code, cap, text, tcap))
         if n < 0:
             raise RuntimeError("fxp_translate: %d %s" % (n, self.last_error()))
         return code.raw[:n], text.value.decode("ascii")

@@ -187,12 +187,14 @@ const double* fxp_lut(int kind, int exponent);
  * takes the FXB_INFO_* selectors that describe the lowering. */
 int fxp_lower(fxp_handle* h);
 int64_t fxp_lower_info(fxp_handle* h, int what);
-/* Translate the loaded program to gfx950 machine code as the batch path would (no device needed): the
- * steady stream (last_sample = 0) or the last-sample stream of the VGPR build with `vgprs` registers
- * (64/72/80/96/128/168/256; 0 = the smallest build that holds the program).  Returns the code size in bytes
- * (negative FX_E_* when the program cannot be translated, see fxp_last_error) and copies at most `cap` bytes of
- * code and at most listing_cap-1 characters of the assembler listing (one instruction per line). */
-int64_t fxp_translate(fxp_handle* h, int vgprs, int last_sample, void* code, int64_t cap, char* listing, int64_t listing_cap);
+/* Translate the loaded program to gfx950 machine code as the batch path would (no device needed), for the VGPR
+ * build with `vgprs` registers (64/72/80/96/128/168/256; 0 = the smallest build that holds the program).
+ * stream: 0 = steady fast, 1 = steady exact, 2 = last-sample fast, 3 = last-sample exact (fast streams assume a
+ * finite register file and leave for the exact one when a non-finite value appears; a program with a non-finite
+ * uniform operand has no fast streams: size 0).  Returns the code size in bytes (negative FX_E_* when the program
+ * cannot be translated, see fxp_last_error) and copies at most `cap` bytes of code and at most listing_cap-1
+ * characters of the assembler listing (one instruction per line). */
+int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap);
 const char* fxp_last_error(fxp_handle* h);
 
 /* library / device probe: number of HIP devices visible (0 if none), never throws */

@@ -177,6 +177,80 @@ def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
     assert (b.info("kernel") > 0) == (kern != "hip")
 
 
+def same_with_nan(ref, got):
+    """bit-equal, except that any NaN matches any NaN (x86 and gfx950 differ in the default NaN's sign bit)"""
+    ref = np.asarray(ref, dtype=np.float32).reshape(-1)
+    got = np.asarray(got, dtype=np.float32).reshape(-1)
+    rn, gn = np.isnan(ref), np.isnan(got)
+    return np.array_equal(rn, gn) and np.array_equal(bits(ref)[~rn], bits(got)[~gn])
+
+
+NONFINITE_PROGRAM = HDR + """static big = 100000000000000000000000000000000000000.0
+static t
+static u
+static w
+itramsize 6 
+idelay read, rd, at, 0
+macs a, a, vol, in
+macw t, big, in, big
+macs u, t, t, -1
+acc3 w, u, a, 0.25
+interp b, w, 0.25, a
+idelay write, in, at, 0
+macs out, rd, b, 0.5
+end"""
+
+
+@pytest.mark.parametrize("case", ["nan_input", "inf_input", "overflow_in_macw", "nan_state", "inf_uniform", "plain"])
+def test_non_finite_values_follow_the_reference(gpu, k, case):
+    """NaN passes the reference's saturate() (FX8010.cpp:275-279) and Inf saturates; the translated program's
+    fast stream assumes finite registers and must hand over to the exact stream wherever a non-finite value can
+    enter: PCM input, state rows, TRAM reads (the delayed input), a non-saturating result (MACW overflow),
+    a non-finite uniform."""
+    N, S = 96, 40
+    x = progs.stimulus(N, S).copy()
+    pre = None
+    if case == "nan_input":
+        x[7, 3] = np.nan
+        x[20, 70] = -np.nan
+    elif case == "inf_input":
+        x[5, 64] = np.inf
+        x[9, 1] = -np.inf
+    elif case == "inf_uniform":
+        x[4, 10] = 0.0  # 0 * Inf
+    elif case == "overflow_in_macw":
+        x[11, 5] = 3.0  # big + wrap(3 * big) = +Inf in `t`, then Inf - Inf
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(NONFINITE_PROGRAM), b.errors()
+    if case == "nan_state":
+        b.set_register_i("a", 33, float("nan"))
+        b.set_register_i("a", 65, float("inf"))
+    elif case == "inf_uniform":
+        b.set_register("vol", float("inf"))
+        b.set_register("big", float("inf"))
+    y = b.process_block(x)
+    saw_nan = False
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(NONFINITE_PROGRAM)
+        if case == "nan_state" and n == 33:
+            o.set_register("a", float("nan"))
+        if case == "nan_state" and n == 65:
+            o.set_register("a", float("inf"))
+        if case == "inf_uniform":
+            o.set_register("vol", float("inf"))
+            o.set_register("big", float("inf"))
+        ref = o.process_block(x[:, n].copy())
+        assert same_with_nan(ref, y[:, n]), "instance %d" % n
+        saw_nan = saw_nan or bool(np.isnan(ref).any())
+        for r in ("a", "b", "t", "u", "w", "out"):
+            rb, gb = o.get_register_bits(r), b.get_register_bits_i(r, n)
+            rf, gf = np.array([rb], dtype=np.uint32).view(np.float32)[0], np.array([gb], dtype=np.uint32).view(np.float32)[0]
+            assert (np.isnan(rf) and np.isnan(gf)) or rb == gb, "instance %d register %s: ref %08x got %08x" % (n, r, rb, gb)
+    if case in ("nan_input", "overflow_in_macw", "nan_state", "inf_uniform"):
+        assert saw_nan  # the case does exercise NaN through saturating instructions
+
+
 def test_delay_line_exact(gpu, k):
     text = "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend"
     x = progs.stimulus(66, 64)

@@ -54,7 +54,7 @@ def program_texts():
 
 
 @needs_llvm
-@pytest.mark.parametrize("last", [False, True], ids=["steady", "last"])
+@pytest.mark.parametrize("last", [0, 1, 2, 3], ids=["steady_fast", "steady_exact", "last_fast", "last_exact"])
 def test_listing_reassembles_to_the_same_bytes(last):
     for name, text in program_texts():
         fe = A.FrontEnd(1)
@@ -70,8 +70,8 @@ def test_structure_of_translated_code():
     for name, text in program_texts():
         fe = A.FrontEnd(1)
         assert fe.load_text(text), name
-        for vgprs in (0, 256):
-            code, listing = fe.translate(vgprs, False)
+        for vgprs, stream in ((0, 0), (0, 1), (256, 0), (0, 3)):
+            code, listing = fe.translate(vgprs, stream)
             lines = listing.strip().split("\n")
             assert lines[-1] == "s_setpc_b64 s[34:35]", name  # back to the end-of-sample frame, nothing after it
             # every VGPR named is inside the build's budget (the smallest build is at least 64)
@@ -83,6 +83,8 @@ def test_structure_of_translated_code():
             # SGPR writes stay inside the record window, the return address and the scratch pair
             for m in re.finditer(r"^(s_mov_b32|s_add_u32|s_addc_u32) s(\d+),", listing, re.M):
                 assert int(m.group(2)) in (18, 19, 20, 21, 22, 23, 24, 25, 62, 63), (name, m.group(0))
+            if stream in (1, 3):
+                assert "s_cbranch" not in listing  # only the fast streams branch (to the exact ones)
             # a call's return address is the instruction after its s_setpc_b64
             words = np.frombuffer(code, dtype=np.uint32)
             assert words[-1] == 0xBE801D22  # s_setpc_b64 s[34:35]
