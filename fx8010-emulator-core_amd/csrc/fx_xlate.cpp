@@ -231,7 +231,7 @@ enum : uint32_t {
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
-    VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
+    VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
     SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
@@ -414,13 +414,21 @@ class Translator {
             const InlineD* inl = nullptr;
             for (const InlineD& k : kInlineF64)
                 if (k.bits == omx) inl = &k;
-            if (inl) {
-                e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), named(inl->code, inl->text), vreg64(8), nullptr);
-            } else {
+            if (!inl) {
                 setRecordWord(6, r.w[6]);
                 setRecordWord(7, r.w[7]);
-                e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), sreg64(kSRecord + 6), vreg64(8), nullptr);
             }
+            const Src m = inl ? named(inl->code, inl->text) : sreg64(kSRecord + 6);
+            if (productWithFloatIsExact(omx)) {
+                // (1-X)*A is exact in fp64 for every float A, so mul-then-add rounds once - exactly what one fma does
+                e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(10), inV3 ? vreg(3) : value(r.w[3]));
+                Src addend = vreg64(10);
+                e_.vop3(VOP3_FMA_F64, "v_fma_f64", vreg64(6), m, vreg64(8), &addend);
+                e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(2), vreg64(6));
+                satStore(vR);
+                return true;
+            }
+            e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), m, vreg64(8), nullptr);
         } else {
             Src x;
             if (!operand(r.w[3], false, &x)) return false;
@@ -433,6 +441,15 @@ class Translator {
         e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(2), vreg64(6));
         satStore(vR);
         return true;
+    }
+
+    // Is d * (double)f exact for every float f?  A float has 24 significant bits, a double 53: yes when d has at
+    // most 29 (zero, or a normal number whose low 24 mantissa bits are clear; subnormal d: no claim).
+    static bool productWithFloatIsExact(uint64_t dbits) {
+        if ((dbits << 1) == 0) return true;
+        const uint32_t exponent = (uint32_t)(dbits >> 52) & 0x7ffu;
+        if (exponent == 0 || exponent == 0x7ffu) return false;
+        return (dbits & 0xffffffull) == 0;
     }
 
     // s(16+k) = word k of the record, unless it holds that value already

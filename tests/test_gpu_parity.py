@@ -177,6 +177,29 @@ def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
     assert (b.info("kernel") > 0) == (kern != "hip")
 
 
+def test_interp_uniform_x_sweep(gpu, k):
+    """INTERP (FX8010.cpp:1180-1187) rounds (1-X)*A and the sum separately in fp64.  The translator uses one fma
+    where (1-X)*A is exact for every float A (X with few significant bits after 1-X) and mul + add elsewhere:
+    both sides of that decision, over operands from denormal to saturated."""
+    consts = ["0.3", "0.5", "0.0001", "0.999", "1.0", "0.0", "0.75", "0.015625", "0.01", "0.0000001", "0.6180339", "0.99999994"]
+    regs = ["r%d" % i for i in range(len(consts))]
+    text = HDR + "".join("static %s\n" % r for r in regs)
+    for r, c in zip(regs, consts):
+        text += "interp %s, %s, %s, in\n" % (r, r, c)       # one-pole smoothing with state
+        text += "interp a, in, %s, %s\n" % (c, r)
+        text += "macs out, out, a, 0.03125\n"
+    text += "end"
+    rng = np.random.default_rng(99)
+    S, N = 96, 128
+    x = rng.uniform(-1.0, 1.0, size=(S, N)).astype(np.float32)
+    x[:, 1] *= np.float32(1e-38)      # denormal products
+    x[:, 2] *= np.float32(1e-20)
+    x[:, 3] = np.where(rng.uniform(size=S) < 0.5, 1.0, -1.0).astype(np.float32)
+    x[:, 4] = np.float32(2.0) * x[:, 4]  # beyond the saturation range on the input side
+    x[5::7, 5] = 0.0
+    check_batch(gpu, text, x, regs=tuple(regs) + ("a", "out", "ccr"))
+
+
 def same_with_nan(ref, got):
     """bit-equal, except that any NaN matches any NaN (x86 and gfx950 differ in the default NaN's sign bit)"""
     ref = np.asarray(ref, dtype=np.float32).reshape(-1)

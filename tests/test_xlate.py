@@ -79,7 +79,7 @@ def test_structure_of_translated_code():
             for m in re.finditer(r"\bv(\d+)\b", listing):
                 assert int(m.group(1)) < budget
             for m in re.finditer(r"v\[(\d+):(\d+)\]", listing):
-                assert int(m.group(2)) < 14  # 64-bit temporaries only
+                assert int(m.group(2)) < 14  # 64-bit temporaries only (v[6:7], v[8:9], v[10:11])
             # SGPR writes stay inside the record window, the return address and the scratch pair
             for m in re.finditer(r"^(s_mov_b32|s_add_u32|s_addc_u32) s(\d+),", listing, re.M):
                 assert int(m.group(2)) in (18, 19, 20, 21, 22, 23, 24, 25, 62, 63), (name, m.group(0))
