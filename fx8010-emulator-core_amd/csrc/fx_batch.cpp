@@ -263,8 +263,9 @@ int Batch::ensureLowered() {
         // first choice for a VGPR build: translate the program into gfx950 code (FX_KERNEL=asm* pins the interpreter)
         const XlateTemplate* tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
         XlateImage image;
-        if (tmpl && buildXlateImage(encodeAsmStream(low_.steady, nullptr, true), encodeAsmStream(low_.last, nullptr, true), *tmpl, &image,
-                                    &xlateWhyNot_)) {
+        const std::vector<MicroOp> steadyRecords = encodeAsmStream(low_.steady, nullptr, true), lastRecords = encodeAsmStream(low_.last, nullptr, true);
+        if (tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize),
+                                    &image, &xlateWhyNot_)) {
             if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still run the old code
             if (xlateModule_) (void)hipModuleUnload(xlateModule_);
             xlateModule_ = nullptr;

@@ -217,7 +217,9 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t 
     std::vector<uint32_t> code4[4];
     std::string text4[4];
     fx::XlateImage plan;
-    if (!fx::planXlate(fx::encodeAsmStream(low.steady, nullptr, true), fx::encodeAsmStream(low.last, nullptr, true), *tmpl, &plan, code4, text4, &h->err))
+    const std::vector<fx::MicroOp> steadyRecords = fx::encodeAsmStream(low.steady, nullptr, true), lastRecords = fx::encodeAsmStream(low.last, nullptr, true);
+    if (!fx::planXlate(steadyRecords, lastRecords, *tmpl, fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize), &plan, code4,
+                       text4, &h->err))
         return FX_E_PROGRAM;
     const std::vector<uint32_t>& words = code4[stream];
     const std::string& text = text4[stream];

@@ -200,6 +200,20 @@ class Emitter {
         put(0x80000000u | (op << 23) | ((sdst.code & 0x7fu) << 16) | (s1.code << 8) | s0.code, l);
         line(std::string(name) + " " + sdst.text + ", " + s0.text + ", " + s1.text);
     }
+    // global_{load,store}_dword with an SGPR base pair and a VGPR byte offset, no immediate offset
+    void global(uint32_t op, bool load, int vdata, int vaddr, int sbase) {
+        w_.push_back(0xdc008000u | (op << 18));
+        w_.push_back((uint32_t)vaddr | (load ? 0u : (uint32_t)vdata << 8) | ((uint32_t)sbase << 16) | (load ? (uint32_t)vdata << 24 : 0u));
+        ++count_;
+        const std::string base = "s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]";
+        if (load) line("global_load_dword v" + std::to_string(vdata) + ", v" + std::to_string(vaddr) + ", " + base);
+        else line("global_store_dword v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + ", " + base);
+    }
+    void waitVmcnt0() {
+        w_.push_back(0xbf8c0f70u);
+        ++count_;
+        line("s_waitcnt vmcnt(0)");
+    }
     void sopc(uint32_t op, const char* name, const Src& s0, const Src& s1) {
         w_.push_back(0xbf000000u | (op << 16) | (s1.code << 8) | s0.code);
         ++count_;
@@ -231,6 +245,9 @@ enum : uint32_t {
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
+    SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
+    SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
+    VOP1_READFIRSTLANE = 2, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
@@ -246,28 +263,48 @@ constexpr int kSEntry = 32;       // s[32:33] = address of the kernel entry
 constexpr int kSEndSample = 34;   // s[34:35] = end-of-sample frame
 constexpr int kSTemp = 62;        // s[62:63] scratch of the handlers, free between them
 constexpr int kSTaint = 78;       // s[78:79] lanes that hold a non-finite value (template prologue)
+constexpr int kVLane4 = 1;        // v1 = lane * 4
+constexpr int kVClassMask = 29;   // v29 = v_cmp_class mask of NaN and +-Inf
+constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane
+constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read
+constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
+constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
+constexpr int kSTramBase[2] = {36, 38}, kSTramSize[2] = {56, 57}, kSTramSlots[2] = {46, 47};  // [iTRAM, xTRAM]
 
 class Translator {
   public:
     // exactReturns == nullptr: the exact stream (NaN passes every saturation).  Otherwise the fast stream, which
     // assumes finite register contents and leaves for the exact stream - at the return address of the same
     // call there, exactReturns[i] for record i - as soon as a handler has tainted the wave.
-    Translator(const XlateTemplate& t, uint32_t codeBase, std::vector<uint32_t>* code, std::string* listing,
+    Translator(const XlateTemplate& t, const XlateProgram& prog, uint32_t codeBase, std::vector<uint32_t>* code, std::string* listing,
                const std::vector<uint32_t>* exactReturns)
-        : tmpl_(t), base_(codeBase), e_(code, listing), fast_(exactReturns != nullptr), exactReturns_(exactReturns) {}
+        : tmpl_(t), prog_(prog), base_(codeBase), e_(code, listing), fast_(exactReturns != nullptr), exactReturns_(exactReturns) {}
 
     bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::vector<uint32_t>* returns, std::string* err) {
         bool ended = false;
-        returns_.assign(records.size(), 0);
+        // sync points, two per record (+ the stream end): [2i] after the wait for TRAM reads pending before record i,
+        // [2i+1] the return address of record i's handler call
+        returns_.assign(2 * records.size() + 2, 0);
+        if (prog_.uniformCursors) {
+            // every TRAM instruction runs on all lanes: the four cursors are the same in every lane, keep them in SGPRs
+            for (int c = 0; c < 4; ++c) e_.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSCursor + c), vreg(kVCursor + c));
+            e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
+        }
         for (size_t i = 0; i < records.size(); ++i) {
             const MicroOp& r = records[i];
             const uint32_t slot = r.w[0];
-            if (slot == AS_ENDSAMPLE) { ended = true; break; }
             index_ = i;
+            if (slot == AS_ENDSAMPLE) { ended = true; break; }
             if (!one(r, slot)) { if (err) *err = err_; return false; }
         }
-        if (returns) *returns = returns_;
         if (!ended) { if (err) *err = "record stream without ENDSAMPLE"; return false; }
+        if (!flush()) { if (err) *err = err_; return false; }
+        if (prog_.uniformCursors) {
+            plainMode();
+            for (int c = 0; c < 4; ++c) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVCursor + c), sreg(kSCursor + c));
+            e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, sreg(kSOod), kVOod);
+        }
+        if (returns) *returns = returns_;
         // the end-of-sample frame sets up its own index mode; EXEC is reset there as well
         e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSEndSample));
         if (stats) { *stats = stats_; stats->instructions = e_.count(); stats->nonFiniteImmediate = nonFinite_; }
@@ -280,6 +317,111 @@ class Translator {
     bool row(uint32_t r, int* v) {
         if (r >= (uint32_t)(tmpl_.vgprs - kRegFileBase)) return fail("register-file row beyond the VGPR budget of the build");
         *v = kRegFileBase + (int)r;
+        for (int p : pending_)
+            if (p == *v) return fail("internal: row with a TRAM read in flight");
+        return true;
+    }
+
+    // TRAM reads are issued without waiting; the wait (and, in the fast stream, the taint check of what arrived
+    // and the hand-over to the exact stream) happens here, before the first use of such a row
+    bool flush() {
+        if (pending_.empty()) return true;
+        e_.waitVmcnt0();
+        returns_[2 * index_] = base_ + (uint32_t)e_.bytes();
+        if (fast_) {
+            plainMode();
+            for (int v : pending_) {
+                e_.vopc(VOPC_CMP_CLASS_F32, "v_cmp_class_f32_e32", vreg(v), kVClassMask);
+                e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
+            }
+            if (!leaveIfTainted((*exactReturns_)[2 * index_])) return false;
+        }
+        pending_.clear();
+        return true;
+    }
+    bool leaveIfTainted(uint32_t target) {
+        if (target == 0) return fail("internal: fast and exact streams differ in their sync points");
+        e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTaint), imm32(0));
+        const int64_t delta = ((int64_t)target - ((int64_t)base_ + (int64_t)e_.bytes() + 4)) / 4;
+        if (delta < -32768 || delta > 32767) return fail("exact stream out of branch range of the fast stream");
+        e_.sopp(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", (uint32_t)delta & 0xffffu, true);
+        return true;
+    }
+    // the record is about to read / write these register-file rows: none may still be in flight
+    bool touch(const MicroOp& r, bool a, bool x, bool y, bool dst) {
+        if (pending_.empty()) return true;
+        const uint32_t rows[4] = {r.w[2], r.w[3], r.w[4], r.w[5]};
+        const bool use[4] = {a, x, y, dst};
+        for (int k = 0; k < 4; ++k)
+            if (use[k])
+                for (int p : pending_)
+                    if (p == kRegFileBase + (int)rows[k]) return flush();
+        return true;
+    }
+
+    static int32_t x86Trunc(uint32_t bits) {  // cvttss2si: 0x80000000 for NaN and anything outside int32
+        float f;
+        std::memcpy(&f, &bits, 4);
+        if (!(f > -2147483904.0f && f < 2147483648.0f)) return INT32_MIN;
+        return (int32_t)f;
+    }
+
+    // IDELAY / XDELAY with uniform cursors (fx_interp_handlers.inc TRAM_READ / TRAM_WRITE are the per-lane versions;
+    // FX8010.cpp:909-967).  Slot arithmetic, bounds and cursor update are scalar; the lanes only move data.
+    bool tram(const MicroOp& r, uint32_t slot) {
+        const bool isRead = slot == AS_TRAM_IR || slot == AS_TRAM_XR;
+        const int t = (slot == AS_TRAM_IR || slot == AS_TRAM_IW) ? 0 : 1;
+        const int cursor = kSCursor + 2 * t + (isRead ? 1 : 0);
+        const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
+        if (!touch(r, !isRead && !(r.w[6] & 1u), false, false, isRead)) return false;
+        plainMode();
+        int vR = 0;
+        if (isRead && !row(r.w[5], &vR)) return false;
+        if (size < 1) {  // the reference would divide by zero: flagged, the read yields 0
+            if (isRead) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
+            return true;
+        }
+        int32_t p = x86Trunc(r.w[4]);
+        p = p > size - 1 ? size - 1 : p;
+        p = p < 0 ? 0 : p;
+        const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
+        if (isRead) {
+            if (p != 0) {
+                e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
+                e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", sreg(kSPos), imm32(0));
+                e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 2, true);
+                e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(kSPos), sreg(kSTramSize[t]));  // C's % keeps it negative: flagged
+                e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(1));
+            }
+            e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSTramSlots[t]));
+            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6, true);
+            e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSPos), pos, imm32(8));
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSTramBase[t]), sreg(kSPos));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSTramBase[t] + 1), imm32(0));
+            e_.global(GLOBAL_LOAD_DWORD, true, vR, kVLane4, kSAddr);
+            e_.sopp(SOPP_BRANCH, "s_branch", 1, true);
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+            pending_.push_back(vR);
+        } else {
+            int vA = 2;
+            if (r.w[6] & 1u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));
+            else if (!row(r.w[2], &vA)) return false;
+            if (p != 0) e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
+            e_.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSAddr), sreg(kSTramSlots[t]), imm32(t == 0 ? 8192u : 1048576u, true));
+            e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSAddr));
+            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6, true);
+            e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSPos), pos, imm32(8));
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSTramBase[t]), sreg(kSPos));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSTramBase[t] + 1), imm32(0));
+            e_.global(GLOBAL_STORE_DWORD, false, vA, kVLane4, kSAddr);
+            e_.sopp(SOPP_BRANCH, "s_branch", 1, true);
+            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
+        }
+        // cursor = (cursor + 1) % size
+        e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(cursor), sreg(cursor), imm32(1));
+        e_.sopc(SOPC_CMP_GE_I32, "s_cmp_ge_i32", sreg(cursor), sreg(kSTramSize[t]));
+        e_.sop2(SOP2_CSELECT_B32, "s_cselect_b32", sreg(cursor), imm32(0), sreg(cursor));
         return true;
     }
     // operand word -> source: a register-file row (VGPR) or the uniform's bit pattern
@@ -463,6 +605,7 @@ class Translator {
     // run the interpreter's handler for this record: operands in s18..s23, return address in s[24:25]
     bool call(const MicroOp& r, uint32_t slot, uint32_t wordMask) {
         if (slot >= (uint32_t)kAsmSlots) return fail("record with an unknown handler slot");
+        if (!flush()) return false;  // the handler addresses rows by index
         for (int k = 2; k < 8; ++k)
             if (wordMask & (1u << k)) setRecordWord(k, r.w[k]);
         const uint32_t at = base_ + (uint32_t)e_.bytes();
@@ -473,19 +616,12 @@ class Translator {
         e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSTemp + 1), sreg(kSEntry + 1), imm32(0));
         e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSTemp));
         if (base_ + (uint32_t)e_.bytes() != ret) return fail("internal: call sequence length");
-        returns_[index_] = ret;
+        returns_[2 * index_ + 1] = ret;
         indexModeUnknown_ = true;
         ++stats_.called;
         const bool canTaint = slot == AS_MACW || slot == AS_MACWN || slot == AS_MACINTW || slot == AS_LUT || slot == AS_TRAM_IR || slot == AS_TRAM_XR;
-        if (fast_ && canTaint) {
-            // the handler may have met a non-finite value: continue in the exact stream, after the same call there
-            const uint32_t target = (*exactReturns_)[index_];
-            if (target == 0) return fail("internal: fast and exact streams differ in their calls");
-            e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTaint), imm32(0));
-            const int64_t delta = ((int64_t)target - ((int64_t)base_ + (int64_t)e_.bytes() + 4)) / 4;
-            if (delta < -32768 || delta > 32767) return fail("exact stream out of branch range of the fast stream");
-            e_.sopp(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", (uint32_t)delta & 0xffffu, true);
-        }
+        // the handler may have met a non-finite value: continue in the exact stream, after the same call there
+        if (fast_ && canTaint && !leaveIfTainted((*exactReturns_)[2 * index_ + 1])) return false;
         return true;
     }
 
@@ -512,9 +648,14 @@ class Translator {
             ++stats_.inlined;
             return true;
         }
+        if (prog_.uniformCursors && slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
+            ++stats_.inlined;
+            return tram(r, slot);
+        }
         if (slot >= AS_MACS && slot < (uint32_t)kAsmSlots) {
             const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2, ccr = rel & 1u;
             if (!ccr) {
+                if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
                 ++stats_.inlined;
                 switch (family) {
                     case 0: return macs(r, kind, false);
@@ -529,6 +670,7 @@ class Translator {
         if (slot == AS_MOV && !ccrLive) {
             int vR;
             Src a;
+            if (!touch(r, !(r.w[6] & 1u), false, false, true)) return false;
             if (!row(r.w[5], &vR) || !operand(r.w[2], r.w[6] & 1u, &a)) return false;
             plainMode();
             e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), a);
@@ -539,13 +681,15 @@ class Translator {
     }
 
     const XlateTemplate& tmpl_;
+    const XlateProgram prog_;
     uint32_t base_;
     Emitter e_;
     XlateStats stats_;
     std::string err_;
     bool fast_;
     const std::vector<uint32_t>* exactReturns_;
-    std::vector<uint32_t> returns_;  // per record: offset of the return address of its handler call (0 = no call)
+    std::vector<uint32_t> returns_;  // sync points of this stream (see run())
+    std::vector<int> pending_;       // VGPRs with a TRAM read in flight
     size_t index_ = 0;
     bool nonFinite_ = false;
     bool indexModeUnknown_ = false;  // the per-sample frame enters the stream with index mode off
@@ -594,11 +738,11 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
     return &g_templates[variant];
 }
 
-bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, uint32_t codeBase,
+bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, const XlateProgram& prog, uint32_t codeBase,
                      const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code, std::string* listing,
                      XlateStats* stats, std::vector<uint32_t>* returns, std::string* err) {
     code->clear();
-    Translator t(tmpl, codeBase, code, listing, exactReturns);
+    Translator t(tmpl, prog, codeBase, code, listing, exactReturns);
     return t.run(records, stats, returns, err);
 }
 
@@ -606,25 +750,48 @@ namespace {
 inline uint32_t align64(uint32_t v) { return (v + 63u) & ~63u; }
 }
 
+XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize) {
+    XlateProgram p;
+    p.iSize = iSize;
+    p.xSize = xSize;
+    // uniform cursors: no TRAM instruction inside a SKIP shadow (every lane executes every one of them, so all
+    // lanes' cursors move together) and every TRAM offset operand uniform
+    bool any = false, ok = true;
+    for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords}) {
+        bool shadow = false;
+        for (const MicroOp& r : *recs) {
+            const uint32_t slot = r.w[0];
+            if (slot == AS_PRED) shadow = true;
+            else if (slot == AS_UNPRED) shadow = false;
+            else if (slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
+                any = true;
+                if (shadow || !(r.w[6] & 4u)) ok = false;
+            }
+        }
+    }
+    p.uniformCursors = any && ok;
+    return p;
+}
+
 bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
-               XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err) {
+               const XlateProgram& prog, XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err) {
     // hole: [steady fast][steady exact][last fast][last exact], each on a cache line.  The exact stream of a pair
     // is translated first (its call return addresses are the fast stream's escape targets); its position depends
     // on the fast stream's size, which does not depend on the targets - so: size the fast stream with dummy targets.
     const std::vector<MicroOp>* recs[2] = {&steadyRecords, &lastRecords};
     uint32_t at = tmpl.holeOff;
     for (int k = 0; k < 2; ++k) {
-        std::vector<uint32_t> exactRet, scratch, dummy(recs[k]->size(), at);
+        std::vector<uint32_t> exactRet, scratch, dummy(2 * recs[k]->size() + 2, at);
         XlateStats fastStats, exactStats;
         // pass 1: size of the fast stream (targets = its own base: in range, value irrelevant)
-        if (!translateStream(*recs[k], tmpl, at, &dummy, &scratch, nullptr, &fastStats, nullptr, err)) return false;
+        if (!translateStream(*recs[k], tmpl, prog, at, &dummy, &scratch, nullptr, &fastStats, nullptr, err)) return false;
         const uint32_t fastBytes = align64((uint32_t)scratch.size() * 4);
         const bool fastOk = !fastStats.nonFiniteImmediate;
         const uint32_t exactAt = fastOk ? at + fastBytes : at;
-        if (!translateStream(*recs[k], tmpl, exactAt, nullptr, &code[2 * k + 1], listing ? &listing[2 * k + 1] : nullptr, &exactStats, &exactRet, err))
+        if (!translateStream(*recs[k], tmpl, prog, exactAt, nullptr, &code[2 * k + 1], listing ? &listing[2 * k + 1] : nullptr, &exactStats, &exactRet, err))
             return false;
         if (fastOk) {
-            if (!translateStream(*recs[k], tmpl, at, &exactRet, &code[2 * k], listing ? &listing[2 * k] : nullptr, &fastStats, nullptr, err)) return false;
+            if (!translateStream(*recs[k], tmpl, prog, at, &exactRet, &code[2 * k], listing ? &listing[2 * k] : nullptr, &fastStats, nullptr, err)) return false;
             if (align64((uint32_t)code[2 * k].size() * 4) != fastBytes) { if (err) *err = "internal: fast stream changed size"; return false; }
         } else {
             code[2 * k].clear();  // a non-finite uniform operand: every wave runs the exact stream
@@ -643,9 +810,9 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
 }
 
 bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
-                     const XlateTemplate& tmpl, XlateImage* out, std::string* err) {
+                     const XlateTemplate& tmpl, const XlateProgram& prog, XlateImage* out, std::string* err) {
     std::vector<uint32_t> code[4];
-    if (!planXlate(steadyRecords, lastRecords, tmpl, out, code, nullptr, err)) return false;
+    if (!planXlate(steadyRecords, lastRecords, tmpl, prog, out, code, nullptr, err)) return false;
     out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
     const uint32_t offs[4] = {out->steadyFastOff, out->steadyOff, out->lastFastOff, out->lastOff};
     for (int k = 0; k < 4; ++k)

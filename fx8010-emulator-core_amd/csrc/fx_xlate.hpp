@@ -38,6 +38,13 @@ struct XlateTemplate {
 // The template of a VGPR build (ASM_V64 .. ASM_V256); nullptr + err when the image is malformed.
 const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err);
 
+// What the translator needs to know about the program beyond its records.
+struct XlateProgram {
+    int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
+    bool uniformCursors = false;  // all lanes' TRAM cursors move together: kept in SGPRs, TRAM instructions inline
+};
+XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize);
+
 struct XlateStats {
     int inlined = 0;     // records translated to straight-line code
     int called = 0;      // records executed by a call to the interpreter's handler
@@ -55,8 +62,9 @@ struct XlateStats {
 // After each handler call that can taint, the fast stream tests the taint mask and continues in the exact
 // stream at the return address of the same call there (exactReturns[record], produced by the exact translation
 // through `returns`).  A wave thus runs fast code until the first non-finite value shows up, exact code after.
+// The same hand-over follows the wait for in-flight TRAM reads of programs with uniform cursors (inline TRAM code).
 // listing (optional) receives one assembler line per instruction, in llvm-mc syntax.
-bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, uint32_t codeBase,
+bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, const XlateProgram& prog, uint32_t codeBase,
                      const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code, std::string* listing,
                      XlateStats* stats, std::vector<uint32_t>* returns, std::string* err);
 
@@ -72,8 +80,8 @@ struct XlateImage {
 // listing[k] in that order (listing may be nullptr).  Without a fast stream (non-finite uniform operand) the
 // fast offsets equal the exact ones.
 bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
-               XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err);
+               const XlateProgram& prog, XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err);
 bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
-                     const XlateTemplate& tmpl, XlateImage* out, std::string* err);
+                     const XlateTemplate& tmpl, const XlateProgram& prog, XlateImage* out, std::string* err);
 
 }  // namespace fx

@@ -80,11 +80,16 @@ def test_structure_of_translated_code():
                 assert int(m.group(1)) < budget
             for m in re.finditer(r"v\[(\d+):(\d+)\]", listing):
                 assert int(m.group(2)) < 14  # 64-bit temporaries only (v[6:7], v[8:9], v[10:11])
-            # SGPR writes stay inside the record window, the return address and the scratch pair
-            for m in re.finditer(r"^(s_mov_b32|s_add_u32|s_addc_u32) s(\d+),", listing, re.M):
-                assert int(m.group(2)) in (18, 19, 20, 21, 22, 23, 24, 25, 62, 63), (name, m.group(0))
+            # SGPR writes stay inside the record window, the return address, the scratch pair and the TRAM cursor block
+            allowed = set(range(18, 26)) | {62, 63} | set(range(80, 88))
+            for m in re.finditer(r"^(s_[a-z0-9_]+) s(\d+),", listing, re.M):
+                if not m.group(1).startswith(("s_cmp", "s_setpc")):
+                    assert int(m.group(2)) in allowed, (name, m.group(0))
+            # branches inside a stream are the fixed skips of the inline TRAM code
+            for m in re.finditer(r"^(s_branch|s_cbranch_scc0) (\d+)$", listing, re.M):
+                assert int(m.group(2)) in (1, 2, 6), (name, m.group(0))
             if stream in (1, 3):
-                assert "s_cbranch" not in listing  # only the fast streams branch (to the exact ones)
+                assert "s_cbranch_scc1" not in listing  # only the fast streams leave (for the exact ones)
             # a call's return address is the instruction after its s_setpc_b64
             words = np.frombuffer(code, dtype=np.uint32)
             assert words[-1] == 0xBE801D22  # s_setpc_b64 s[34:35]
