@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5"])
-    ap.add_argument("--samples", type=int, default=256, help="sample periods per step (block length S)")
+    ap.add_argument("--samples", type=int, default=4096, help="sample periods per step (block length S; SURVEY 8d: 4096)")
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (0 = BASELINE.json's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only); 0 disables")
     ap.add_argument("--extra-configs", action="store_true", help="also report untimed single-launch MIPS of the other configs")
@@ -44,19 +44,23 @@ def parse():
 
 
 def device_stimulus(torch, n_inst, n_samples, first_instance, device):
-    """fx8010_programs.stimulus() on the device (same counter-based hash, same bits)."""
+    """fx8010_programs.stimulus() on the device (same counter-based hash, same bits), built in slabs of 256
+    sample periods so that the int64 temporaries stay small next to the [S, N] fp32 result."""
     M = 0xFFFFFFFF
-    n = (torch.arange(n_inst, dtype=torch.int64, device=device) + first_instance)[None, :]
-    s = torch.arange(n_samples, dtype=torch.int64, device=device)[:, None]
-    x = (n * 0x9E3779B1 + s * 0x85EBCA77 + 0xF8010) & M
-    x = x ^ (x >> 16)
-    x = (x * 0x85EBCA6B) & M
-    x = x ^ (x >> 13)
-    x = (x * 0xC2B2AE35) & M
-    x = x ^ (x >> 16)
-    i32 = torch.where(x >= 2 ** 31, x - 2 ** 32, x)
-    f = i32.to(torch.float32) * (2.0 ** -31)
-    return (f * 0.9).contiguous()
+    out = torch.empty((n_samples, n_inst), dtype=torch.float32, device=device)
+    n = (torch.arange(n_inst, dtype=torch.int64, device=device) + first_instance)[None, :] * 0x9E3779B1 + 0xF8010
+    for s0 in range(0, n_samples, 256):
+        s1 = min(n_samples, s0 + 256)
+        s = torch.arange(s0, s1, dtype=torch.int64, device=device)[:, None]
+        x = (n + s * 0x85EBCA77) & M
+        x = x ^ (x >> 16)
+        x = (x * 0x85EBCA6B) & M
+        x = x ^ (x >> 13)
+        x = (x * 0xC2B2AE35) & M
+        x = x ^ (x >> 16)
+        i32 = torch.where(x >= 2 ** 31, x - 2 ** 32, x)
+        out[s0:s1] = i32.to(torch.float32) * (2.0 ** -31) * 0.9
+    return out
 
 
 def usable_cores():

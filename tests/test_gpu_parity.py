@@ -282,6 +282,20 @@ def test_delay_line_exact(gpu, k):
     check_batch(gpu, text, x, regs=("rd", "b", "a"))
 
 
+def test_delay_inside_skip_shadow(gpu, k):
+    """A TRAM instruction a lane skips does not advance that lane's cursor (FX8010.cpp:1037: skipped instructions
+    are not executed), so cursors differ from lane to lane: the translator must not keep them in SGPRs here."""
+    text = ("itramsize 7 \nxtramsize 11 \n" + HDR + "static t\n"
+            "idelay read, rd, at, 0\nxdelay read, b, at, 0\n"
+            "macs t, in, 0, 0\nskip ccr, ccr, 6, 2\n"
+            "idelay write, in, at, 0\nxdelay write, rd, at, 0\n"
+            "macs out, rd, b, 0.5\nend")
+    x = progs.stimulus(130, 200)
+    b, _ = check_batch(gpu, text, x, regs=("rd", "b", "t", "ccr"))
+    if k == "default":
+        assert b.info("xlate_called") >= 4  # the four TRAM instructions run in the interpreter's per-lane handlers
+
+
 def test_delay_write_offset_and_ood(gpu, k):
     # write offset 3 stays inside the reference's array (wpos+3 < 8192) and lands beyond `size`
     text = "itramsize 8 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 3\nmacs out, 0, rd, 1.0\nend"
