@@ -12,6 +12,7 @@
 #include "fx_batch.hpp"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 
@@ -259,7 +260,13 @@ int Batch::ensureLowered() {
 
     // upload: steady | last | row table
     useXlate_ = false;
-    if (useAsm_ && asmVariant_ != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
+    xlateDeferred_ = false;
+    if (useAsm_ && asmVariant_ != ASM_LDS && controlHeat_ > 0 && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0)) {
+        // controls are moving (a set_register within the last few blocks): a translation costs a module load
+        // (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until the controls have been quiet
+        xlateDeferred_ = true;
+        xlateWhyNot_ = "deferred: control registers are changing";
+    } else if (useAsm_ && asmVariant_ != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
         // first choice for a VGPR build: translate the program into gfx950 code (FX_KERNEL=asm* pins the interpreter)
         const XlateTemplate* tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
         XlateImage image;
@@ -321,6 +328,7 @@ int Batch::setRegister(const std::string& key, float v) {
     const bool resident = laneResident(r);
     forcedLane_[r] = 0;  // every instance holds the same value again
     lowDirty_ = true;    // immediates (and possibly the classification) change
+    if (loaded_ && everLowered_) controlHeat_ = kHeatPerChange;
     if (resident && dState_) {
         if (lastStream_) (void)hipStreamSynchronize(lastStream_);
         int rc = fillRows({(uint32_t)r}, {bitsOf(v)});
@@ -371,8 +379,10 @@ int Batch::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
 int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
     (void)hipSetDevice(device_);
     if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
+    if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;  // quiet again: translate
     int rc = ensureLowered();
     if (rc != 0) return rc;
+    everLowered_ = true;
     if (nSamples == 0) return 0;
     if (!dIn || !dOut) return fail(FX_E_ARG, "null buffer");
     hipStream_t s = pick(stream);

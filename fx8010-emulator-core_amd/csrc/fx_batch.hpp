@@ -91,6 +91,10 @@ private:
     uint32_t xlateCodeBytes_ = 0;
     int xlateInlined_ = 0, xlateCalled_ = 0;
     std::string xlateWhyNot_;
+    // control changes re-lower; while they keep coming the interpreter tier is used (see ensureLowered)
+    static constexpr int kHeatPerChange = 8;  // blocks a change keeps the translation deferred
+    int controlHeat_ = 0;
+    bool xlateDeferred_ = false, everLowered_ = false;
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;
     size_t streamCap_ = 0;

@@ -353,6 +353,36 @@ def test_set_register_broadcast_and_per_instance(gpu, k):
     assert b.get_register_i("nonexistent", 0) == 1.0
 
 
+def test_control_changes_defer_the_translation(gpu, monkeypatch):
+    """A control change re-lowers the program.  Translating costs a module load, so while changes keep coming the
+    interpreter runs the blocks; once the controls have been quiet for a few blocks the program is translated
+    again.  Results are the reference's throughout (the main.cpp slider schedule: a change every 8 samples)."""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    text = HDR + "macs a, a, vol, in\ninterp b, b, vol, a\nmacs out, b, a, 0.5\nend"
+    N = 70
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    o = Oracle(1)
+    assert o.load_text(text)
+    x = progs.stimulus(N, 8 * 40)
+    tiers = []
+    for blk in range(40):
+        if 3 <= blk < 12:
+            v = 0.1 + 0.05 * blk
+            b.set_register("vol", v)
+            o.set_register("vol", v)
+        xs = x[8 * blk:8 * blk + 8]
+        y = b.process_block(xs)
+        ref = o.process_block(xs[:, 5].copy())
+        assert np.array_equal(bits(ref), bits(y[:, 5])), "block %d" % blk
+        tiers.append(b.info("kernel"))
+    assert tiers[0] >= 9 and tiers[2] >= 9          # translated before the first change
+    assert all(2 <= t <= 8 for t in tiers[3:12])    # interpreter while the slider moves
+    assert tiers[-1] >= 9                           # translated again after the quiet period
+    assert b.instruction_counter_i(5) == o.instruction_counter()
+
+
 def test_noise_seed_per_instance(gpu, k):
     text = HDR + "macs out, 0, noise, 1.0\nend"
     N, S = 66, 40
