@@ -271,7 +271,7 @@ int Batch::ensureLowered() {
         const XlateTemplate* tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
         XlateImage image;
         const std::vector<MicroOp> steadyRecords = encodeAsmStream(low_.steady, nullptr, true), lastRecords = encodeAsmStream(low_.last, nullptr, true);
-        if (tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize),
+        if (tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow),
                                     &image, &xlateWhyNot_)) {
             if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still run the old code
             if (xlateModule_) (void)hipModuleUnload(xlateModule_);
@@ -283,6 +283,8 @@ int Batch::ensureLowered() {
             xlateSteady_ = (uint64_t)image.steadyFastOff | ((uint64_t)image.steadyOff << 32);
             xlateLast_ = (uint64_t)image.lastFastOff | ((uint64_t)image.lastOff << 32);
             xlateCodeBytes_ = image.codeBytes;
+            xlateWildRow_ = image.wildRow;
+            xlateUnsaturated_ = image.steady.unsaturated;
             xlateInlined_ = image.steady.inlined;
             xlateCalled_ = image.steady.called;
             useXlate_ = true;
@@ -310,7 +312,11 @@ int Batch::ensureLowered() {
     std::memcpy(host.data(), low_.steady.data(), nOps * 32);
     std::memcpy(host.data() + nOps * 8, low_.last.data(), nOps * 32);
     size_t p = nOps * 16;
-    for (const RowCopy& rcp : low_.loadRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+    for (const RowCopy& rcp : low_.loadRows) {
+        // translated programs: bit 15 marks a row of the BOUNDED class (its state value is checked against 1.0)
+        const bool bounded = useXlate_ && rcp.ldsRow < xlateWildRow_.size() && !xlateWildRow_[rcp.ldsRow];
+        host[p++] = rcp.ldsRow | (bounded ? 0x8000u : 0u) | ((uint32_t)rcp.stateRow << 16);
+    }
     for (const RowCopy& rcp : low_.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
     for (int zr : low_.zeroRows) host[p++] = (uint32_t)zr;
     if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still read the old stream
@@ -558,6 +564,7 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_CODE_BYTES: return useXlate_ ? (int64_t)xlateCodeBytes_ : 0;
         case FXB_INFO_XLATE_INLINED: return useXlate_ ? xlateInlined_ : 0;
         case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;
+        case FXB_INFO_XLATE_UNSATURATED: return useXlate_ ? xlateUnsaturated_ : 0;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
         case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? 0 : (int64_t)low_.nRows * 256 * instPerLane_;

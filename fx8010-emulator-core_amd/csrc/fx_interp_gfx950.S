@@ -216,7 +216,13 @@ KNAME:
 	s_load_dword s64, s[72:73], s63                       // ldsRow | stateRow << 16
 	s_waitcnt lgkmcnt(0)
 	s_lshr_b32 s65, s64, 16
+#ifdef XLATE
+	s_bitcmp1_b32 s64, 15                                 // row of the BOUNDED class (fx_xlate.hpp)
+	s_cselect_b32 s69, 1, 0
+	s_and_b32 s64, s64, 0x7fff
+#else
 	s_and_b32 s64, s64, 0xffff
+#endif
 	s_mul_i32 s66, s65, s60
 	s_mul_hi_u32 s67, s65, s60
 	s_add_u32 s66, s66, s10
@@ -227,7 +233,12 @@ KNAME:
 #endif
 	s_waitcnt vmcnt(0)
 #ifdef XLATE
+	// taint: a BOUNDED row must start inside [-1, 1] (NaN fails too), any other row must start finite
 	v_cmp_class_f32 vcc, v2, v29
+	s_cmp_eq_u32 s69, 0
+	s_cbranch_scc1 .Lrow_checked
+	v_cmp_nle_f32_e64 vcc, |v2|, 1.0
+.Lrow_checked:
 	s_or_b64 s[78:79], s[78:79], vcc
 #endif
 	STOREV s64, v2

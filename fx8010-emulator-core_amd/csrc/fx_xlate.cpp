@@ -3,6 +3,8 @@
 
 #include <elf.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -186,6 +188,13 @@ class Emitter {
         if (s2) t += std::string(", ") + ((neg & 4) ? "-" : "") + s2->text;
         line(t);
     }
+    // VOPC in its VOP3 form, result to VCC, |src0| when abs0
+    void vop3cmp(uint32_t op, const char* name, const Src& s0, bool abs0, const Src& s1) {
+        w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | 106u);
+        w_.push_back(s0.code | (s1.code << 9));
+        ++count_;
+        line(std::string(name) + " vcc, " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
+    }
     void sop1(uint32_t op, const char* name, const Src& sdst, const Src& ssrc) {
         put(0xbe800000u | ((sdst.code & 0x7fu) << 16) | (op << 8) | ssrc.code, ssrc);
         line(std::string(name) + " " + sdst.text + ", " + ssrc.text);
@@ -247,7 +256,7 @@ enum : uint32_t {
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
-    VOP1_READFIRSTLANE = 2, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
+    VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
@@ -331,7 +340,9 @@ class Translator {
         if (fast_) {
             plainMode();
             for (int v : pending_) {
-                e_.vopc(VOPC_CMP_CLASS_F32, "v_cmp_class_f32_e32", vreg(v), kVClassMask);
+                // a row of the bounded class must stay inside [-1, 1] (NaN fails the test as well); any other finite
+                if (isBoundedVgpr(v)) e_.vop3cmp(VOP3_CMP_NLE_F32, "v_cmp_nle_f32_e64", vreg(v), true, imm32(0x3f800000u));
+                else e_.vopc(VOPC_CMP_CLASS_F32, "v_cmp_class_f32_e32", vreg(v), kVClassMask);
                 e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
             }
             if (!leaveIfTainted((*exactReturns_)[2 * index_])) return false;
@@ -433,6 +444,46 @@ class Translator {
         return true;
     }
 
+    bool isBoundedVgpr(int v) const {
+        const int r = v - kRegFileBase;
+        return r >= 0 && r < (int)prog_.wildRow.size() && !prog_.wildRow[r];
+    }
+    // upper bound of |operand| that the fast stream may rely on: |c| of a uniform, 1 for a row of the bounded
+    // class (the taint checks keep that invariant), +inf for any other row
+    double bound(uint32_t word, bool uniform) const {
+        if (uniform) {
+            float f;
+            std::memcpy(&f, &word, 4);
+            return f == f ? std::fabs((double)f) : HUGE_VAL;
+        }
+        return (word < prog_.wildRow.size() && !prog_.wildRow[word]) ? 1.0 : HUGE_VAL;
+    }
+    // Can the saturation of this instruction's result be dropped in the fast stream?  Every rounding step is
+    // monotone and the bounds are floats, so |exact bound| <= 1 carries through the fp32 (fp64 for INTERP) roundings.
+    bool resultWithinUnit(uint32_t family, uint32_t kind, const MicroOp& r) const {
+        if (!fast_ || kind == 7) return false;
+        const bool uA = kind & 1, uX = kind & 2, uY = kind & 4;
+        if (family <= 1) {  // A +- X*Y: a folded product sits in the X word
+            const double bp = (uX && uY) ? bound(r.w[3], true) : bound(r.w[3], uX) * bound(r.w[4], uY);
+            return bound(r.w[2], uA) + bp <= 1.0;
+        }
+        if (family == 2) {  // (A + X) + Y: a folded A + X sits in the A word
+            const double bs = (uA && uX) ? bound(r.w[2], true) : bound(r.w[2], uA) + bound(r.w[3], uX);
+            return bs + bound(r.w[4], uY) <= 1.0;
+        }
+        // INTERP: a convex combination of A and Y when X is a constant in [2^-20, 1]
+        if (!uX) return false;
+        double omx;
+        const uint64_t bitsOmx = (uint64_t)r.w[6] | ((uint64_t)r.w[7] << 32);
+        std::memcpy(&omx, &bitsOmx, 8);
+        if (!(omx >= 0.0 && omx <= 1.0 - 9.5367431640625e-07)) return false;
+        if (bound(r.w[2], uA) > 1.0) return false;
+        if (uY) {  // folded product X*Y in the X word: |p| <= X = 1 - omx must hold
+            return bound(r.w[3], true) <= 1.0 - omx;
+        }
+        return bound(r.w[4], false) <= 1.0;
+    }
+
     // a uniform operand's bit pattern; a NaN or Inf among them rules the fast stream out
     Src value(uint32_t bits) {
         if ((bits & 0x7f800000u) == 0x7f800000u) nonFinite_ = true;
@@ -490,16 +541,19 @@ class Translator {
         }
         bool inV3;
         if (!product(r, kind, &inV3)) return false;
+        const bool within = resultWithinUnit(neg ? 1 : 0, kind, r);  // then the sum goes straight to its row
+        const int d = within ? vR : 2;
         if (inV3) {
             Src a;
             if (!operand(r.w[2], kind & 1, &a)) return false;
-            e_.vop2(neg ? VOP2_SUB_F32 : VOP2_ADD_F32, neg ? "v_sub_f32_e32" : "v_add_f32_e32", 2, a, 3);
+            e_.vop2(neg ? VOP2_SUB_F32 : VOP2_ADD_F32, neg ? "v_sub_f32_e32" : "v_add_f32_e32", d, a, 3);
         } else {
             int vA;
             if (!row(r.w[2], &vA)) return false;
-            e_.vop2(neg ? VOP2_SUBREV_F32 : VOP2_ADD_F32, neg ? "v_subrev_f32_e32" : "v_add_f32_e32", 2, value(r.w[3]), vA);
+            e_.vop2(neg ? VOP2_SUBREV_F32 : VOP2_ADD_F32, neg ? "v_subrev_f32_e32" : "v_add_f32_e32", d, value(r.w[3]), vA);
         }
-        satStore(vR);
+        if (within) ++stats_.unsaturated;
+        else satStore(vR);
         return true;
     }
 
@@ -512,10 +566,12 @@ class Translator {
             return true;
         }
         const bool uA = kind & 1, uX = kind & 2, uY = kind & 4;
+        const bool within = resultWithinUnit(2, kind, r);
+        const int d = within ? vR : 2;
         if (uA && uX) {  // t = A + X folded into the A word
             int vY;
             if (!row(r.w[4], &vY)) return false;
-            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, value(r.w[2]), vY);
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", d, value(r.w[2]), vY);
         } else {
             Src a;
             int b;
@@ -531,9 +587,10 @@ class Translator {
             e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, a, b);
             Src y;
             if (!operand(r.w[4], uY, &y)) return false;
-            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, y, 2);
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", d, y, 2);
         }
-        satStore(vR);
+        if (within) ++stats_.unsaturated;
+        else satStore(vR);
         return true;
     }
 
@@ -548,6 +605,9 @@ class Translator {
         }
         bool inV3;
         if (!product(r, kind, &inV3)) return false;
+        const bool within = resultWithinUnit(3, kind, r);
+        const int d = within ? vR : 2;
+        if (within) ++stats_.unsaturated;
         Src a;
         if (!operand(r.w[2], kind & 1, &a)) return false;
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), a);
@@ -566,8 +626,8 @@ class Translator {
                 e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(10), inV3 ? vreg(3) : value(r.w[3]));
                 Src addend = vreg64(10);
                 e_.vop3(VOP3_FMA_F64, "v_fma_f64", vreg64(6), m, vreg64(8), &addend);
-                e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(2), vreg64(6));
-                satStore(vR);
+                e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(d), vreg64(6));
+                if (!within) satStore(vR);
                 return true;
             }
             e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), m, vreg64(8), nullptr);
@@ -580,8 +640,8 @@ class Translator {
         }
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), inV3 ? vreg(3) : value(r.w[3]));
         e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
-        e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(2), vreg64(6));
-        satStore(vR);
+        e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(d), vreg64(6));
+        if (!within) satStore(vR);
         return true;
     }
 
@@ -750,7 +810,8 @@ namespace {
 inline uint32_t align64(uint32_t v) { return (v + 63u) & ~63u; }
 }
 
-XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize) {
+XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
+                            int nRows, const std::vector<int>& inputRows) {
     XlateProgram p;
     p.iSize = iSize;
     p.xSize = xSize;
@@ -770,6 +831,50 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
         }
     }
     p.uniformCursors = any && ok;
+
+    // Row classes.  BOUNDED: every value the row can hold lies in [-1, 1] - its writers saturate, or pass a bounded
+    // value on - given that it started there (the template checks the state rows of this class, and inline TRAM
+    // reads into them, against 1.0).  WILD: anything else: CCR, PCM input rows, results of the wrap-around and
+    // integer instructions, of a per-lane TRAM handler, or copies of wild values.  Optimistic fixpoint.
+    p.wildRow.assign((size_t)std::max(nRows, 1), 0);
+    auto wild = [&](uint32_t row) { return row >= p.wildRow.size() || p.wildRow[row] != 0; };
+    auto big = [](uint32_t bits) {
+        float f;
+        std::memcpy(&f, &bits, 4);
+        return !(std::fabs(f) <= 1.0f);
+    };
+    auto operandWild = [&](uint32_t word, bool uniform) { return uniform ? big(word) : wild(word); };
+    p.wildRow[0] = 1;  // CCR holds 0, 2, 6, 8, 16, 20
+    for (int r : inputRows)
+        if (r >= 0 && (size_t)r < p.wildRow.size()) p.wildRow[(size_t)r] = 1;
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords}) {
+            for (const MicroOp& r : *recs) {
+                const uint32_t slot = r.w[0], dst = r.w[5];
+                const bool uA = r.w[6] & 1u, uX = r.w[6] & 2u, uY = r.w[6] & 4u;
+                bool makesWild = false;
+                switch (slot) {
+                    case AS_MOV: makesWild = operandWild(r.w[2], uA); break;
+                    case AS_LIMIT:
+                    case AS_LIMITN: makesWild = operandWild(r.w[3], uX) || operandWild(r.w[4], uY); break;
+                    case AS_TSTNEG: makesWild = operandWild(r.w[3], uX); break;  // X or (~X scaled back): inside [-1, 1] when X is
+                    case AS_LUT: makesWild = operandWild(r.w[2], uA); break;     // tables map [-1, 1] into [-1, 1]
+                    case AS_MACW:
+                    case AS_MACWN:
+                    case AS_MACINTW:
+                    case AS_ANDXOR: makesWild = true; break;
+                    case AS_TRAM_IR:
+                    case AS_TRAM_XR: makesWild = !p.uniformCursors; break;  // the inline read is checked, the handler's is not
+                    default: continue;  // saturating families, NOISE (|n| <= 1), instructions without a result
+                }
+                if (makesWild && dst < p.wildRow.size() && !p.wildRow[dst]) {
+                    p.wildRow[dst] = 1;
+                    changed = true;
+                }
+            }
+        }
+    }
     return p;
 }
 
@@ -801,6 +906,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
         (k == 0 ? out->steady : out->last) = fastOk ? fastStats : exactStats;
         at = exactAt + align64((uint32_t)code[2 * k + 1].size() * 4);
     }
+    out->wildRow = prog.wildRow;
     out->codeBytes = at - tmpl.holeOff;
     if (out->codeBytes + 4 > tmpl.holeBytes) {
         if (err) *err = "translated program larger than the code hole of the template";

@@ -42,13 +42,17 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err);
 struct XlateProgram {
     int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
     bool uniformCursors = false;  // all lanes' TRAM cursors move together: kept in SGPRs, TRAM instructions inline
+    std::vector<uint8_t> wildRow; // per register-file row: 0 = BOUNDED class (always inside [-1, 1]), 1 = WILD
 };
-XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize);
+// nRows = rows of the register file, inputRows = the rows the frame writes the PCM input to (-1: unused channel)
+XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
+                            int nRows, const std::vector<int>& inputRows);
 
 struct XlateStats {
     int inlined = 0;     // records translated to straight-line code
     int called = 0;      // records executed by a call to the interpreter's handler
     int instructions = 0;
+    int unsaturated = 0; // saturating instructions whose result provably lies in [-1, 1]: no v_med3 in the fast stream
     bool nonFiniteImmediate = false;  // a NaN / Inf among the uniform operands: no fast stream for this program
 };
 
@@ -75,6 +79,7 @@ struct XlateImage {
     uint32_t steadyFastOff = 0, steadyOff = 0, lastFastOff = 0, lastOff = 0;
     uint32_t codeBytes = 0;
     XlateStats steady, last;  // of the stream a finite wave runs
+    std::vector<uint8_t> wildRow;  // row classes the code relies on: the loader flags BOUNDED rows in the row table
 };
 // Lays the four streams out ([steady fast][steady exact][last fast][last exact]) and translates them; code[k] /
 // listing[k] in that order (listing may be nullptr).  Without a fast stream (non-finite uniform operand) the

@@ -274,6 +274,46 @@ def test_non_finite_values_follow_the_reference(gpu, k, case):
         assert saw_nan  # the case does exercise NaN through saturating instructions
 
 
+def test_saturation_elision_is_sound(gpu, k):
+    """The translator drops the saturation of an instruction whose result provably lies in [-1, 1] given that its
+    row operands do (rows written only by saturating instructions, checked against 1.0 where they enter: state,
+    inline TRAM reads).  Values beyond 1 arriving through every such entrance must put the saturation back."""
+    text = ("itramsize 9 \n" + HDR + "static t\nstatic u\nstatic w\n"
+            "idelay read, rd, at, 0\n"
+            "macs t, 0, rd, 0.5\n"          # rd: bounded class through the checked inline read
+            "macs u, 0, a, vol\n"            # a: bounded class (only saturating writers), state may be set beyond 1
+            "interp w, u, 0.25, t\n"
+            "interp b, in, 0.25, w\n"        # in: wild, keeps its saturation
+            "macs a, a, 0.5, in\n"
+            "idelay write, in, at, 0\n"
+            "macs out, 0, w, 1.0\n"
+            "acc3 t, t, u, b\n"
+            "end")
+    N, S = 130, 64
+    x = progs.stimulus(N, S).copy()
+    x[3, 7] = 3.0          # through the delay line into rd nine samples later
+    x[20, 64] = -2.5
+    x[30:34, 100] = 1.5
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    b.set_register_i("a", 12, 5.0)     # a bounded-class row starting outside [-1, 1]
+    b.set_register_i("w", 70, -3.0)
+    y = b.process_block(x)
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(text)
+        if n == 12:
+            o.set_register("a", 5.0)
+        if n == 70:
+            o.set_register("w", -3.0)
+        ref = o.process_block(x[:, n].copy())
+        assert np.array_equal(bits(ref), bits(y[:, n])), "instance %d" % n
+        for r in ("a", "b", "t", "u", "w", "rd", "out"):
+            assert b.get_register_bits_i(r, n) == o.get_register_bits(r), "instance %d register %s" % (n, r)
+    if k == "default":
+        assert b.info("xlate_unsaturated") >= 3
+
+
 def test_delay_line_exact(gpu, k):
     text = "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend"
     x = progs.stimulus(66, 64)
