@@ -344,6 +344,20 @@ LutDevice::LutDevice(const Luts& l) : blob(kLutBlobDoubles, 0.0), invStep(63.0 /
             blob[kLutSegOff + (tsel * 64 + k) * 2 + 1] = y1;
         }
     }
+    // fp32 thresholds: smallest float x whose t = (double)x - -1.0 reaches the bound
+    auto firstFloatReaching = [](double bound) {
+        float x = (float)(bound - 1.0);
+        while ((double)x - -1.0 >= bound) x = std::nextafterf(x, -4.0f);
+        while ((double)x - -1.0 < bound) x = std::nextafterf(x, 4.0f);
+        return x;
+    };
+    float* xthr = reinterpret_cast<float*>(&blob[kLutXthrOff]);
+    xthr[0] = -HUGE_VALF;
+    for (int k = 1; k <= 63; ++k) xthr[k] = firstFloatReaching(blob[kLutThrOff + k]);
+    xthr[64] = xthr[65] = HUGE_VALF;
+    float* xdom = reinterpret_cast<float*>(&blob[kLutXdomOff]);
+    xdom[0] = firstFloatReaching(-step);
+    xdom[1] = firstFloatReaching(64.0 * step);
 }
 
 }  // namespace fx

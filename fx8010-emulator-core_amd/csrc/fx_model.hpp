@@ -93,11 +93,17 @@ struct Luts {
 //   thr[k]   k = 0..64 : smallest double t with (int)(t / step) >= k   (thr[0] = 0, thr[64] = +inf)
 //   x1[k]    k = 0..63 : -1.0 + k*step
 //   seg[table][k]      : { (y2 - y1) / (x2 - x1), y1 }   table 0..31 LOG, 32..63 EXP
-// Blob layout (doubles): thr[65] | pad to 66 | x1[64] | seg[64][64][2]   => kLutBlobDoubles.
+// The translated programs (fx_xlate.cpp) find idx from the fp32 operand itself: t = (double)x + 1.0 is monotone in
+// x, so there are fp32 thresholds with the same meaning,
+//   xthr[k]  k = 0..65 : smallest float x with (double)x + 1.0 >= thr[k]   (xthr[0] = -inf, xthr[64..65] = +inf)
+//   xdom[2]            : smallest floats x with t >= -step and with t >= 64*step (outside: index out of range, flagged)
+// Blob layout (doubles): thr[65] | pad to 66 | x1[64] | seg[64][64][2] | xthr[66] as floats | xdom[2] as floats
 constexpr int kLutThrOff = 0;
 constexpr int kLutX1Off = 66;
 constexpr int kLutSegOff = 66 + 64;
-constexpr int kLutBlobDoubles = kLutSegOff + 64 * 64 * 2;
+constexpr int kLutXthrOff = kLutSegOff + 64 * 64 * 2;  // 66 floats = 33 doubles
+constexpr int kLutXdomOff = kLutXthrOff + 33;          // 2 floats = 1 double
+constexpr int kLutBlobDoubles = kLutXdomOff + 1;
 struct LutDevice {
     std::vector<double> blob;
     double invStep;  // 63/2: only used to guess idx, the thresholds decide

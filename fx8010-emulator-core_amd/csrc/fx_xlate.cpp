@@ -223,6 +223,21 @@ class Emitter {
         ++count_;
         line("s_waitcnt vmcnt(0)");
     }
+    // global_load_dwordx2 / x4 into v[vdata ..], VGPR byte offset, SGPR base pair
+    void globalLoadWide(uint32_t op, int dwords, int vdata, int vaddr, int sbase) {
+        w_.push_back(0xdc008000u | (op << 18));
+        w_.push_back((uint32_t)vaddr | ((uint32_t)sbase << 16) | ((uint32_t)vdata << 24));
+        ++count_;
+        line("global_load_dwordx" + std::to_string(dwords) + " v[" + std::to_string(vdata) + ":" + std::to_string(vdata + dwords - 1) + "], v" +
+             std::to_string(vaddr) + ", s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]");
+    }
+    // VOPC in its VOP3 form with an SGPR-pair destination
+    void vop3cmpTo(uint32_t op, const char* name, int sdst, const Src& s0, const Src& s1) {
+        w_.push_back(0xd0000000u | (op << 16) | (uint32_t)sdst);
+        w_.push_back(s0.code | (s1.code << 9));
+        ++count_;
+        line(std::string(name) + " s[" + std::to_string(sdst) + ":" + std::to_string(sdst + 1) + "], " + s0.text + ", " + s1.text);
+    }
     void sopc(uint32_t op, const char* name, const Src& s0, const Src& s1) {
         w_.push_back(0xbf000000u | (op << 16) | (s1.code << 8) | s0.code);
         ++count_;
@@ -256,7 +271,9 @@ enum : uint32_t {
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
-    VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
+    VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
+    VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49,
+    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
@@ -278,6 +295,8 @@ constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane
 constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read
 constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
 constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
+constexpr int kSLut = 40;          // s[40:41] = LUT blob
+constexpr int kSLutXthr = 88, kSLutX1 = 90, kSLutSeg = 92;  // s[88:93]: bases of the fp32 thresholds, x1[] and the current table's segments
 constexpr int kSTramBase[2] = {36, 38}, kSTramSize[2] = {56, 57}, kSTramSlots[2] = {46, 47};  // [iTRAM, xTRAM]
 
 class Translator {
@@ -298,6 +317,14 @@ class Translator {
             // every TRAM instruction runs on all lanes: the four cursors are the same in every lane, keep them in SGPRs
             for (int c = 0; c < 4; ++c) e_.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSCursor + c), vreg(kVCursor + c));
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
+        }
+        bool anyLut = false;
+        for (const MicroOp& r : records) anyLut = anyLut || r.w[0] == AS_LUT;
+        if (anyLut) {
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutXthr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutXthr + 1), sreg(kSLut + 1), imm32(0));
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutX1), sreg(kSLut), imm32((uint32_t)kLutX1Off * 8, true));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutX1 + 1), sreg(kSLut + 1), imm32(0));
         }
         for (size_t i = 0; i < records.size(); ++i) {
             const MicroOp& r = records[i];
@@ -375,6 +402,72 @@ class Translator {
         std::memcpy(&f, &bits, 4);
         if (!(f > -2147483904.0f && f < 2147483648.0f)) return INT32_MIN;
         return (int32_t)f;
+    }
+
+    // LOG / EXP with a per-lane operand and a uniform table (FX8010.cpp:1113-1125, linearInterpolate :283-296), from
+    // the host tables of fx_model.hpp: idx is found from the fp32 operand itself (guess (x+1)*31.5, corrected
+    // against the two neighbouring fp32 thresholds), then y = slope * ((double)x - x1) + y1, two roundings as the
+    // reference's.  Bit-identical to the interpreter's h_lut (dense sweep in tests/test_gpu_parity.py).
+    bool lut(const MicroOp& r) {
+        int vA, vR;
+        if (!touch(r, true, false, false, true) || !row(r.w[2], &vA) || !row(r.w[5], &vR)) return false;
+        plainMode();
+        const bool operandWild = r.w[2] >= prog_.wildRow.size() || prog_.wildRow[r.w[2]];
+        if (!segKnown_ || segOff_ != r.w[3]) {
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutSeg), sreg(kSLut), imm32(r.w[3], true));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutSeg + 1), sreg(kSLut + 1), imm32(0));
+            segKnown_ = true;
+            segOff_ = r.w[3];
+        }
+        e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x3f800000u), vA);
+        e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 6, imm32(0x41fc0000u), 6);                  // * 31.5
+        e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
+        Src zero = imm32(0), top = imm32(63);
+        e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
+        e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
+        e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSLutXthr);                        // xthr[g], xthr[g+1]
+        e_.waitVmcnt0();
+        e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // x >= xthr[g+1]: one up
+        e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));      // x <  xthr[g]  : one down
+        // (two instructions between a VALU write of VCC / an SGPR pair and the VALU read of it)
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
+        Src one = imm32(1), vcc = named(106, "vcc"), tmp = sreg64(kSTemp);
+        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(10), zero, one, &vcc);
+        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(11), zero, one, &tmp);
+        e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 6, vreg(6), 10);
+        e_.vop2(VOP2_SUB_U32, "v_sub_u32_e32", 6, vreg(6), 11);
+        e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
+        e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+        e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                         // x1[idx]
+        e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
+        e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                         // slope, y1
+        if (operandWild) {
+            // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutXdomOff * 8, true));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
+            e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSAddr);
+        }
+        e_.waitVmcnt0();
+        if (operandWild) {
+            e_.vopc(VOPC_CMP_NGE_F32, "v_cmp_nge_f32_e32", vreg(vA), 8);
+            e_.vop3cmpTo(VOP3_CMP_NLT_F32, "v_cmp_nlt_f32_e64", kSTemp, vreg(vA), vreg(9));
+            e_.sop2(SOP2_OR_B64, "s_or_b64", named(106, "vcc"), named(106, "vcc"), sreg64(kSTemp));
+            Src flag = imm32(16);
+            e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(7), zero, flag, &vcc);
+            e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, vreg(kVOod), 7);
+        }
+        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
+        e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(12), vreg64(2), vreg64(12), nullptr);
+        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(4), nullptr);
+        e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
+        returns_[2 * index_ + 1] = base_ + (uint32_t)e_.bytes();
+        if (operandWild && fast_) {  // a wild operand can be Inf / NaN, and then so is the result
+            e_.vopc(VOPC_CMP_CLASS_F32, "v_cmp_class_f32_e32", vreg(vR), kVClassMask);
+            e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
+            if (!leaveIfTainted((*exactReturns_)[2 * index_ + 1])) return false;
+        }
+        return true;
     }
 
     // IDELAY / XDELAY with uniform cursors (fx_interp_handlers.inc TRAM_READ / TRAM_WRITE are the per-lane versions;
@@ -708,6 +801,10 @@ class Translator {
             ++stats_.inlined;
             return true;
         }
+        if (slot == AS_LUT && !ccrLive && !(r.w[6] & 1u)) {
+            ++stats_.inlined;
+            return lut(r);
+        }
         if (prog_.uniformCursors && slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
             ++stats_.inlined;
             return tram(r, slot);
@@ -750,6 +847,8 @@ class Translator {
     const std::vector<uint32_t>* exactReturns_;
     std::vector<uint32_t> returns_;  // sync points of this stream (see run())
     std::vector<int> pending_;       // VGPRs with a TRAM read in flight
+    bool segKnown_ = false;          // s[92:93] holds the segment base of table offset segOff_
+    uint32_t segOff_ = 0;
     size_t index_ = 0;
     bool nonFinite_ = false;
     bool indexModeUnknown_ = false;  // the per-sample frame enters the stream with index mode off

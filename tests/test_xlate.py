@@ -79,9 +79,9 @@ def test_structure_of_translated_code():
             for m in re.finditer(r"\bv(\d+)\b", listing):
                 assert int(m.group(1)) < budget
             for m in re.finditer(r"v\[(\d+):(\d+)\]", listing):
-                assert int(m.group(2)) < 14  # 64-bit temporaries only (v[6:7], v[8:9], v[10:11])
-            # SGPR writes stay inside the record window, the return address, the scratch pair and the TRAM cursor block
-            allowed = set(range(18, 26)) | {62, 63} | set(range(80, 88))
+                assert int(m.group(2)) < 14  # temporaries only (v[2:5] .. v[12:13])
+            # SGPR writes stay inside the record window, the return address, the scratch pair, the TRAM cursor and LUT base blocks
+            allowed = set(range(18, 26)) | {62, 63} | set(range(80, 94))  # + s[88:93]: LUT table bases
             for m in re.finditer(r"^(s_[a-z0-9_]+) s(\d+),", listing, re.M):
                 if not m.group(1).startswith(("s_cmp", "s_setpc")):
                     assert int(m.group(2)) in allowed, (name, m.group(0))
