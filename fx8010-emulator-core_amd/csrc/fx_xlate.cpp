@@ -231,6 +231,13 @@ class Emitter {
         line("global_load_dwordx" + std::to_string(dwords) + " v[" + std::to_string(vdata) + ":" + std::to_string(vdata + dwords - 1) + "], v" +
              std::to_string(vaddr) + ", s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]");
     }
+    // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
+    void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
+        w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | (sdst.code & 0xffu));
+        w_.push_back(s0.code | (s1.code << 9));
+        ++count_;
+        line(std::string(name) + " " + sdst.text + ", " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
+    }
     // VOPC in its VOP3 form with an SGPR-pair destination
     void vop3cmpTo(uint32_t op, const char* name, int sdst, const Src& s0, const Src& s1) {
         w_.push_back(0xd0000000u | (op << 16) | (uint32_t)sdst);
@@ -272,6 +279,8 @@ enum : uint32_t {
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
+    VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
+    SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
     VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49,
     VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
@@ -326,11 +335,13 @@ class Translator {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutX1), sreg(kSLut), imm32((uint32_t)kLutX1Off * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutX1 + 1), sreg(kSLut + 1), imm32(0));
         }
+        records_ = &records;
         for (size_t i = 0; i < records.size(); ++i) {
             const MicroOp& r = records[i];
             const uint32_t slot = r.w[0];
             index_ = i;
             if (slot == AS_ENDSAMPLE) { ended = true; break; }
+            if (i == consumed_) continue;  // a SKIP fused into the instruction that set its CCR
             if (!one(r, slot)) { if (err) *err = err_; return false; }
         }
         if (!ended) { if (err) *err = "record stream without ENDSAMPLE"; return false; }
@@ -778,15 +789,161 @@ class Translator {
         return true;
     }
 
+    // ---- CCR, SKIP and its shadow ------------------------------------------------------------------------
+    // setCCR (FX8010.cpp:211-232) of the value in vR into the CCR row (v32); same instruction sequence as the
+    // interpreter's CCR_FROM
+    void ccrFrom(int vR) {
+        const Src vcc = named(106, "vcc"), t0 = sreg64(62), t1 = sreg64(64), t2 = sreg64(66), r = vreg(vR), one = imm32(0x3f800000u), zero = imm32(0);
+        e_.vop3cmpG(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", vcc, r, true, one);   // |r| < 1
+        e_.vop3cmpG(VOP3_CMP_EQ_F32, "v_cmp_eq_f32_e64", t0, r, true, one);    // |r| == 1
+        e_.vop3cmpG(VOP3_CMP_GT_F32, "v_cmp_gt_f32_e64", t1, zero, false, r);  // r < 0
+        e_.vop3cmpG(VOP3_CMP_EQ_F32, "v_cmp_eq_f32_e64", t2, zero, false, r);  // r == 0
+        Src two = imm32(2), sixteen = imm32(16), eight = imm32(8), v6 = vreg(6), v7 = vreg(7);
+        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", v6, zero, two, &vcc);         // normalised: 2
+        e_.sop2(SOP2_OR_B64, "s_or_b64", vcc, vcc, t0);
+        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", v6, v6, sixteen, &t0);        // saturated: 16
+        e_.sop2(SOP2_AND_B64, "s_and_b64", t1, t1, vcc);                        // negative and |r| <= 1: +4 (6 / 20)
+        e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 7, imm32(4), 6);
+        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", v6, v6, v7, &t1);
+        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", v6, v6, eight, &t2);          // zero: 8
+        e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(kRegFileBase), v6);
+    }
+
+    static float asFloat(uint32_t bits) {
+        float f;
+        std::memcpy(&f, &bits, 4);
+        return f;
+    }
+    // SKIP with uniform X and Y (FX8010.cpp:1175-1179): the CCR value it waits for and the count it sets
+    static bool uniformSkip(const MicroOp& r, float* want, int32_t* count) {
+        if (r.w[0] != AS_SKIP || (r.w[6] & 6u) != 6u) return false;
+        *want = (float)x86Trunc(r.w[3]);
+        *count = x86Trunc(r.w[4]);
+        return true;
+    }
+    // Does anything observe the CCR row after record j before an instruction overwrites it?  (Conservative: the end
+    // of the stream counts as an observer.)
+    bool ccrDeadAfter(size_t j) const {
+        const std::vector<MicroOp>& rec = *records_;
+        for (size_t k = j + 1; k < rec.size(); ++k) {
+            const uint32_t slot = rec[k].w[0];
+            if (slot == AS_ENDSAMPLE || slot == AS_SKIP) return false;
+            if (slot == AS_NOP || slot == AS_PRED || slot == AS_UNPRED) continue;
+            uint32_t kind, ccr;
+            if (slot >= AS_MACS) { kind = ((slot - AS_MACS) % 16) / 2; ccr = (slot - AS_MACS) & 1u; }
+            else { kind = rec[k].w[6] & 7u; ccr = (rec[k].w[6] >> 3) & 1u; }
+            if ((!(kind & 1u) && rec[k].w[2] == 0) || (!(kind & 2u) && rec[k].w[3] == 0 && slot != AS_LUT) || (!(kind & 4u) && rec[k].w[4] == 0)) return false;
+            if (ccr) return true;
+        }
+        return false;
+    }
+    // A SKIP outside every shadow, followed by exactly the `count` shadowed instructions it can skip and then
+    // unshadowed code: its whole shadow runs under one EXEC mask instead of a PRED per instruction.
+    bool simpleShadow(size_t j, int32_t count) const {
+        if (predOpen_ || count < 1) return false;
+        const std::vector<MicroOp>& rec = *records_;
+        int32_t groups = 0;
+        for (size_t k = j + 1; k < rec.size(); ++k) {
+            const uint32_t slot = rec[k].w[0];
+            if (slot == AS_PRED) { ++groups; continue; }
+            if (groups == 0) return false;  // the instruction after the SKIP is not shadowed
+            if (slot == AS_SKIP) return false;
+            if (slot == AS_UNPRED || slot == AS_ENDSAMPLE) return groups == count;
+        }
+        return false;
+    }
+    // vcc = lanes whose CCR would equal `want`, straight from the value in vR (setCCR inverted)
+    bool ccrPredicate(float want, int vR) {
+        const Src vcc = named(106, "vcc"), t0 = sreg64(62), r = vreg(vR), zero = imm32(0), one = imm32(0x3f800000u), mone = imm32(0xbf800000u);
+        if (want == 8.0f) e_.vopc(VOPC_CMP_EQ_F32, "v_cmp_eq_f32_e32", zero, vR);
+        else if (want == 16.0f) e_.vopc(VOPC_CMP_EQ_F32, "v_cmp_eq_f32_e32", one, vR);
+        else if (want == 20.0f) e_.vopc(VOPC_CMP_EQ_F32, "v_cmp_eq_f32_e32", mone, vR);
+        else if (want == 0.0f) e_.vop3cmpG(VOP3_CMP_NLE_F32, "v_cmp_nle_f32_e64", vcc, r, true, one);  // |r| > 1 or NaN
+        else if (want == 2.0f) {  // 0 < r < 1
+            e_.vopc(VOPC_CMP_LT_F32, "v_cmp_lt_f32_e32", zero, vR);
+            e_.vop3cmpG(VOP3_CMP_GT_F32, "v_cmp_gt_f32_e64", t0, one, false, r);
+            e_.sop2(SOP2_AND_B64, "s_and_b64", vcc, vcc, t0);
+        } else if (want == 6.0f) {  // -1 < r < 0
+            e_.vopc(VOPC_CMP_GT_F32, "v_cmp_gt_f32_e32", zero, vR);
+            e_.vop3cmpG(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", t0, mone, false, r);
+            e_.sop2(SOP2_AND_B64, "s_and_b64", vcc, vcc, t0);
+        } else return false;  // CCR never takes this value
+        return true;
+    }
+    // lanes in vcc take the skip: numSkip = count, or - for a simple shadow - leave EXEC until the UNPRED
+    void takeSkip(size_t j, int32_t count) {
+        const Src vcc = named(106, "vcc"), exec = named(126, "exec");
+        const int32_t n = count < 0 ? 1 : count;  // a negative count skips exactly one instruction (FX8010.cpp:1238)
+        if (simpleShadow(j, n)) {
+            e_.sop2(SOP2_ANDN2_B64, "s_andn2_b64", exec, exec, vcc);
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVShadowCount, imm32((uint32_t)n), kVShadowCount);  // the others execute all n
+            regionPreds_ = n;
+            ++stats_.regions;
+            return;
+        }
+        Src c = imm32((uint32_t)count);
+        if (c.hasLit) {
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(5), c);
+            c = vreg(5);
+        } else {
+            e_.sopp(SOPP_NOP, "s_nop", 0, true);
+        }
+        e_.sopp(SOPP_NOP, "s_nop", 0, true);  // two wait states between the VALU write of VCC and its VALU read
+        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(kVNumSkip), vreg(kVNumSkip), c, &vcc);
+    }
+    bool skipInline(const MicroOp& r) {
+        float want;
+        int32_t count;
+        if (!uniformSkip(r, &want, &count)) return false;
+        plainMode();
+        e_.vopc(VOPC_CMP_EQ_F32, "v_cmp_eq_f32_e32", imm32(asBitsOf(want)), kRegFileBase);
+        takeSkip(index_, count);
+        return true;
+    }
+    static uint32_t asBitsOf(float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    }
+    // after a saturating instruction (or MACMV) has left its result in vR with a live CCR: derive the CCR - or, when
+    // the only observer is the SKIP that follows, that SKIP's predicate directly
+    void ccrOrSkip(int vR) {
+        const std::vector<MicroOp>& rec = *records_;
+        size_t j = index_ + 1;
+        while (j < rec.size() && rec[j].w[0] == AS_NOP) ++j;
+        float want;
+        int32_t count;
+        if (j < rec.size() && uniformSkip(rec[j], &want, &count) && ccrDeadAfter(j)) {
+            if (ccrPredicate(want, vR)) takeSkip(j, count);
+            consumed_ = j;
+            ++stats_.fusedSkips;
+            return;
+        }
+        ccrFrom(vR);
+    }
+
     bool one(const MicroOp& r, uint32_t slot) {
         const uint32_t ccrLive = (r.w[6] >> 3) & 1u;
         if (slot == AS_NOP) return true;  // END / NOP only count (staticCount)
         if (slot == AS_UNPRED) {
             e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
             ++stats_.inlined;
+            predOpen_ = false;
+            regionPreds_ = 0;
+            return true;
+        }
+        if (slot == AS_PRED && regionPreds_ > 0) {  // inside a simple shadow: EXEC already excludes the skipping lanes
+            --regionPreds_;
+            predOpen_ = true;
+            ++stats_.inlined;
+            return true;
+        }
+        if (slot == AS_SKIP && skipInline(r)) {
+            ++stats_.inlined;
             return true;
         }
         if (slot == AS_PRED) {
+            predOpen_ = true;
             // instruction inside a SKIP shadow (FX8010.cpp:1037,1235-1241): lanes with numSkip == 0 execute it,
             // the others count their skip down; v15 counts the executed ones
             plainMode();
@@ -821,16 +978,31 @@ class Translator {
                     default: return interp(r, kind);
                 }
             }
-            // a live CCR: the interpreter's handler derives it (w6:w7 matter to INTERP only)
-            return call(r, slot, family == 3 ? 0xfcu : 0x3cu);
+            // a live CCR.  Last-sample streams materialise every CCR write and run once per block: they call the
+            // interpreter's handler (compact code).  Steady streams: the same code as above, then setCCR of the stored
+            // result - or the predicate of the SKIP that reads it.
+            if (prog_.compactCcr) return call(r, slot, family == 3 ? 0xfcu : 0x3cu);
+            if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
+            ++stats_.inlined;
+            bool ok;
+            switch (family) {
+                case 0: ok = macs(r, kind, false); break;
+                case 1: ok = macs(r, kind, true); break;
+                case 2: ok = acc3(r, kind); break;
+                default: ok = interp(r, kind); break;
+            }
+            if (!ok) return false;
+            ccrOrSkip(kRegFileBase + (int)r.w[5]);
+            return true;
         }
-        if (slot == AS_MOV && !ccrLive) {
+        if (slot == AS_MOV && !(ccrLive && prog_.compactCcr)) {
             int vR;
             Src a;
             if (!touch(r, !(r.w[6] & 1u), false, false, true)) return false;
             if (!row(r.w[5], &vR) || !operand(r.w[2], r.w[6] & 1u, &a)) return false;
             plainMode();
             e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), a);
+            if (ccrLive) ccrOrSkip(vR);
             ++stats_.inlined;
             return true;
         }
@@ -847,6 +1019,10 @@ class Translator {
     const std::vector<uint32_t>* exactReturns_;
     std::vector<uint32_t> returns_;  // sync points of this stream (see run())
     std::vector<int> pending_;       // VGPRs with a TRAM read in flight
+    const std::vector<MicroOp>* records_ = nullptr;
+    size_t consumed_ = (size_t)-1;   // record already translated together with its predecessor
+    bool predOpen_ = false;          // EXEC is restricted by a PRED / a simple shadow
+    int32_t regionPreds_ = 0;        // PRED records of the current simple shadow still to come
     bool segKnown_ = false;          // s[92:93] holds the segment base of table offset segOff_
     uint32_t segOff_ = 0;
     size_t index_ = 0;
@@ -978,13 +1154,15 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
 }
 
 bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
-               const XlateProgram& prog, XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err) {
+               const XlateProgram& program, XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err) {
     // hole: [steady fast][steady exact][last fast][last exact], each on a cache line.  The exact stream of a pair
     // is translated first (its call return addresses are the fast stream's escape targets); its position depends
     // on the fast stream's size, which does not depend on the targets - so: size the fast stream with dummy targets.
     const std::vector<MicroOp>* recs[2] = {&steadyRecords, &lastRecords};
     uint32_t at = tmpl.holeOff;
     for (int k = 0; k < 2; ++k) {
+        XlateProgram prog = program;
+        prog.compactCcr = k == 1;
         std::vector<uint32_t> exactRet, scratch, dummy(2 * recs[k]->size() + 2, at);
         XlateStats fastStats, exactStats;
         // pass 1: size of the fast stream (targets = its own base: in range, value irrelevant)
@@ -1005,7 +1183,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
         (k == 0 ? out->steady : out->last) = fastOk ? fastStats : exactStats;
         at = exactAt + align64((uint32_t)code[2 * k + 1].size() * 4);
     }
-    out->wildRow = prog.wildRow;
+    out->wildRow = program.wildRow;
     out->codeBytes = at - tmpl.holeOff;
     if (out->codeBytes + 4 > tmpl.holeBytes) {
         if (err) *err = "translated program larger than the code hole of the template";

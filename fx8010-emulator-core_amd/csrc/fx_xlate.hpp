@@ -42,6 +42,7 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err);
 struct XlateProgram {
     int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
     bool uniformCursors = false;  // all lanes' TRAM cursors move together: kept in SGPRs, TRAM instructions inline
+    bool compactCcr = false;      // set by planXlate for the last-sample streams: live-CCR instructions call the handler
     std::vector<uint8_t> wildRow; // per register-file row: 0 = BOUNDED class (always inside [-1, 1]), 1 = WILD
 };
 // nRows = rows of the register file, inputRows = the rows the frame writes the PCM input to (-1: unused channel)
@@ -52,6 +53,8 @@ struct XlateStats {
     int inlined = 0;     // records translated to straight-line code
     int called = 0;      // records executed by a call to the interpreter's handler
     int instructions = 0;
+    int fusedSkips = 0;  // SKIPs translated as a predicate on the value that would have set their CCR
+    int regions = 0;     // SKIP shadows run under one EXEC mask (no per-instruction PRED)
     int unsaturated = 0; // saturating instructions whose result provably lies in [-1, 1]: no v_med3 in the fast stream
     bool nonFiniteImmediate = false;  // a NaN / Inf among the uniform operands: no fast stream for this program
 };
