@@ -34,7 +34,7 @@ struct AsmArgs {
     int cursorRow, noiseRow;
     int oodRow, countLo, countHi, staticCount;
     int lutX1Off;
-    int pad_;
+    int initOff;  // translated programs: byte offset (from the kernel entry) of code to run once before the first sample, 0 = none
 };
 static_assert(offsetof(AsmArgs, lut) == 0x40, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, nLoad) == 0x58, "AsmArgs layout");
@@ -83,7 +83,7 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
 hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream);
 
 // Launches a kernel with the interpreter's argument block from another module (a translated program, fx_xlate.hpp):
-// ceil(n/64) single-wavefront workgroups, no LDS.
-hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, hipStream_t stream);
+// ceil(n/64) single-wavefront workgroups, ldsBytes of dynamic LDS each.
+hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, size_t ldsBytes, hipStream_t stream);
 
 }  // namespace fx

@@ -283,6 +283,8 @@ int Batch::ensureLowered() {
             xlateSteady_ = (uint64_t)image.steadyFastOff | ((uint64_t)image.steadyOff << 32);
             xlateLast_ = (uint64_t)image.lastFastOff | ((uint64_t)image.lastOff << 32);
             xlateCodeBytes_ = image.codeBytes;
+            xlateInitOff_ = image.initOff;
+            xlateLdsBytes_ = image.ldsBytes;
             xlateWildRow_ = image.wildRow;
             xlateUnsaturated_ = image.steady.unsaturated;
             xlateInlined_ = image.steady.inlined;
@@ -452,7 +454,8 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                 // code streams are named by their byte offset from the kernel entry: {fast, exact} per argument
                 g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteady_);
                 g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLast_);
-                e = launchAsmFunction(xlateFn_, g, s);
+                g.initOff = (int)xlateInitOff_;
+                e = launchAsmFunction(xlateFn_, g, xlateLdsBytes_, s);
             } else {
                 e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
             }

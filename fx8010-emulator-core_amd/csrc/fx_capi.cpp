@@ -213,9 +213,9 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t 
     }
     const fx::XlateTemplate* tmpl = fx::xlateTemplate((fx::AsmVariant)v, &h->err);
     if (!tmpl) return FX_E_PROGRAM;
-    if (stream < 0 || stream > 3) { h->err = "stream: 0 steady fast, 1 steady exact, 2 last fast, 3 last exact"; return FX_E_ARG; }
-    std::vector<uint32_t> code4[4];
-    std::string text4[4];
+    if (stream < 0 || stream > 4) { h->err = "stream: 0 steady fast, 1 steady exact, 2 last fast, 3 last exact, 4 run-once"; return FX_E_ARG; }
+    std::vector<uint32_t> code4[5];
+    std::string text4[5];
     fx::XlateImage plan;
     const std::vector<fx::MicroOp> steadyRecords = fx::encodeAsmStream(low.steady, nullptr, true), lastRecords = fx::encodeAsmStream(low.last, nullptr, true);
     if (!fx::planXlate(steadyRecords, lastRecords, *tmpl, fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow), &plan, code4,

@@ -82,6 +82,7 @@
 	.set KA_COUNTHI,  0xa8
 	.set KA_STATICCNT,0xac
 	.set KA_LUTX1OFF, 0xb0      // byte offset of x1[] inside the LUT blob
+	.set KA_INIT,     0xb4      // translated programs: offset of run-once code (LDS tables), 0 = none
 	.set KA_SIZE,     0xb8
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
@@ -269,6 +270,21 @@ KNAME:
 	s_add_u32 s66, s66, s60
 	s_addc_u32 s67, s67, 0
 	global_load_dword v21, v27, s[66:67]
+#ifdef XLATE
+	// run-once code of the translated program (copies the LOG/EXP tables it uses into LDS); returns through s[24:25]
+	s_load_dword s62, s[0:1], KA_INIT
+	s_waitcnt lgkmcnt(0)
+	s_cmp_eq_u32 s62, 0
+	s_cbranch_scc1 .Lno_init
+	s_add_u32 s62, s62, s32
+	s_addc_u32 s63, s33, 0
+	s_getpc_b64 s[24:25]
+.Lpc_init:
+	s_add_u32 s24, s24, (.Lno_init-.Lpc_init)
+	s_addc_u32 s25, s25, 0
+	s_setpc_b64 s[62:63]
+.Lno_init:
+#endif
 	// first sample's input
 	v_mov_b32 v23, 0
 	v_mov_b32 v24, 0

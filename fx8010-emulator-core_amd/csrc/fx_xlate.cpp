@@ -161,6 +161,8 @@ Src imm32(uint32_t bits, bool forceLiteral = false) {
 
 // ---- instruction emitter -----------------------------------------------------------------------------------
 class Emitter {
+    static constexpr uint32_t DS_READ2_B32_OP = 0x37;
+
   public:
     Emitter(std::vector<uint32_t>* words, std::string* listing) : w_(*words), text_(listing) {}
 
@@ -231,6 +233,33 @@ class Emitter {
         line("global_load_dwordx" + std::to_string(dwords) + " v[" + std::to_string(vdata) + ":" + std::to_string(vdata + dwords - 1) + "], v" +
              std::to_string(vaddr) + ", s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]");
     }
+    // LDS: reads return into v[vdst..], byte offset in the instruction (read2: two dword offsets)
+    void dsRead(uint32_t op, const char* name, int dwords, int vdst, int vaddr, uint32_t offset) {
+        w_.push_back(0xd8000000u | (op << 17) | (offset & 0xffffu));
+        w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
+        ++count_;
+        line(std::string(name) + " v[" + std::to_string(vdst) + ":" + std::to_string(vdst + dwords - 1) + "], v" + std::to_string(vaddr) +
+             (offset ? " offset:" + std::to_string(offset) : ""));
+    }
+    void dsRead2B32(int vdst, int vaddr, uint32_t dword0, uint32_t dword1) {
+        w_.push_back(0xd8000000u | (DS_READ2_B32_OP << 17) | (dword1 << 8) | dword0);
+        w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
+        ++count_;
+        line("ds_read2_b32 v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], v" + std::to_string(vaddr) +
+             (dword0 ? " offset0:" + std::to_string(dword0) : "") + " offset1:" + std::to_string(dword1));
+    }
+    void dsWriteB128(int vaddr, int vdata, uint32_t offset) {
+        w_.push_back(0xd8000000u | (0xdfu << 17) | (offset & 0xffffu));
+        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
+        ++count_;
+        line("ds_write_b128 v" + std::to_string(vaddr) + ", v[" + std::to_string(vdata) + ":" + std::to_string(vdata + 3) + "]" +
+             (offset ? " offset:" + std::to_string(offset) : ""));
+    }
+    void waitLgkm0() {
+        w_.push_back(0xbf8cc07fu);
+        ++count_;
+        line("s_waitcnt lgkmcnt(0)");
+    }
     // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
     void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | (sdst.code & 0xffu));
@@ -282,7 +311,7 @@ enum : uint32_t {
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
     SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
     VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49,
-    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
+    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
@@ -304,6 +333,7 @@ constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane
 constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read
 constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
 constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
+constexpr uint32_t kLdsXthr = 0, kLdsXdom = 264, kLdsX1 = 272, kLdsSeg = 784, kLdsSegBytes = 1024;  // LUT tables in LDS
 constexpr int kSLut = 40;          // s[40:41] = LUT blob
 constexpr int kSLutXthr = 88, kSLutX1 = 90, kSLutSeg = 92;  // s[88:93]: bases of the fp32 thresholds, x1[] and the current table's segments
 constexpr int kSTramBase[2] = {36, 38}, kSTramSize[2] = {56, 57}, kSTramSlots[2] = {46, 47};  // [iTRAM, xTRAM]
@@ -329,7 +359,7 @@ class Translator {
         }
         bool anyLut = false;
         for (const MicroOp& r : records) anyLut = anyLut || r.w[0] == AS_LUT;
-        if (anyLut) {
+        if (anyLut && prog_.lutTables.empty()) {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutXthr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutXthr + 1), sreg(kSLut + 1), imm32(0));
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutX1), sreg(kSLut), imm32((uint32_t)kLutX1Off * 8, true));
@@ -424,7 +454,11 @@ class Translator {
         if (!touch(r, true, false, false, true) || !row(r.w[2], &vA) || !row(r.w[5], &vR)) return false;
         plainMode();
         const bool operandWild = r.w[2] >= prog_.wildRow.size() || prog_.wildRow[r.w[2]];
-        if (!segKnown_ || segOff_ != r.w[3]) {
+        int ldsTable = -1;
+        for (size_t k = 0; k < prog_.lutTables.size(); ++k)
+            if (prog_.lutTables[k] == r.w[3]) ldsTable = (int)k;
+        const bool lds = ldsTable >= 0;
+        if (!lds && (!segKnown_ || segOff_ != r.w[3])) {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutSeg), sreg(kSLut), imm32(r.w[3], true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutSeg + 1), sreg(kSLut + 1), imm32(0));
             segKnown_ = true;
@@ -436,8 +470,13 @@ class Translator {
         Src zero = imm32(0), top = imm32(63);
         e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
         e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
-        e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSLutXthr);                        // xthr[g], xthr[g+1]
-        e_.waitVmcnt0();
+        if (lds) {
+            e_.dsRead2B32(8, 7, kLdsXthr / 4, kLdsXthr / 4 + 1);
+            e_.waitLgkm0();
+        } else {
+            e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSLutXthr);                    // xthr[g], xthr[g+1]
+            e_.waitVmcnt0();
+        }
         e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // x >= xthr[g+1]: one up
         e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));      // x <  xthr[g]  : one down
         // (two instructions between a VALU write of VCC / an SGPR pair and the VALU read of it)
@@ -448,18 +487,30 @@ class Translator {
         e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 6, vreg(6), 10);
         e_.vop2(VOP2_SUB_U32, "v_sub_u32_e32", 6, vreg(6), 11);
         e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
-        e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
-        e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                         // x1[idx]
-        e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
-        e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                         // slope, y1
-        if (operandWild) {
-            // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it
-            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutXdomOff * 8, true));
-            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
-            e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSAddr);
+        if (lds) {
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, kLdsX1);                        // x1[idx]
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
+            e_.dsRead(DS_READ_B128, "ds_read_b128", 4, 2, 7, kLdsSeg + (uint32_t)ldsTable * kLdsSegBytes);  // slope, y1
+            if (operandWild) {
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
+                e_.dsRead2B32(8, 7, kLdsXdom / 4, kLdsXdom / 4 + 1);
+            }
+            e_.waitLgkm0();
+        } else {
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+            e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                     // x1[idx]
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
+            e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                     // slope, y1
+            if (operandWild) {
+                // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it
+                e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutXdomOff * 8, true));
+                e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
+                e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSAddr);
+            }
+            e_.waitVmcnt0();
         }
-        e_.waitVmcnt0();
         if (operandWild) {
             e_.vopc(VOPC_CMP_NGE_F32, "v_cmp_nge_f32_e32", vreg(vA), 8);
             e_.vop3cmpTo(VOP3_CMP_NLT_F32, "v_cmp_nlt_f32_e64", kSTemp, vreg(vA), vreg(9));
@@ -1083,6 +1134,35 @@ bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& t
 
 namespace {
 inline uint32_t align64(uint32_t v) { return (v + 63u) & ~63u; }
+
+// Run-once code: copy [blobOff, blobOff + bytes) of the LUT blob to LDS [ldsOff, ..), 16 bytes per lane and round;
+// bytes is a multiple of 16.  v2 = lane * 16.
+void emitLdsCopy(Emitter& e, uint32_t blobOff, uint32_t ldsOff, uint32_t bytes) {
+    for (uint32_t done = 0; done < bytes; done += 1024) {
+        const uint32_t lanes = std::min<uint32_t>(64, (bytes - done) / 16);
+        e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32(blobOff + done, true));
+        e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
+        if (lanes < 64) {
+            const uint64_t mask = (1ull << lanes) - 1;
+            e.sop1(SOP1_MOV_B32, "s_mov_b32", named(126, "exec_lo"), imm32((uint32_t)mask));
+            e.sop1(SOP1_MOV_B32, "s_mov_b32", named(127, "exec_hi"), imm32((uint32_t)(mask >> 32)));
+        }
+        e.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 4, 2, kSAddr);
+        e.waitVmcnt0();
+        e.dsWriteB128(2, 4, ldsOff + done);
+        if (lanes < 64) e.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+    }
+}
+
+void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string* listing) {
+    Emitter e(code, listing);
+    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 2, imm32(4), 0);  // v0 = lane
+    emitLdsCopy(e, (uint32_t)kLutXthrOff * 8, kLdsXthr, 272);    // fp32 thresholds + domain bounds (adjacent in the blob)
+    emitLdsCopy(e, (uint32_t)kLutX1Off * 8, kLdsX1, 512);
+    for (size_t k = 0; k < prog.lutTables.size(); ++k) emitLdsCopy(e, prog.lutTables[k], kLdsSeg + (uint32_t)k * kLdsSegBytes, kLdsSegBytes);
+    e.waitLgkm0();
+    e.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSReturn));
+}
 }
 
 XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
@@ -1106,6 +1186,13 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
         }
     }
     p.uniformCursors = any && ok;
+
+    // LOG/EXP tables the inline code uses (per-lane operand, CCR not observed): up to 8 of them go to LDS
+    for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords})
+        for (const MicroOp& r : *recs)
+            if (r.w[0] == AS_LUT && !(r.w[6] & 1u) && !((r.w[6] >> 3) & 1u) && std::find(p.lutTables.begin(), p.lutTables.end(), r.w[3]) == p.lutTables.end())
+                p.lutTables.push_back(r.w[3]);
+    if (p.lutTables.size() > 8) p.lutTables.clear();
 
     // Row classes.  BOUNDED: every value the row can hold lies in [-1, 1] - its writers saturate, or pass a bounded
     // value on - given that it started there (the template checks the state rows of this class, and inline TRAM
@@ -1154,7 +1241,7 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
 }
 
 bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
-               const XlateProgram& program, XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err) {
+               const XlateProgram& program, XlateImage* out, std::vector<uint32_t> code[5], std::string listing[5], std::string* err) {
     // hole: [steady fast][steady exact][last fast][last exact], each on a cache line.  The exact stream of a pair
     // is translated first (its call return addresses are the fast stream's escape targets); its position depends
     // on the fast stream's size, which does not depend on the targets - so: size the fast stream with dummy targets.
@@ -1184,6 +1271,15 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
         at = exactAt + align64((uint32_t)code[2 * k + 1].size() * 4);
     }
     out->wildRow = program.wildRow;
+    out->initOff = 0;
+    out->ldsBytes = 0;
+    code[4].clear();
+    if (!program.lutTables.empty()) {
+        emitInit(program, &code[4], listing ? &listing[4] : nullptr);
+        out->initOff = at;
+        out->ldsBytes = kLdsSeg + (uint32_t)program.lutTables.size() * kLdsSegBytes;
+        at += align64((uint32_t)code[4].size() * 4);
+    }
     out->codeBytes = at - tmpl.holeOff;
     if (out->codeBytes + 4 > tmpl.holeBytes) {
         if (err) *err = "translated program larger than the code hole of the template";
@@ -1194,11 +1290,11 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
 
 bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
                      const XlateTemplate& tmpl, const XlateProgram& prog, XlateImage* out, std::string* err) {
-    std::vector<uint32_t> code[4];
+    std::vector<uint32_t> code[5];
     if (!planXlate(steadyRecords, lastRecords, tmpl, prog, out, code, nullptr, err)) return false;
     out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
-    const uint32_t offs[4] = {out->steadyFastOff, out->steadyOff, out->lastFastOff, out->lastOff};
-    for (int k = 0; k < 4; ++k)
+    const uint32_t offs[5] = {out->steadyFastOff, out->steadyOff, out->lastFastOff, out->lastOff, out->initOff};
+    for (int k = 0; k < 5; ++k)
         if (!code[k].empty()) std::memcpy(out->elf.data() + tmpl.holeFileOff + (offs[k] - tmpl.holeOff), code[k].data(), code[k].size() * 4);
     return true;
 }

@@ -42,6 +42,9 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err);
 struct XlateProgram {
     int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
     bool uniformCursors = false;  // all lanes' TRAM cursors move together: kept in SGPRs, TRAM instructions inline
+    // LOG/EXP tables in LDS: the fp32 thresholds, x1[] and the {slope, y1} arrays of the tables the program uses
+    // (lutTables = their byte offsets in the LUT blob, in LDS order); empty = tables are read from global memory
+    std::vector<uint32_t> lutTables;
     bool compactCcr = false;      // set by planXlate for the last-sample streams: live-CCR instructions call the handler
     std::vector<uint8_t> wildRow; // per register-file row: 0 = BOUNDED class (always inside [-1, 1]), 1 = WILD
 };
@@ -80,15 +83,17 @@ struct XlateImage {
     std::vector<unsigned char> elf;
     // entry offsets from the kernel entry; AsmArgs.steady = steadyFastOff | steadyOff << 32, .last likewise
     uint32_t steadyFastOff = 0, steadyOff = 0, lastFastOff = 0, lastOff = 0;
+    uint32_t initOff = 0;   // run-once code (AsmArgs.initOff), 0 = none
+    uint32_t ldsBytes = 0;  // dynamic LDS per workgroup
     uint32_t codeBytes = 0;
     XlateStats steady, last;  // of the stream a finite wave runs
     std::vector<uint8_t> wildRow;  // row classes the code relies on: the loader flags BOUNDED rows in the row table
 };
 // Lays the four streams out ([steady fast][steady exact][last fast][last exact]) and translates them; code[k] /
-// listing[k] in that order (listing may be nullptr).  Without a fast stream (non-finite uniform operand) the
+// listing[k] in that order (listing may be nullptr); code[4] = the run-once code (LDS tables), empty when none.  Without a fast stream (non-finite uniform operand) the
 // fast offsets equal the exact ones.
 bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
-               const XlateProgram& prog, XlateImage* out, std::vector<uint32_t> code[4], std::string listing[4], std::string* err);
+               const XlateProgram& prog, XlateImage* out, std::vector<uint32_t> code[5], std::string listing[5], std::string* err);
 bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
                      const XlateTemplate& tmpl, const XlateProgram& prog, XlateImage* out, std::string* err);
 

@@ -54,16 +54,21 @@ def program_texts():
 
 
 @needs_llvm
-@pytest.mark.parametrize("last", [0, 1, 2, 3], ids=["steady_fast", "steady_exact", "last_fast", "last_exact"])
+@pytest.mark.parametrize("last", [0, 1, 2, 3, 4], ids=["steady_fast", "steady_exact", "last_fast", "last_exact", "run_once"])
 def test_listing_reassembles_to_the_same_bytes(last):
+    seen = 0
     for name, text in program_texts():
         fe = A.FrontEnd(1)
         assert fe.load_text(text), name
         code, listing = fe.translate(0, last)
+        if last == 4 and not code:
+            continue  # no LOG/EXP tables to stage in LDS
+        seen += 1
         assert len(code) > 0 and len(code) % 4 == 0
         again = assemble(listing)
         assert again[: len(code)] == code, "%s: encoder and assembler disagree" % name
         assert len(again) == len(code), name
+    assert seen > 0
 
 
 def test_structure_of_translated_code():
