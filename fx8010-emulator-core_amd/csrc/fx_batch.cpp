@@ -363,6 +363,36 @@ int Batch::setRegisterAt(const std::string& key, int64_t inst, float v) {
     return 0;
 }
 
+int Batch::setRegisterArray(const std::string& key, const float* values) {
+    (void)hipSetDevice(device_);
+    const int r = prog_.findRegister(key);
+    if (r < 0) return 1;
+    if (!values) return fail(FX_E_ARG, "null buffer");
+    if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    if (!laneResident(r)) {  // uniform so far: from now on a per-instance row (every lane is overwritten below)
+        forcedLane_[r] = 1;
+        lowDirty_ = true;
+    }
+    hipError_t e = hipMemcpy(dState_ + (size_t)r * nPad_, values, sizeof(float) * (size_t)n_, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hipFail(e, "setRegisterArray");
+    return 0;
+}
+
+int Batch::getRegisterArray(const std::string& key, float* values) {
+    (void)hipSetDevice(device_);
+    const int r = prog_.findRegister(key);
+    if (r < 0) return 1;
+    if (!values) return fail(FX_E_ARG, "null buffer");
+    if (!dState_ || !laneResident(r)) {
+        for (int64_t i = 0; i < n_; ++i) values[i] = hostValue_[r];
+        return 0;
+    }
+    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    hipError_t e = hipMemcpy(values, dState_ + (size_t)r * nPad_, sizeof(float) * (size_t)n_, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : hipFail(e, "getRegisterArray");
+}
+
 float Batch::getRegisterAt(const std::string& key, int64_t inst) {
     (void)hipSetDevice(device_);
     const int r = prog_.findRegister(key);

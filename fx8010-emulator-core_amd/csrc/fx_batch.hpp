@@ -30,6 +30,8 @@ public:
     int setRegister(const std::string& key, float v);                    // 0 found, 1 not found, <0 error
     int setRegisterAt(const std::string& key, int64_t inst, float v);
     float getRegisterAt(const std::string& key, int64_t inst);           // 1.0f when not found
+    int setRegisterArray(const std::string& key, const float* values);   // values[n]
+    int getRegisterArray(const std::string& key, float* values);
     int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
 
     int processHost(const float* in, float* out, int nSamples);           // synchronous

@@ -108,6 +108,8 @@ int fxb_load_text(fxb_handle* h, const char* text) { return (h && text && h->bat
 int fxb_set_register(fxb_handle* h, const char* key, float v) { return (h && key) ? h->batch.setRegister(key, v) : 1; }
 int fxb_set_register_i(fxb_handle* h, const char* key, int64_t inst, float v) { return (h && key) ? h->batch.setRegisterAt(key, inst, v) : 1; }
 float fxb_get_register_i(fxb_handle* h, const char* key, int64_t inst) { return (h && key) ? h->batch.getRegisterAt(key, inst) : 1.0f; }
+int fxb_set_register_array(fxb_handle* h, const char* key, const float* values) { return (h && key) ? h->batch.setRegisterArray(key, values) : 1; }
+int fxb_get_register_array(fxb_handle* h, const char* key, float* values) { return (h && key) ? h->batch.getRegisterArray(key, values) : 1; }
 int fxb_seed_noise_i(fxb_handle* h, int64_t inst, int32_t x1, int32_t x2) { return h ? h->batch.seedNoiseAt(inst, x1, x2) : FX_E_ARG; }
 int fxb_process_block(fxb_handle* h, const float* in, float* out, int n) { return h ? h->batch.processHost(in, out, n) : FX_E_ARG; }
 int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n, void* stream) {

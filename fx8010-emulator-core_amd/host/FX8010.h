@@ -115,6 +115,8 @@ public:
     int setRegisterValue(const std::string& key, float value) { return fxb_set_register(h_, key.c_str(), value); }
     int setRegisterValue(const std::string& key, int64_t instance, float value) { return fxb_set_register_i(h_, key.c_str(), instance, value); }
     float getRegisterValue(const std::string& key, int64_t instance) { return fxb_get_register_i(h_, key.c_str(), instance); }
+    // one value per instance (values.size() == instances): per-instance control automation between blocks
+    int setRegisterValues(const std::string& key, const std::vector<float>& values) { return fxb_set_register_array(h_, key.c_str(), values.data()); }
     // nSamples sample periods for every instance (host buffers, synchronous)
     void process(const float* in, float* out, int nSamples) {
         if (fxb_process_block(h_, in, out, nSamples) < 0) throw std::runtime_error(std::string("FX8010Batch::process: ") + fxb_last_error(h_));

@@ -98,6 +98,11 @@ int fxb_set_register(fxb_handle* h, const char* key, float value);
 int fxb_set_register_i(fxb_handle* h, const char* key, int64_t instance, float value);
 /* getRegisterValue of one instance (1.0f when not found) */
 float fxb_get_register_i(fxb_handle* h, const char* key, int64_t instance);
+/* setRegisterValue / getRegisterValue of every instance at once: values[n_instances], one per instance - what N
+ * callers of the reference's setRegisterValue would do before a block (per-instance control automation).
+ * 0 found, 1 not found, <0 FX_E_*.  One host-to-device copy; the register becomes per-instance. */
+int fxb_set_register_array(fxb_handle* h, const char* key, const float* values);
+int fxb_get_register_array(fxb_handle* h, const char* key, float* values);
 /* white-noise generator seeds of one instance (reference: g_x1/g_x2, include/FX8010.h:290-291;
  * every instance starts with the reference's seeds) */
 int fxb_seed_noise_i(fxb_handle* h, int64_t instance, int32_t x1, int32_t x2);

@@ -423,6 +423,35 @@ def test_control_changes_defer_the_translation(gpu, monkeypatch):
     assert b.instruction_counter_i(5) == o.instruction_counter()
 
 
+def test_register_arrays_per_instance_automation(gpu, k):
+    """fxb_set_register_array: one control value per instance before each block - N reference objects whose
+    caller moves a different slider on each (main.cpp:107-114 per object)."""
+    text = HDR + "macs a, a, vol, in\ninterp b, b, vol, a\nmacs out, b, a, 0.5\nend"
+    N, S, blocks = 96, 16, 4
+    x = progs.stimulus(N, S * blocks)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    oracles = []
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(text)
+        oracles.append(o)
+    rng = np.random.default_rng(5)
+    for blk in range(blocks):
+        vols = rng.uniform(0.0, 1.0, size=N).astype(np.float32)
+        assert b.set_register_array("vol", vols) == 0
+        y = b.process_block(x[blk * S:(blk + 1) * S])
+        for n in range(N):
+            oracles[n].set_register("vol", float(vols[n]))
+            ref = oracles[n].process_block(x[blk * S:(blk + 1) * S, n].copy())
+            assert np.array_equal(bits(ref), bits(y[:, n])), "block %d instance %d" % (blk, n)
+        assert np.array_equal(bits(b.get_register_array("vol")), bits(vols))
+    got = b.get_register_array("a")
+    for n in range(N):
+        assert int(bits(got[n:n + 1])[0]) == oracles[n].get_register_bits("a")
+    assert b.set_register_array("nosuch", np.zeros(N, dtype=np.float32)) == 1
+
+
 def test_noise_seed_per_instance(gpu, k):
     text = HDR + "macs out, 0, noise, 1.0\nend"
     N, S = 66, 40
