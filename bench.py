@@ -197,10 +197,18 @@ def main():
         rows = batch.info("num_rows")
         kid = batch.info("kernel")
         vg = (0, 0, 64, 72, 80, 96, 128, 168, 256)
-        kernel_kind = ("fx_step_block (HIP C++)" if kid == 0 else "fx_interp_lds (gfx950 asm interpreter, LDS register file)" if kid == 1 else
-                       "fx_interp_v%d (gfx950 asm interpreter, VGPR register file)" % vg[kid] if kid <= 8 else
-                       "fx_xlate_v%d (program translated to gfx950 code: %d records inline, %d handler calls, %d code bytes)"
-                       % (vg[kid - 7], batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_code_bytes")))
+        if kid == 0:
+            kernel_kind = "fx_step_block (HIP C++)"
+        elif kid == 1:
+            kernel_kind = "fx_interp_lds (gfx950 asm interpreter, LDS register file)"
+        elif kid <= 8:
+            kernel_kind = "fx_interp_v%d (gfx950 asm interpreter, VGPR register file)" % vg[kid]
+        else:
+            pair = kid >= 16
+            kernel_kind = ("%s_v%d (program translated to gfx950 code%s: %d records inline, %d handler calls, %d saturations elided, %d code bytes)"
+                           % ("fx_pair" if pair else "fx_xlate", vg[kid - 15] if pair else vg[kid - 7],
+                              ", two instances per lane, packed fp32" if pair else "",
+                              batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_unsaturated"), batch.info("xlate_code_bytes")))
         # algorithmic HBM bytes of ONE launch on ONE GPU: PCM in+out, every executed
         # TRAM read/write, and the once-per-block register-file spill/fill
         bytes_per_inst_sample = 4 * (1 + 1) + 4 * tram_ops

@@ -203,8 +203,8 @@ const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err)
     return e == hipSuccess ? g_tables[device][variant] : nullptr;
 }
 
-hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, size_t ldsBytes, hipStream_t stream) {
-    return launchRaw(fn, args, (unsigned)((args.n + 63) / 64), ldsBytes, stream);
+hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream) {
+    return launchRaw(fn, args, grid, ldsBytes, stream);
 }
 
 hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream) {

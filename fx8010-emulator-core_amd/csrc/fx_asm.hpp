@@ -83,7 +83,7 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
 hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream);
 
 // Launches a kernel with the interpreter's argument block from another module (a translated program, fx_xlate.hpp):
-// ceil(n/64) single-wavefront workgroups, ldsBytes of dynamic LDS each.
-hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, size_t ldsBytes, hipStream_t stream);
+// `grid` single-wavefront workgroups, ldsBytes of dynamic LDS each.
+hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream);
 
 }  // namespace fx

@@ -154,7 +154,8 @@ int Batch::ensureState() {
 int Batch::ensureTram() {
     auto grow = [&](float*& buf, int& have, int want) -> int {
         if (want <= have) return 0;
-        const size_t waves = (size_t)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
+        size_t waves = (size_t)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
+        if (instPerLane_ == 1) waves = (waves + 1) & ~(size_t)1;  // the pair frame owns the tiles of wavefronts 2w and 2w+1
         const size_t pitch = 256 * (size_t)instPerLane_;  // bytes of one slot of one wavefront
         float* fresh = nullptr;
         const size_t bytes = waves * (size_t)want * pitch;
@@ -268,11 +269,36 @@ int Batch::ensureLowered() {
         xlateWhyNot_ = "deferred: control registers are changing";
     } else if (useAsm_ && asmVariant_ != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
         // first choice for a VGPR build: translate the program into gfx950 code (FX_KERNEL=asm* pins the interpreter)
-        const XlateTemplate* tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
-        XlateImage image;
         const std::vector<MicroOp> steadyRecords = encodeAsmStream(low_.steady, nullptr, true), lastRecords = encodeAsmStream(low_.last, nullptr, true);
-        if (tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow),
-                                    &image, &xlateWhyNot_)) {
+        XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow);
+        XlateImage image;
+        const XlateTemplate* tmpl = nullptr;
+        bool built = false;
+        // Two instances per lane (fx_pair_gfx950.S: v_pk_mul_f32 / v_pk_add_f32 over both) - opt-in with FX_KERNEL=xlate2
+        // for programs without SKIP and handler calls.  Measured on MI355X it is slower than one instance per lane
+        // (config5, 262144 instances: 13.5 vs 14.3 e12 instr/s): the packed instructions issue at half rate, so they
+        // save nothing, and the pair waves halve the occupancy.  Kept as a tested experiment.
+        const bool pairForced = forceHip && std::strcmp(forceHip, "xlate2") == 0;
+        if (pairForced) {
+            int pv = ASM_V96;
+            while (pv < ASM_V256 && 32 + 2 * low_.nRows > kAsmVgprRows[pv] + 32) ++pv;
+            std::string why;
+            const XlateTemplate* pt = (32 + 2 * low_.nRows <= kAsmVgprRows[pv] + 32) ? xlateTemplate((AsmVariant)pv, true, &why) : nullptr;
+            if (pt) {
+                XlateProgram pairProg = xprog;
+                pairProg.pair = true;
+                if (buildXlateImage(steadyRecords, lastRecords, *pt, pairProg, &image, &why)) {
+                    tmpl = pt;
+                    built = true;
+                    xlatePairVariant_ = (AsmVariant)pv;
+                }
+            }
+        }
+        if (!built) {
+            tmpl = xlateTemplate(asmVariant_, false, &xlateWhyNot_);
+            built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &xlateWhyNot_);
+        }
+        if (built) {
             if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still run the old code
             if (xlateModule_) (void)hipModuleUnload(xlateModule_);
             xlateModule_ = nullptr;
@@ -289,6 +315,7 @@ int Batch::ensureLowered() {
             xlateUnsaturated_ = image.steady.unsaturated;
             xlateInlined_ = image.steady.inlined;
             xlateCalled_ = image.steady.called;
+            xlatePair_ = tmpl->pair;
             useXlate_ = true;
         }
     }
@@ -485,7 +512,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                 g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteady_);
                 g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLast_);
                 g.initOff = (int)xlateInitOff_;
-                e = launchAsmFunction(xlateFn_, g, xlateLdsBytes_, s);
+                e = launchAsmFunction(xlateFn_, g, (unsigned)((n_ + (xlatePair_ ? 127 : 63)) / (xlatePair_ ? 128 : 64)), xlateLdsBytes_, s);
             } else {
                 e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
             }
@@ -593,7 +620,7 @@ int64_t Batch::info(int what) {
     if (ensureLowered() != 0) return -1;
     switch (what) {
         case FXB_INFO_INST_PER_LANE: return instPerLane_;
-        case FXB_INFO_KERNEL: return useAsm_ ? (useXlate_ ? 8 : 1) + (int)asmVariant_ : 0;
+        case FXB_INFO_KERNEL: return useAsm_ ? (useXlate_ ? (xlatePair_ ? 16 + (int)xlatePairVariant_ : 8 + (int)asmVariant_) : 1 + (int)asmVariant_) : 0;
         case FXB_INFO_XLATE_CODE_BYTES: return useXlate_ ? (int64_t)xlateCodeBytes_ : 0;
         case FXB_INFO_XLATE_INLINED: return useXlate_ ? xlateInlined_ : 0;
         case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;

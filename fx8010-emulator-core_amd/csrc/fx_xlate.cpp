@@ -35,7 +35,28 @@ const unsigned char kBlobV256[] = {
 #include "build/fx_xlate_v256_blob.inc"
 };
 
+const unsigned char kPairV96[] = {
+#include "build/fx_pair_v96_blob.inc"
+};
+const unsigned char kPairV128[] = {
+#include "build/fx_pair_v128_blob.inc"
+};
+const unsigned char kPairV168[] = {
+#include "build/fx_pair_v168_blob.inc"
+};
+const unsigned char kPairV256[] = {
+#include "build/fx_pair_v256_blob.inc"
+};
+
 struct BlobRef { const unsigned char* p; size_t n; const char* kernel; int vgprs; };
+// frames with two instances per lane (fx_pair_gfx950.S): rows = (vgprs - 32) / 2
+const BlobRef kPairBlobs[ASM_VARIANTS] = {
+    {nullptr, 0, "", 0}, {nullptr, 0, "", 0}, {nullptr, 0, "", 0}, {nullptr, 0, "", 0},
+    {kPairV96, sizeof(kPairV96), "fx_pair_v96", 96},
+    {kPairV128, sizeof(kPairV128), "fx_pair_v128", 128},
+    {kPairV168, sizeof(kPairV168), "fx_pair_v168", 168},
+    {kPairV256, sizeof(kPairV256), "fx_pair_v256", 256},
+};
 const BlobRef kBlobs[ASM_VARIANTS] = {
     {nullptr, 0, "", 0},
     {kBlobV64, sizeof(kBlobV64), "fx_xlate_v64", 64},
@@ -85,9 +106,9 @@ SymbolAt findSymbol(const unsigned char* img, size_t n, const std::string& name)
 }
 
 std::mutex g_mu;
-XlateTemplate g_templates[ASM_VARIANTS];
-bool g_parsed[ASM_VARIANTS] = {};
-std::string g_parseErr[ASM_VARIANTS];
+XlateTemplate g_templates[2][ASM_VARIANTS];
+bool g_parsed[2][ASM_VARIANTS] = {};
+std::string g_parseErr[2][ASM_VARIANTS];
 
 // ---- operands --------------------------------------------------------------------------------------------
 struct Src {
@@ -1142,14 +1163,19 @@ class Translator {
             return tram(r, slot);
         }
         bool ok = true;
-        if (slot == AS_LUT && !((r.w[6] >> 3) & 1u) && !(r.w[6] & 1u)) {
-            for (half_ = 0; half_ < 2 && ok; ++half_) ok = lut(r);
+        const bool genericCcr = slot < AS_MACS && ((r.w[6] >> 3) & 1u) && !ccrDeadAfter(index_);
+        if (slot == AS_LUT && !(r.w[6] & 1u)) {
+            for (half_ = 0; half_ < 2 && ok; ++half_) {
+                ok = lut(r);
+                if (ok && genericCcr) ccrFrom(vrow(r.w[5], half_));
+            }
             half_ = 0;
             ++stats_.inlined;
             return ok;
         }
         if (slot >= AS_MACS && slot < (uint32_t)kAsmSlots) {
-            const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2, ccr = rel & 1u;
+            const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2;
+            const uint32_t ccr = (rel & 1u) && !ccrDeadAfter(index_) ? 1u : 0u;
             if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
             ++stats_.inlined;
             switch (family) {
@@ -1171,7 +1197,7 @@ class Translator {
                 ok = row(r.w[5], &vR) && operand(r.w[2], r.w[6] & 1u, &a);
                 if (!ok) break;
                 e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), a);
-                if ((r.w[6] >> 3) & 1u) ccrFrom(vR);
+                if (genericCcr) ccrFrom(vR);
             }
             half_ = 0;
             ++stats_.inlined;
@@ -1182,7 +1208,8 @@ class Translator {
 
     bool one(const MicroOp& r, uint32_t slot) {
         if (prog_.pair) return onePair(r, slot);
-        const uint32_t ccrLive = (r.w[6] >> 3) & 1u;
+        // (generic records carry their CCR flag in w6; a write the stream overwrites before anything reads it is dead)
+        const uint32_t ccrLive = (slot < AS_MACS && ((r.w[6] >> 3) & 1u) && !ccrDeadAfter(index_)) ? 1u : 0u;
         if (slot == AS_NOP) return true;  // END / NOP only count (staticCount)
         if (slot == AS_UNPRED) {
             e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
@@ -1217,16 +1244,21 @@ class Translator {
             ++stats_.inlined;
             return true;
         }
-        if (slot == AS_LUT && !ccrLive && !(r.w[6] & 1u)) {
+        if (slot == AS_LUT && !(r.w[6] & 1u) && !(ccrLive && prog_.compactCcr)) {
             ++stats_.inlined;
-            return lut(r);
+            if (!lut(r)) return false;
+            if (ccrLive) ccrFrom(vrow(r.w[5], 0));
+            return true;
         }
         if (prog_.uniformCursors && slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
             ++stats_.inlined;
             return tram(r, slot);
         }
         if (slot >= AS_MACS && slot < (uint32_t)kAsmSlots) {
-            const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2, ccr = rel & 1u;
+            const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2;
+            // a CCR write that the stream itself overwrites before anything can read it is dead (the last-sample
+            // stream marks every write live; only the final one is state)
+            const uint32_t ccr = (rel & 1u) && !ccrDeadAfter(index_) ? 1u : 0u;
             if (!ccr) {
                 if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
                 ++stats_.inlined;
@@ -1265,6 +1297,11 @@ class Translator {
             ++stats_.inlined;
             return true;
         }
+        if (slot < AS_MACS && ((r.w[6] >> 3) & 1u) && !ccrLive) {
+            MicroOp q = r;
+            q.w[6] &= ~8u;  // the handler need not derive a CCR nobody sees
+            return call(q, slot, 0x7cu);
+        }
         return call(r, slot, 0x7cu);  // generic handlers read w2..w6
     }
 
@@ -1296,25 +1333,27 @@ class Translator {
 
 }  // namespace
 
-const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
-    if (variant <= ASM_LDS || variant >= ASM_VARIANTS) {
+const XlateTemplate* xlateTemplate(AsmVariant variant, bool pair, std::string* err) {
+    const int k = pair ? 1 : 0;
+    if (variant <= ASM_LDS || variant >= ASM_VARIANTS || (pair && !kPairBlobs[variant].p)) {
         if (err) *err = "no translation template for this build";
         return nullptr;
     }
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_parsed[variant]) {
-        g_parsed[variant] = true;
-        const BlobRef& b = kBlobs[variant];
+    if (!g_parsed[k][variant]) {
+        g_parsed[k][variant] = true;
+        const BlobRef& b = pair ? kPairBlobs[variant] : kBlobs[variant];
         XlateTemplate t;
         t.image = b.p;
         t.imageBytes = b.n;
         t.kernelName = b.kernel;
         t.vgprs = b.vgprs;
-        const SymbolAt k = findSymbol(b.p, b.n, t.kernelName);
+        t.pair = pair;
+        const SymbolAt kn = findSymbol(b.p, b.n, t.kernelName);
         const SymbolAt tab = findSymbol(b.p, b.n, t.kernelName + "_table");
         const SymbolAt hole = findSymbol(b.p, b.n, t.kernelName + "_hole");
-        if (!k.found || !tab.found || !hole.found || tab.fileOff + (kAsmSlots + 2) * 4 > b.n) {
-            g_parseErr[variant] = "translation template " + t.kernelName + ": symbols not found in the code object";
+        if (!kn.found || !tab.found || !hole.found || tab.fileOff + (kAsmSlots + 2) * 4 > b.n) {
+            g_parseErr[k][variant] = "translation template " + t.kernelName + ": symbols not found in the code object";
         } else {
             uint32_t table[kAsmSlots + 2];
             std::memcpy(table, b.p + tab.fileOff, sizeof(table));
@@ -1322,17 +1361,17 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
             t.holeOff = table[kAsmSlots];
             t.holeBytes = table[kAsmSlots + 1];
             t.holeFileOff = hole.fileOff;
-            if ((uint64_t)t.holeOff != hole.value - k.value || t.holeFileOff + t.holeBytes > b.n || (t.holeBytes & 3u))
-                g_parseErr[variant] = "translation template " + t.kernelName + ": inconsistent hole";
+            if ((uint64_t)t.holeOff != hole.value - kn.value || t.holeFileOff + t.holeBytes > b.n || (t.holeBytes & 3u))
+                g_parseErr[k][variant] = "translation template " + t.kernelName + ": inconsistent hole";
             else
-                g_templates[variant] = t;
+                g_templates[k][variant] = t;
         }
     }
-    if (!g_parseErr[variant].empty()) {
-        if (err) *err = g_parseErr[variant];
+    if (!g_parseErr[k][variant].empty()) {
+        if (err) *err = g_parseErr[k][variant];
         return nullptr;
     }
-    return &g_templates[variant];
+    return &g_templates[k][variant];
 }
 
 bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, const XlateProgram& prog, uint32_t codeBase,
@@ -1398,10 +1437,10 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
     }
     p.uniformCursors = any && ok;
 
-    // LOG/EXP tables the inline code uses (per-lane operand, CCR not observed): up to 8 of them go to LDS
+    // LOG/EXP tables the inline code uses (per-lane operand): up to 8 of them go to LDS
     for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords})
         for (const MicroOp& r : *recs)
-            if (r.w[0] == AS_LUT && !(r.w[6] & 1u) && !((r.w[6] >> 3) & 1u) && std::find(p.lutTables.begin(), p.lutTables.end(), r.w[3]) == p.lutTables.end())
+            if (r.w[0] == AS_LUT && !(r.w[6] & 1u) && std::find(p.lutTables.begin(), p.lutTables.end(), r.w[3]) == p.lutTables.end())
                 p.lutTables.push_back(r.w[3]);
     if (p.lutTables.size() > 8) p.lutTables.clear();
 

@@ -29,14 +29,16 @@ struct XlateTemplate {
     size_t imageBytes = 0;
     std::string kernelName;
     int vgprs = 0;                        // VGPR budget of the build (register file = v32 .. v[vgprs-1])
+    bool pair = false;                    // two instances per lane (fx_pair_gfx950.S): row r = v[32+2r : 33+2r]
     uint32_t handlerOff[kAsmSlots] = {};  // byte offset of each handler (register set _a) from the kernel entry
     uint32_t holeOff = 0;                 // byte offset of the hole from the kernel entry
     uint32_t holeBytes = 0;
     size_t holeFileOff = 0;               // where the hole sits in the ELF file
 };
 
-// The template of a VGPR build (ASM_V64 .. ASM_V256); nullptr + err when the image is malformed.
-const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err);
+// The template of a VGPR build (ASM_V64 .. ASM_V256; pair frames: ASM_V96 .. ASM_V256); nullptr + err when there is
+// none or the image is malformed.
+const XlateTemplate* xlateTemplate(AsmVariant variant, bool pair, std::string* err);
 
 // What the translator needs to know about the program beyond its records.
 struct XlateProgram {
