@@ -520,6 +520,28 @@ def test_register_arrays_per_instance_automation(gpu, k):
     assert b.set_register_array("nosuch", np.zeros(N, dtype=np.float32)) == 1
 
 
+def test_programs_beyond_the_translator_fall_back(gpu, monkeypatch):
+    """A program whose translation does not fit the template's code hole runs on the interpreter, one whose
+    register file exceeds 224 rows on the interpreter's LDS build - same results."""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    rng = np.random.default_rng(11)
+    regs = ["r%d" % i for i in range(40)]
+    body = []
+    for i in range(6000):
+        a, b_, c = rng.choice(regs, 3)
+        body.append(("macs %s, %s, %s, 0.37" if i % 3 else "interp %s, %s, 0.3, %s") % (a, b_, c))
+    big = HDR + "".join("static %s\n" % r for r in regs) + "macs r0, in, 0.5, 0.5\n" + "\n".join(body) + "\nmacs out, r1, r2, 0.5\nend"
+    x = progs.stimulus(66, 6)
+    b, _ = check_batch(gpu, big, x, regs=("r3", "r17", "out"), instances=[0, 65])
+    assert 2 <= b.info("kernel") <= 8  # interpreter, VGPR register file
+    wide_regs = ["w%d" % i for i in range(240)]
+    wide = HDR + "".join("static %s\n" % r for r in wide_regs) + "macs w0, in, 0.5, 0.5\n"
+    wide += "".join("macs w%d, w%d, w%d, 0.9\n" % (i, i - 1, (i * 7) % 240) for i in range(1, 240)) + "macs out, w239, w100, 0.5\nend"
+    b, _ = check_batch(gpu, wide, x, regs=("w239", "out"), instances=[0, 65])
+    assert b.info("kernel") == 1  # interpreter, LDS register file
+
+
 def test_noise_seed_per_instance(gpu, k):
     text = HDR + "macs out, 0, noise, 1.0\nend"
     N, S = 66, 40
