@@ -1055,15 +1055,18 @@ class Translator {
     // of the stream counts as an observer.)
     bool ccrDeadAfter(size_t j) const {
         const std::vector<MicroOp>& rec = *records_;
+        bool shadowed = false;  // a write inside a SKIP shadow happens in some lanes only: it kills nothing
         for (size_t k = j + 1; k < rec.size(); ++k) {
             const uint32_t slot = rec[k].w[0];
             if (slot == AS_ENDSAMPLE || slot == AS_SKIP) return false;
+            if (slot == AS_PRED) shadowed = true;
+            if (slot == AS_UNPRED) shadowed = false;
             if (slot == AS_NOP || slot == AS_PRED || slot == AS_UNPRED) continue;
             uint32_t kind, ccr;
             if (slot >= AS_MACS) { kind = ((slot - AS_MACS) % 16) / 2; ccr = (slot - AS_MACS) & 1u; }
             else { kind = rec[k].w[6] & 7u; ccr = (rec[k].w[6] >> 3) & 1u; }
             if ((!(kind & 1u) && rec[k].w[2] == 0) || (!(kind & 2u) && rec[k].w[3] == 0 && slot != AS_LUT) || (!(kind & 4u) && rec[k].w[4] == 0)) return false;
-            if (ccr) return true;
+            if (ccr && !shadowed) return true;
         }
         return false;
     }

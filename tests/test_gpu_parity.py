@@ -542,6 +542,39 @@ def test_programs_beyond_the_translator_fall_back(gpu, monkeypatch):
     assert b.info("kernel") == 1  # interpreter, LDS register file
 
 
+@pytest.mark.parametrize("chunk", range(6))
+def test_random_programs(gpu, chunk, monkeypatch):
+    """differential fuzz on the default tier: random in-domain programs over all opcodes, SKIPs of every CCR value
+    and count, `ccr` / `noise` / literals as operands, delay lines - every instance against the oracle"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_fuzz
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    N, S = 70, 12
+    x = progs.stimulus(N, S)
+    for seed in range(chunk * 16, chunk * 16 + 16):
+        rng = np.random.default_rng(91000 + seed)
+        gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
+        text = gen(rng, int(rng.integers(6, 90)), int(rng.integers(3, 40)))
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        y = b.process_block(x)
+        y2 = b.process_block(x)
+        for n in range(0, N, 3):
+            o = Oracle(1)
+            assert o.load_text(text)
+            r1 = o.process_block(x[:, n].copy())
+            r2 = o.process_block(x[:, n].copy())
+            if o.ood_flags():
+                continue
+            assert same_with_nan(r1, y[:, n]) and same_with_nan(r2, y2[:, n]), "seed %d instance %d (kernel %d)\n%s" % (seed, n, b.info("kernel"), text)
+            assert b.instruction_counter_i(n) == o.instruction_counter(), "seed %d instance %d counter" % (seed, n)
+            rb, gb = o.get_register_bits("ccr"), b.get_register_bits_i("ccr", n)
+            assert rb == gb, "seed %d instance %d ccr %08x %08x" % (seed, n, rb, gb)
+
+
 def test_noise_seed_per_instance(gpu, k):
     text = HDR + "macs out, 0, noise, 1.0\nend"
     N, S = 66, 40

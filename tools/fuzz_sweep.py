@@ -1,0 +1,62 @@
+"""Wide differential fuzz of the default tier against the oracle (the GPU test suite runs 96 of these programs).
+
+    python tools/fuzz_sweep.py [first_seed] [count]
+"""
+import os
+import sys
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "fx8010-emulator-core_amd/python"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+
+import fx8010_amd as A  # noqa: E402
+import fx8010_programs as P  # noqa: E402
+import stress_fuzz  # noqa: E402
+from pyoracle import Oracle  # noqa: E402
+
+
+def same(ref, got):
+    ref = np.asarray(ref, dtype=np.float32).reshape(-1)
+    got = np.asarray(got, dtype=np.float32).reshape(-1)
+    rn, gn = np.isnan(ref), np.isnan(got)
+    return np.array_equal(rn, gn) and np.array_equal(ref.view(np.uint32)[~rn], got.view(np.uint32)[~gn])
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+    N, S = 70, 10
+    x = P.stimulus(N, S)
+    failures, kernels = [], {}
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(500000 + seed)
+        gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
+        text = gen(rng, int(rng.integers(4, 100)), int(rng.integers(2, 50)))
+        b = A.Batch(N, 1, 0)
+        if not b.load_text(text):
+            continue
+        y1 = b.process_block(x)
+        y2 = b.process_block(x)
+        kernels[b.info("kernel")] = kernels.get(b.info("kernel"), 0) + 1
+        for n in (0, 1, 37, 64, 69):
+            o = Oracle(1)
+            o.load_text(text)
+            r1 = o.process_block(x[:, n].copy())
+            r2 = o.process_block(x[:, n].copy())
+            if o.ood_flags():
+                continue
+            ok = same(r1, y1[:, n]) and same(r2, y2[:, n]) and b.instruction_counter_i(n) == o.instruction_counter()
+            ok = ok and b.get_register_bits_i("ccr", n) == o.get_register_bits("ccr")
+            if not ok:
+                failures.append(seed)
+                print("MISMATCH seed", seed, "instance", n, "kernel", b.info("kernel"), flush=True)
+                break
+        del b
+    print("fuzz sweep:", count, "programs, kernels", kernels, "failures", failures)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

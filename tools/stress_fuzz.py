@@ -42,6 +42,38 @@ def random_program(rng, n_instr, n_regs):
     return "\n".join(L)
 
 
+def random_program2(rng, n_instr, n_regs):
+    """a second flavour: TRAM instructions anywhere (also inside SKIP shadows), longer and negative skip counts,
+    LOG/EXP of registers, more `ccr` traffic"""
+    regs = ["r%d" % i for i in range(n_regs)]
+    lits = ["0", "0.5", "-0.25", "1.0", "0.125", "-1", "0.999", "0.0625", "2"]
+    L = ["input in 0", "output out 0", "control c = 0.3", "static noise", "static rd", "static xd",
+         "itramsize %d " % rng.integers(1, 14), "xtramsize %d " % rng.integers(1, 40)] + ["static %s" % r for r in regs]
+    sat_ops = ["macs", "macsn", "acc3", "interp", "macints"]
+    for i in range(n_instr):
+        kind = rng.integers(0, 100)
+        src = lambda: str(rng.choice(regs + regs + regs + lits + ["in", "c", "out", "ccr", "noise", "rd", "xd"]))
+        dst = str(rng.choice(regs + ["out"]))
+        if kind < 55:
+            L.append("%s %s, %s, %s, %s" % (rng.choice(sat_ops), dst, src(), src(), src()))
+        elif kind < 63:
+            L.append("%s %s, %s, %s, %s" % (rng.choice(["macw", "macwn", "macintw", "macmv", "tstneg", "limit", "limitn", "andxor"]), dst, src(), src(), src()))
+        elif kind < 72:
+            L.append("%s %s, %s, %d, 0" % (rng.choice(["log", "exp"]), dst, str(rng.choice(regs[:2] + ["in", "c"])), rng.integers(0, 32)))
+        elif kind < 84 and i + 6 < n_instr:
+            L.append("skip ccr, ccr, %s, %d" % (rng.choice(["0", "2", "6", "8", "16", "20", "3"]), rng.integers(-1, 5)))
+        elif kind < 88:
+            L.append("idelay read, rd, at, 0")
+        elif kind < 92:
+            L.append("idelay write, %s, at, %d" % (str(rng.choice(regs + ["in"])), rng.integers(0, 2)))
+        elif kind < 96:
+            L.append("xdelay read, xd, at, 0")
+        else:
+            L.append("xdelay write, %s, at, 0" % str(rng.choice(regs + ["in"])))
+    L += ["macs %s, %s, %s, %s" % (regs[0], regs[0], regs[-1], "0.5"), "macs out, out, %s, 0.5" % regs[0], "end"]
+    return "\n".join(L)
+
+
 def main():
     n_prog = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
