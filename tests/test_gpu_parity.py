@@ -650,3 +650,41 @@ def test_cpp_drop_in_class_harness(gpu):
         ref = o.process_block(np.array([xin], dtype=np.float32))[0]
         assert abs(ref - yout) <= 1e-6 * max(1.0, abs(ref)), i  # printed with 6 significant digits
     assert "64 instructions" in out and "emulated MIPS" in out and "control: volume" in out
+
+
+def test_wav_front_end(gpu, tmp_path):
+    """host/fx8010_wav.cpp: a 16-bit stereo WAV through 5 instances with a swept control; the picked instance's float
+    WAV equals the oracle run on s/32768 with that instance's control value."""
+    import os
+    import struct
+    import subprocess
+    import wave
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "fx8010-emulator-core_amd")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(pkg, "csrc"), "wav"])
+    text = ("input l 0\ninput r 1\noutput ol 0\noutput or 1\ncontrol gain = 0.5\nstatic s\nitramsize 7 \nstatic rd\n"
+            "idelay read, rd, at, 0\nmacs s, l, r, gain\ninterp ol, ol, 0.25, s\nmacs or, rd, r, gain\nidelay write, s, at, 0\nend")
+    prog = tmp_path / "p.da"
+    prog.write_text(text)
+    rng = np.random.default_rng(3)
+    frames = 5000
+    pcm = rng.integers(-32768, 32767, size=(frames, 2), dtype=np.int16)
+    with wave.open(str(tmp_path / "in.wav"), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(48000)
+        w.writeframes(pcm.tobytes())
+    out = subprocess.run([os.path.join(pkg, "host", "fx8010_wav"), str(prog), str(tmp_path / "in.wav"), str(tmp_path / "out.wav"),
+                          "--instances", "5", "--pick", "3", "--block", "1024", "--sweep", "gain=0.1:0.9"],
+                         stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "5000 frames x 2 channel(s) x 5 instance(s)" in out
+    raw = (tmp_path / "out.wav").read_bytes()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE" and struct.unpack("<H", raw[20:22])[0] == 3
+    y = np.frombuffer(raw[44:], dtype=np.float32).reshape(frames, 2)
+    o = Oracle(2)
+    assert o.load_text(text), o.errors()
+    o.set_register("gain", float(np.float32(0.1) + (np.float32(0.9) - np.float32(0.1)) * np.float32(3) / np.float32(4)))
+    x = pcm.astype(np.float32) / np.float32(32768.0)
+    ref = o.process_block(x)
+    assert np.array_equal(bits(ref), bits(y))
