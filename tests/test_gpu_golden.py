@@ -1,0 +1,93 @@
+"""GPU path against the committed golden vectors (tests/golden/*.json: outputs of the UNMODIFIED reference, see
+tests/golden/make_golden.py) - directly, without the oracle in between.  The fixture's single instance is placed
+at several lanes of a batch (first, last lane of a wavefront, a ragged tail); every copy must reproduce the
+reference's output words, final register bits, instruction count and loader diagnostics."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fx8010_programs as progs
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as fh:
+        return json.load(fh)
+
+
+def f32(hexstr, shape=None):
+    a = np.frombuffer(bytes.fromhex(hexstr), dtype=np.uint32).view(np.float32)
+    return a.reshape(shape) if shape else a
+
+
+@pytest.fixture(params=["default", "asm", "hip"], ids=["xlate", "asm", "hip"])
+def tier(request, monkeypatch):
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    if request.param != "default":
+        monkeypatch.setenv("FX_KERNEL", request.param)
+    return request.param
+
+
+def run_case(gpu, case, text=None, N=67):
+    ch = case["channels"]
+    b = gpu.Batch(N, ch, 0)
+    ok = b.load_text(text if text is not None else case["program"])
+    assert ok == case["load_ok"], case["name"]
+    assert [list(e) for e in b.errors()] == [list(e) for e in case["errors"]], case["name"]
+    assert b.controls() == case["controls"] and b.meta() == case["meta"], case["name"]
+    if not ok:
+        return
+    x1 = f32(case["input"], case["shape"])  # [S] or [S, channels]
+    S = x1.shape[0]
+    x = np.repeat(x1.reshape(S, ch, 1), N, axis=2).reshape((S, N) if ch == 1 else (S, ch, N)).copy()
+    sets = {int(k): v for k, v in case.get("sets", {}).items()}
+    cuts = sorted(set([0] + list(sets) + [S]))
+    outs = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        for reg, val in sets.get(lo, []):
+            b.set_register(reg, val)
+        if hi > lo:
+            outs.append(b.process_block(x[lo:hi]))
+    y = np.concatenate(outs, axis=0)
+    want = f32(case["output"], case["shape"]).view(np.uint32)
+    for n in (0, 63, 64, N - 1):
+        got = (y[..., n] if ch == 1 else y[:, :, n]).view(np.uint32)
+        bad = np.nonzero(want.reshape(-1) != np.ascontiguousarray(got).reshape(-1))[0]
+        assert bad.size == 0, "%s instance %d: first mismatch at flat sample %d" % (case["name"], n, bad[0])
+        assert b.instruction_counter_i(n) == case["counter"], (case["name"], n)
+        for reg, bits in case["registers"].items():
+            assert b.get_register_bits_i(reg, n) == bits, (case["name"], reg, n)
+
+
+@pytest.mark.parametrize("fixture", ["opcodes.json", "known_answers.json", "slider.json", "feedback_delay.json"])
+def test_reference_vectors(gpu, tier, fixture):
+    for case in load(fixture):
+        run_case(gpu, case)  # (skip_over_end is a multi-pass program: it runs on the HIP kernel whatever tier is asked)
+
+
+def test_config_programs(gpu, tier):
+    for case in load("configs.json"):
+        text = progs.CONFIGS[case["config"]]()
+        run_case(gpu, dict(case), text=text)
+
+
+def test_lut_probe_all_exponents(gpu, tier):
+    probe = load("lut_probe.json")
+    x1 = f32(probe["input"])
+    S, N = x1.shape[0], 65
+    x = np.repeat(x1.reshape(S, 1), N, axis=1).copy()
+    hdr = "input in 0\noutput out 0\n"
+    for c in probe["cases"]:
+        op, e = c["name"][:3], int(c["name"][3:])
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(hdr + "%s out, in, %d, 0\nend" % (op, e))
+        y = b.process_block(x)
+        want = f32(c["output"]).view(np.uint32)
+        for n in (0, 64):
+            assert np.array_equal(np.ascontiguousarray(y[:, n]).view(np.uint32), want), (c["name"], n)
