@@ -688,3 +688,35 @@ def test_wav_front_end(gpu, tmp_path):
     x = pcm.astype(np.float32) / np.float32(32768.0)
     ref = o.process_block(x)
     assert np.array_equal(bits(ref), bits(y))
+
+
+@pytest.mark.parametrize("name", ["config4", "config5"])
+def test_full_size_shard(gpu, name, monkeypatch):
+    """BASELINE's per-GPU instance count (262 144): sampled instances across the whole shard against the oracle over
+    three blocks, and a size-independent property - instances fed the same PCM produce the same words wherever
+    they sit in the batch (first wavefront, middle, ragged end of the last one)."""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    N, S, blocks = 262144 - 37, 24, 3
+    text = progs.CONFIGS[name]()
+    x = progs.stimulus(N, S * blocks).copy()
+    twins = [5, 64 * 1000 + 63, N // 2 + 1, N - 1]
+    for t in twins[1:]:
+        x[:, t] = x[:, twins[0]]
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    ys = [b.process_block(x[i * S:(i + 1) * S]) for i in range(blocks)]
+    y = np.concatenate(ys, axis=0)
+    for t in twins[1:]:
+        assert np.array_equal(bits(y[:, t]), bits(y[:, twins[0]])), "instance %d differs from its twin" % t
+    total = 0
+    for n in (0, 63, 64, 4097, 99999, N // 2, N - 65, N - 2):
+        o = Oracle(1)
+        assert o.load_text(text)
+        ref = np.concatenate([o.process_block(x[i * S:(i + 1) * S, n].copy()) for i in range(blocks)])
+        assert np.array_equal(bits(ref), bits(y[:, n])), "instance %d" % n
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+        total += 1
+    assert b.ood_flags() == 0
+    if name == "config5":
+        assert b.instruction_counter() == N * 512 * S * blocks  # no SKIP: every instance executes every instruction
