@@ -111,6 +111,9 @@ bool g_parsed[2][ASM_VARIANTS] = {};
 std::string g_parseErr[2][ASM_VARIANTS];
 
 // ---- operands --------------------------------------------------------------------------------------------
+// operand texts are only needed for a listing; building them costs more than the encoding itself
+thread_local bool tlsWantText = false;
+
 struct Src {
     uint32_t code = 0;  // 9-bit source operand
     uint32_t lit = 0;
@@ -121,31 +124,31 @@ struct Src {
 Src vreg(int n) {
     Src s;
     s.code = 256u + (uint32_t)n;
-    s.text = "v" + std::to_string(n);
+    if (tlsWantText) s.text = "v" + std::to_string(n);
     return s;
 }
 Src vreg64(int n) {
     Src s;
     s.code = 256u + (uint32_t)n;
-    s.text = "v[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
+    if (tlsWantText) s.text = "v[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
     return s;
 }
 Src sreg(int n) {
     Src s;
     s.code = (uint32_t)n;
-    s.text = "s" + std::to_string(n);
+    if (tlsWantText) s.text = "s" + std::to_string(n);
     return s;
 }
 Src sreg64(int n) {
     Src s;
     s.code = (uint32_t)n;
-    s.text = "s[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
+    if (tlsWantText) s.text = "s[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
     return s;
 }
 Src named(uint32_t code, const char* text) {
     Src s;
     s.code = code;
-    s.text = text;
+    if (tlsWantText) s.text = text;
     return s;
 }
 
@@ -166,17 +169,19 @@ Src imm32(uint32_t bits, bool forceLiteral = false) {
     Src s;
     const int32_t iv = (int32_t)bits;
     if (!forceLiteral) {
-        if (iv >= 0 && iv <= 64) { s.code = 128u + (uint32_t)iv; s.text = std::to_string(iv); return s; }
-        if (iv >= -16 && iv <= -1) { s.code = 192u + (uint32_t)(-iv); s.text = std::to_string(iv); return s; }
+        if (iv >= 0 && iv <= 64) { s.code = 128u + (uint32_t)iv; if (tlsWantText) s.text = std::to_string(iv); return s; }
+        if (iv >= -16 && iv <= -1) { s.code = 192u + (uint32_t)(-iv); if (tlsWantText) s.text = std::to_string(iv); return s; }
         for (const InlineF& k : kInlineF32)
-            if (k.bits == bits) { s.code = k.code; s.text = k.text; return s; }
+            if (k.bits == bits) { s.code = k.code; if (tlsWantText) s.text = k.text; return s; }
     }
-    char buf[16];
-    std::snprintf(buf, sizeof(buf), "0x%x", bits);
     s.code = 255;
     s.lit = bits;
     s.hasLit = true;
-    s.text = buf;
+    if (tlsWantText) {
+        char buf[16];
+        std::snprintf(buf, sizeof(buf), "0x%x", bits);
+        s.text = buf;
+    }
     return s;
 }
 
@@ -185,28 +190,29 @@ class Emitter {
     static constexpr uint32_t DS_READ2_B32_OP = 0x37;
 
   public:
-    Emitter(std::vector<uint32_t>* words, std::string* listing) : w_(*words), text_(listing) {}
+    Emitter(std::vector<uint32_t>* words, std::string* listing) : w_(*words), text_(listing) { tlsWantText = listing != nullptr; }
 
     size_t bytes() const { return w_.size() * 4; }
     int count() const { return count_; }
 
     void vop2(uint32_t op, const char* name, int vdst, const Src& src0, int vsrc1, const char* tail = "") {
         put((op << 25) | ((uint32_t)vdst << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
-        line(std::string(name) + " v" + std::to_string(vdst) + ", " + src0.text + ", v" + std::to_string(vsrc1) + tail);
+        if (text_) line(std::string(name) + " v" + std::to_string(vdst) + ", " + src0.text + ", v" + std::to_string(vsrc1) + tail);
     }
     void vop1(uint32_t op, const char* name, const Src& vdst, const Src& src0) {
         put(0x7e000000u | ((vdst.code & 0xffu) << 17) | (op << 9) | src0.code, src0);
-        line(std::string(name) + " " + vdst.text + ", " + src0.text);
+        if (text_) line(std::string(name) + " " + vdst.text + ", " + src0.text);
     }
     void vopc(uint32_t op, const char* name, const Src& src0, int vsrc1) {
         put(0x7c000000u | (op << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
-        line(std::string(name) + " vcc, " + src0.text + ", v" + std::to_string(vsrc1));
+        if (text_) line(std::string(name) + " vcc, " + src0.text + ", v" + std::to_string(vsrc1));
     }
     // VOP3A: no literals on gfx9; neg = per-source negate bits
     void vop3(uint32_t op, const char* name, const Src& vdst, const Src& s0, const Src& s1, const Src* s2, uint32_t neg = 0) {
         w_.push_back(0xd0000000u | (op << 16) | (vdst.code & 0xffu));
         w_.push_back(s0.code | (s1.code << 9) | ((s2 ? s2->code : 0u) << 18) | (neg << 29));
         ++count_;
+        if (!text_) return;
         std::string t = std::string(name) + " " + vdst.text + ", " + ((neg & 1) ? "-" : "") + s0.text + ", " + ((neg & 2) ? "-" : "") + s1.text;
         if (s2) t += std::string(", ") + ((neg & 4) ? "-" : "") + s2->text;
         line(t);
@@ -216,21 +222,21 @@ class Emitter {
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | 106u);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
-        line(std::string(name) + " vcc, " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
+        if (text_) line(std::string(name) + " vcc, " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
     }
     void sop1(uint32_t op, const char* name, const Src& sdst, const Src& ssrc) {
         put(0xbe800000u | ((sdst.code & 0x7fu) << 16) | (op << 8) | ssrc.code, ssrc);
-        line(std::string(name) + " " + sdst.text + ", " + ssrc.text);
+        if (text_) line(std::string(name) + " " + sdst.text + ", " + ssrc.text);
     }
     void sop1NoDst(uint32_t op, const char* name, const Src& ssrc) {
         put(0xbe800000u | (op << 8) | ssrc.code, ssrc);
-        line(std::string(name) + " " + ssrc.text);
+        if (text_) line(std::string(name) + " " + ssrc.text);
     }
     void sop2(uint32_t op, const char* name, const Src& sdst, const Src& s0, const Src& s1) {
         // at most one literal, which then follows the instruction word
         const Src& l = s1.hasLit ? s1 : s0;
         put(0x80000000u | (op << 23) | ((sdst.code & 0x7fu) << 16) | (s1.code << 8) | s0.code, l);
-        line(std::string(name) + " " + sdst.text + ", " + s0.text + ", " + s1.text);
+        if (text_) line(std::string(name) + " " + sdst.text + ", " + s0.text + ", " + s1.text);
     }
     // global_{load,store}_dword with an SGPR base pair and a VGPR byte offset, no immediate offset
     void global(uint32_t op, bool load, int vdata, int vaddr, int sbase) {
@@ -238,20 +244,21 @@ class Emitter {
         w_.push_back((uint32_t)vaddr | (load ? 0u : (uint32_t)vdata << 8) | ((uint32_t)sbase << 16) | (load ? (uint32_t)vdata << 24 : 0u));
         ++count_;
         const std::string base = "s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]";
+        if (!text_) return;
         if (load) line("global_load_dword v" + std::to_string(vdata) + ", v" + std::to_string(vaddr) + ", " + base);
         else line("global_store_dword v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + ", " + base);
     }
     void waitVmcnt0() {
         w_.push_back(0xbf8c0f70u);
         ++count_;
-        line("s_waitcnt vmcnt(0)");
+        if (text_) line("s_waitcnt vmcnt(0)");
     }
     // global_load_dwordx2 / x4 into v[vdata ..], VGPR byte offset, SGPR base pair
     void globalLoadWide(uint32_t op, int dwords, int vdata, int vaddr, int sbase) {
         w_.push_back(0xdc008000u | (op << 18));
         w_.push_back((uint32_t)vaddr | ((uint32_t)sbase << 16) | ((uint32_t)vdata << 24));
         ++count_;
-        line("global_load_dwordx" + std::to_string(dwords) + " v[" + std::to_string(vdata) + ":" + std::to_string(vdata + dwords - 1) + "], v" +
+        if (text_) line("global_load_dwordx" + std::to_string(dwords) + " v[" + std::to_string(vdata) + ":" + std::to_string(vdata + dwords - 1) + "], v" +
              std::to_string(vaddr) + ", s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]");
     }
     // packed fp32 (VOP3P): dst and sources are 64-bit; an SGPR source is broadcast from its low dword (op_sel_hi 0);
@@ -260,64 +267,65 @@ class Emitter {
         w_.push_back(0xd3800000u | (op << 16) | 0x4000u | ((negSrc & 7u) << 8) | (uint32_t)vdst);
         w_.push_back(s0.code | (s1.code << 9) | (s0Broadcast ? 0x10000000u : 0x18000000u) | ((negSrc & 7u) << 29));
         ++count_;
+        if (!text_) return;
         std::string t = std::string(name) + " v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], " + s0.text + ", " + s1.text;
         if (s0Broadcast) t += " op_sel_hi:[0,1]";
         if (negSrc) {
             const std::string m = std::string("[") + ((negSrc & 1) ? "1" : "0") + "," + ((negSrc & 2) ? "1" : "0") + "]";
             t += " neg_lo:" + m + " neg_hi:" + m;
         }
-        line(t);
+        if (text_) line(t);
     }
     // LDS: reads return into v[vdst..], byte offset in the instruction (read2: two dword offsets)
     void dsRead(uint32_t op, const char* name, int dwords, int vdst, int vaddr, uint32_t offset) {
         w_.push_back(0xd8000000u | (op << 17) | (offset & 0xffffu));
         w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
         ++count_;
-        line(std::string(name) + " v[" + std::to_string(vdst) + ":" + std::to_string(vdst + dwords - 1) + "], v" + std::to_string(vaddr) +
+        if (text_) line(std::string(name) + " v[" + std::to_string(vdst) + ":" + std::to_string(vdst + dwords - 1) + "], v" + std::to_string(vaddr) +
              (offset ? " offset:" + std::to_string(offset) : ""));
     }
     void dsRead2B32(int vdst, int vaddr, uint32_t dword0, uint32_t dword1) {
         w_.push_back(0xd8000000u | (DS_READ2_B32_OP << 17) | (dword1 << 8) | dword0);
         w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
         ++count_;
-        line("ds_read2_b32 v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], v" + std::to_string(vaddr) +
+        if (text_) line("ds_read2_b32 v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], v" + std::to_string(vaddr) +
              (dword0 ? " offset0:" + std::to_string(dword0) : "") + " offset1:" + std::to_string(dword1));
     }
     void dsWriteB128(int vaddr, int vdata, uint32_t offset) {
         w_.push_back(0xd8000000u | (0xdfu << 17) | (offset & 0xffffu));
         w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
         ++count_;
-        line("ds_write_b128 v" + std::to_string(vaddr) + ", v[" + std::to_string(vdata) + ":" + std::to_string(vdata + 3) + "]" +
+        if (text_) line("ds_write_b128 v" + std::to_string(vaddr) + ", v[" + std::to_string(vdata) + ":" + std::to_string(vdata + 3) + "]" +
              (offset ? " offset:" + std::to_string(offset) : ""));
     }
     void waitLgkm0() {
         w_.push_back(0xbf8cc07fu);
         ++count_;
-        line("s_waitcnt lgkmcnt(0)");
+        if (text_) line("s_waitcnt lgkmcnt(0)");
     }
     // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
     void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | (sdst.code & 0xffu));
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
-        line(std::string(name) + " " + sdst.text + ", " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
+        if (text_) line(std::string(name) + " " + sdst.text + ", " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
     }
     // VOPC in its VOP3 form with an SGPR-pair destination
     void vop3cmpTo(uint32_t op, const char* name, int sdst, const Src& s0, const Src& s1) {
         w_.push_back(0xd0000000u | (op << 16) | (uint32_t)sdst);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
-        line(std::string(name) + " s[" + std::to_string(sdst) + ":" + std::to_string(sdst + 1) + "], " + s0.text + ", " + s1.text);
+        if (text_) line(std::string(name) + " s[" + std::to_string(sdst) + ":" + std::to_string(sdst + 1) + "], " + s0.text + ", " + s1.text);
     }
     void sopc(uint32_t op, const char* name, const Src& s0, const Src& s1) {
         w_.push_back(0xbf000000u | (op << 16) | (s1.code << 8) | s0.code);
         ++count_;
-        line(std::string(name) + " " + s0.text + ", " + s1.text);
+        if (text_) line(std::string(name) + " " + s0.text + ", " + s1.text);
     }
     void sopp(uint32_t op, const char* name, uint32_t simm, bool showImm) {
         w_.push_back(0xbf800000u | (op << 16) | (simm & 0xffffu));
         ++count_;
-        line(showImm ? std::string(name) + " " + std::to_string(simm) : std::string(name));
+        if (text_) line(showImm ? std::string(name) + " " + std::to_string(simm) : std::string(name));
     }
 
   private:
@@ -329,6 +337,7 @@ class Emitter {
     void line(const std::string& t) {
         if (text_) { *text_ += t; *text_ += '\n'; }
     }
+    bool listing() const { return text_ != nullptr; }
     std::vector<uint32_t>& w_;
     std::string* text_;
     int count_ = 0;
@@ -882,7 +891,7 @@ class Translator {
     Src pairTemp(int v) const {
         Src s;
         s.code = 256u + (uint32_t)v;
-        s.text = "v[" + std::to_string(v) + ":" + std::to_string(v + 1) + "]";
+        if (tlsWantText) s.text = "v[" + std::to_string(v) + ":" + std::to_string(v + 1) + "]";
         return s;
     }
     // a uniform as the (broadcast) SGPR source of a packed instruction
