@@ -262,7 +262,9 @@ int Batch::ensureLowered() {
     // upload: steady | last | row table
     useXlate_ = false;
     xlateDeferred_ = false;
-    if (useAsm_ && asmVariant_ != ASM_LDS && controlHeat_ > 0 && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0)) {
+    // (a block of more than ~half a millisecond of translated code pays for its translation at once)
+    const double blockMs = (double)n_ * (double)pendingSamples_ * (double)std::max(low_.staticCount, 1) / 1e10;
+    if (useAsm_ && asmVariant_ != ASM_LDS && controlHeat_ > 0 && blockMs < 0.5 && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0)) {
         // controls are moving (a set_register within the last few blocks): a translation costs a module load
         // (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until the controls have been quiet
         xlateDeferred_ = true;
@@ -444,6 +446,7 @@ int Batch::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
 int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
     (void)hipSetDevice(device_);
     if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
+    pendingSamples_ = nSamples;
     if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;  // quiet again: translate
     int rc = ensureLowered();
     if (rc != 0) return rc;

@@ -99,6 +99,7 @@ private:
     // control changes re-lower; while they keep coming the interpreter tier is used (see ensureLowered)
     static constexpr int kHeatPerChange = 8;  // blocks a change keeps the translation deferred
     int controlHeat_ = 0;
+    int pendingSamples_ = 0;  // block length of the call that triggered the lowering
     bool xlateDeferred_ = false, everLowered_ = false;
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;

@@ -489,6 +489,14 @@ def test_control_changes_defer_the_translation(gpu, monkeypatch):
     assert all(2 <= t <= 8 for t in tiers[3:12])    # interpreter while the slider moves
     assert tiers[-1] >= 9                           # translated again after the quiet period
     assert b.instruction_counter_i(5) == o.instruction_counter()
+    # a long block is worth a translation even while the slider moves
+    big = gpu.Batch(70000, 1, 0)
+    assert big.load_text(progs.config5())
+    xb = progs.stimulus(70000, 256)
+    big.process_block(xb)
+    big.set_register(big.controls()[0], 0.3)
+    big.process_block(xb)
+    assert big.info("kernel") >= 9
 
 
 def test_register_arrays_per_instance_automation(gpu, k):
