@@ -138,9 +138,15 @@ def main():
     rank, local, world = shard.env_world()
     if world == 1:
         local = 0
+    # rehearsal on a box with fewer GPUs than ranks (FX_BENCH_REHEARSAL=1): ranks share the devices round-robin and
+    # meet over gloo instead of RCCL, which refuses two ranks on one device - same code path otherwise
+    rehearsal = os.environ.get("FX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = shard.init_process_group("nccl", dev)  # RCCL; None for a single process
+    dist = shard.init_process_group("gloo" if rehearsal else "nccl", dev)  # RCCL; None for a single process
+    reduce_dev = "cpu" if rehearsal else dev
 
     text = progs.CONFIGS[args.config]()
     n_inst = args.instances or progs.CONFIG_INSTANCES[args.config]
@@ -188,8 +194,8 @@ def main():
     executed = batch.instruction_counter() - c0  # reference counting: END/SKIP count, skipped don't
     ood = batch.ood_flags()
 
-    elapsed = shard.reduce_scalar(dist, elapsed, "max", dev)            # slowest rank
-    executed_all = shard.reduce_scalar(dist, executed, "sum", dev)      # whole job
+    elapsed = shard.reduce_scalar(dist, elapsed, "max", reduce_dev)            # slowest rank
+    executed_all = shard.reduce_scalar(dist, executed, "sum", reduce_dev)      # whole job
 
     if rank == 0:
         mips = executed_all / elapsed / 1e6
