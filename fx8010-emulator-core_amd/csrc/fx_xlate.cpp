@@ -776,14 +776,24 @@ class Translator {
             e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), value(r.w[2]));
             return true;
         }
+        // a multiplier of exactly +-1.0 needs no multiplication: x * 1.0 is x for every x (denormals kept, NaN stays NaN)
+        int pv = 3;
         bool inV3;
-        if (!product(r, kind, &inV3)) return false;
+        const uint32_t unitWord = ((kind & 6u) == 2u) ? r.w[3] : ((kind & 6u) == 4u) ? r.w[4] : 0u;
+        if ((unitWord & 0x7fffffffu) == 0x3f800000u) {
+            if (!row((kind & 6u) == 2u ? r.w[4] : r.w[3], &pv)) return false;
+            if (unitWord >> 31) neg = !neg;
+            inV3 = true;
+            ++stats_.unitMultipliers;
+        } else if (!product(r, kind, &inV3)) {
+            return false;
+        }
         const bool within = resultWithinUnit(neg ? 1 : 0, kind, r);  // then the sum goes straight to its row
         const int d = within ? vR : 2;
         if (inV3) {
             Src a;
             if (!operand(r.w[2], kind & 1, &a)) return false;
-            e_.vop2(neg ? VOP2_SUB_F32 : VOP2_ADD_F32, neg ? "v_sub_f32_e32" : "v_add_f32_e32", d, a, 3);
+            e_.vop2(neg ? VOP2_SUB_F32 : VOP2_ADD_F32, neg ? "v_sub_f32_e32" : "v_add_f32_e32", d, a, pv);
         } else {
             int vA;
             if (!row(r.w[2], &vA)) return false;
@@ -839,6 +849,12 @@ class Translator {
         if (kind == 7) {
             e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), value(r.w[2]));
             return true;
+        }
+        if ((kind & 6u) == 4u && r.w[4] == 0x3f800000u) {  // Y = 1.0: the product is X itself
+            int vX;
+            if (!row(r.w[3], &vX)) return false;
+            ++stats_.unitMultipliers;
+            return interpTail(r, kind, vreg(vX), vR);
         }
         bool inV3;
         if (!product(r, kind, &inV3)) return false;
