@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5"])
+    ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5", "tram_bound"])
     ap.add_argument("--samples", type=int, default=4096, help="sample periods per step (block length S; SURVEY 8d: 4096)")
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (0 = BASELINE.json's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only); 0 disables")

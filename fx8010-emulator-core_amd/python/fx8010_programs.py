@@ -176,6 +176,21 @@ def config5(pairs=4):
     return "\n".join(L)
 
 
+def tram_bound(pairs=16):
+    """Not a BASELINE configuration: a delay-line-dominated program (16 xTRAM reads + 16 writes around 34 cheap
+    instructions, 136 algorithmic bytes per instance-sample) that puts the HBM side of the roofline to the test."""
+    L = [_HEADER.format(name="tram_bound", comment="memory-bound probe: 16 xtram taps")]
+    L += ["xtramsize 8192 ", "input in 0", "output out 0", "static m"]
+    L += ["static d%d" % j for j in range(pairs)] + ["static w%d" % j for j in range(pairs)]
+    body = ["xdelay read, d%d, at, 0" % j for j in range(pairs)]
+    body.append("macs m, 0, in, 0.5")
+    for j in range(pairs):
+        body.append("macs w%d, m, d%d, 0.45" % (j, (j + 1) % pairs))
+    body.append("macs out, 0, w0, 0.5")
+    body += ["xdelay write, w%d, at, 0" % j for j in range(pairs)]
+    return "\n".join(L + body + ["end"])
+
+
 CONFIGS = {
     "config1_shipped": config1_shipped,
     "config1_logtube": config1_logtube,
@@ -183,10 +198,11 @@ CONFIGS = {
     "config3": config3,
     "config4": config4,
     "config5": config5,
+    "tram_bound": tram_bound,
 }
 
 # instances / samples BASELINE.json quotes per config (config 5: per-GPU shard of 2 097 152 / 8)
-CONFIG_INSTANCES = {"config1_shipped": 1, "config1_logtube": 1, "config2": 4096, "config3": 65536, "config4": 262144, "config5": 262144}
+CONFIG_INSTANCES = {"config1_shipped": 1, "config1_logtube": 1, "config2": 4096, "config3": 65536, "config4": 262144, "config5": 262144, "tram_bound": 262144}
 
 
 def count_instructions(text):

@@ -78,7 +78,7 @@ def check_batch(gpu, text, x, regs=("ccr",), channels=1, instances=None, blocks=
     return b, y
 
 
-@pytest.mark.parametrize("name", ["config1_shipped", "config1_logtube", "config2", "config3", "config4", "config5"])
+@pytest.mark.parametrize("name", ["config1_shipped", "config1_logtube", "config2", "config3", "config4", "config5", "tram_bound"])
 def test_config_programs_bit_exact(gpu, name, k):
     text = progs.CONFIGS[name]()
     N, S = 130, 257  # ragged last wavefront, odd block length
@@ -86,7 +86,7 @@ def test_config_programs_bit_exact(gpu, name, k):
     regs = {"config2": ("t", "s30", "in", "out", "ccr"), "config3": ("rd", "a", "t", "ccr"), "config4": ("x", "a", "b", "o", "ccr"),
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
     b, _ = check_batch(gpu, text, x, regs=regs)
-    if k == "xlate2" and name in ("config2", "config3", "config5"):
+    if k == "xlate2" and name in ("config2", "config3", "config5", "tram_bound"):
         assert b.info("kernel") >= 20  # these translate for the pair frame
     if isinstance(k, str):
         want = {"default": tuple(range(9, 16)), "xlate2": tuple(range(9, 24)), "xlate_v256": (15,), "asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
