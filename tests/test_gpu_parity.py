@@ -728,3 +728,64 @@ def test_full_size_shard(gpu, name, monkeypatch):
     assert b.ood_flags() == 0
     if name == "config5":
         assert b.instruction_counter() == N * 512 * S * blocks  # no SKIP: every instance executes every instruction
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_api_sequences(gpu, seed, monkeypatch):
+    """Random sequences of the calls a host makes between blocks - block lengths from 1 sample up, broadcast control
+    changes (they re-lower, defer the translation, bring it back), per-instance and whole-array register writes,
+    register reads - mirrored on one oracle per checked instance.  Exercises every tier transition with live state."""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    rng = np.random.default_rng(4200 + seed)
+    text = ("itramsize 9 \nxtramsize 21 \n" + HDR + "control mix = 0.25\nstatic t\nstatic u\n"
+            "idelay read, rd, at, 0\nxdelay read, t, at, 0\n"
+            "macs a, a, vol, in\ninterp b, b, mix, a\nmacsn u, t, rd, mix\n"
+            + ("log u, u, 3, 0\n" if seed % 2 else "macs u, u, b, 0.5\n")
+            + ("macs t, u, 0, 0\nskip ccr, ccr, 6, 1\nmacs u, u, noise, 0.125\n" if seed % 3 == 0 else "")
+            + "idelay write, b, at, 0\nxdelay write, u, at, 0\nmacs out, u, b, vol\nend")
+    N = 150
+    check = [0, 63, 64, 149]
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    oracles = {}
+    for n in check:
+        o = Oracle(1)
+        assert o.load_text(text)
+        oracles[n] = o
+    pos = 0
+    x = progs.stimulus(N, 2000)
+    tiers = set()
+    for step in range(40):
+        op = rng.integers(0, 10)
+        if op < 5:
+            S = int(rng.choice([1, 2, 7, 8, 33, 64]))
+            xs = x[pos:pos + S]
+            pos += S
+            y = b.process_block(xs)
+            tiers.add(b.info("kernel"))
+            for n in check:
+                ref = oracles[n].process_block(xs[:, n].copy())
+                assert np.array_equal(bits(ref), bits(y[:, n])), "seed %d step %d instance %d (kernel %d)" % (seed, step, n, b.info("kernel"))
+        elif op < 7:
+            name, v = str(rng.choice(["vol", "mix"])), float(np.float32(rng.uniform(0.0, 1.0)))
+            assert b.set_register(name, v) == 0
+            for o in oracles.values():
+                o.set_register(name, v)
+        elif op < 8:
+            name, n, v = str(rng.choice(["a", "vol", "u"])), int(rng.choice(check)), float(np.float32(rng.uniform(-1.0, 1.0)))
+            assert b.set_register_i(name, n, v) == 0
+            oracles[n].set_register(name, v)
+        elif op < 9:
+            vals = rng.uniform(0.0, 1.0, size=N).astype(np.float32)
+            assert b.set_register_array("mix", vals) == 0
+            for n in check:
+                oracles[n].set_register("mix", float(vals[n]))
+        else:
+            for n in check:
+                for r in ("a", "b", "u", "t", "rd", "vol", "mix", "ccr"):
+                    assert b.get_register_bits_i(r, n) == oracles[n].get_register_bits(r), "seed %d step %d %s[%d]" % (seed, step, r, n)
+    for n in check:
+        assert b.instruction_counter_i(n) == oracles[n].instruction_counter()
+    assert b.ood_flags() == 0
+    assert len(tiers) >= 1
