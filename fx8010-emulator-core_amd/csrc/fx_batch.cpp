@@ -198,6 +198,8 @@ int Batch::chooseInstPerLane() const {
     return 1;
 }
 
+bool Batch::intrinsicLane(int reg) const { return reg >= 0 && (size_t)reg < intrinsicLane_.size() && intrinsicLane_[reg] != 0; }
+
 bool Batch::laneResident(int reg) const {
     if (reg < (int)forcedLane_.size() && forcedLane_[reg]) return true;
     return !lowDirty_ ? low_.rowOfReg[reg] >= 0 : (reg < (int)low_.rowOfReg.size() && low_.rowOfReg[reg] >= 0);
@@ -256,6 +258,9 @@ int Batch::ensureLowered() {
         if (fresh.rowOfReg[r] >= 0 && !was && !forced) { rows.push_back((uint32_t)r); values.push_back(bitsOf(hostValue_[r])); }
     }
     low_ = std::move(fresh);
+    // registers the program itself keeps per-instance (it writes them): a static property, valid until the next load
+    intrinsicLane_.assign(low_.rowOfReg.size(), 0);
+    for (size_t r = 0; r < low_.rowOfReg.size(); ++r) intrinsicLane_[r] = low_.rowOfReg[r] >= 0 && !forcedLane_[r];
     if (!rows.empty() && (rc = fillRows(rows, values)) != 0) return rc;
     if ((rc = ensureTram()) != 0) return rc;
 
@@ -362,11 +367,13 @@ int Batch::setRegister(const std::string& key, float v) {
     const int r = prog_.findRegister(key);
     if (r < 0) return 1;
     hostValue_[r] = v;
-    const bool resident = laneResident(r);
     forcedLane_[r] = 0;  // every instance holds the same value again
     lowDirty_ = true;    // immediates (and possibly the classification) change
     if (loaded_ && everLowered_) controlHeat_ = kHeatPerChange;
-    if (resident && dState_) {
+    if (dState_) {
+        // Invariant: the state row of EVERY register holds its current value for every instance, also while the
+        // register is uniform (folded into the code) - so that a later per-instance write only has to force the
+        // register per-lane, whatever the lowering in force says about it.
         if (lastStream_) (void)hipStreamSynchronize(lastStream_);
         int rc = fillRows({(uint32_t)r}, {bitsOf(v)});
         if (rc != 0) return rc;
@@ -381,9 +388,7 @@ int Batch::setRegisterAt(const std::string& key, int64_t inst, float v) {
     if (inst < 0 || inst >= n_) return fail(FX_E_ARG, "instance out of range");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
     if (lastStream_) (void)hipStreamSynchronize(lastStream_);
-    if (!laneResident(r)) {
-        int rc = fillRows({(uint32_t)r}, {bitsOf(hostValue_[r])});
-        if (rc != 0) return rc;
+    if (!forcedLane_[r] && !intrinsicLane(r)) {  // (the row is valid, see setRegister; the next lowering keeps the register per-lane)
         forcedLane_[r] = 1;
         lowDirty_ = true;
     }
@@ -399,7 +404,7 @@ int Batch::setRegisterArray(const std::string& key, const float* values) {
     if (!values) return fail(FX_E_ARG, "null buffer");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
     if (lastStream_) (void)hipStreamSynchronize(lastStream_);
-    if (!laneResident(r)) {  // uniform so far: from now on a per-instance row (every lane is overwritten below)
+    if (!forcedLane_[r] && !intrinsicLane(r)) {  // from now on a per-instance row (every lane is overwritten below)
         forcedLane_[r] = 1;
         lowDirty_ = true;
     }

@@ -58,12 +58,14 @@ private:
     int ensureTram();
     int fillRows(const std::vector<uint32_t>& rows, const std::vector<uint32_t>& values);
     bool laneResident(int reg) const;
+    bool intrinsicLane(int reg) const;
     int chooseInstPerLane() const;
     hipStream_t pick(hipStream_t s) const { return s ? s : stream_; }
 
     Program prog_;
     std::vector<float> hostValue_;      // current value of every register as the host knows it
     std::vector<uint8_t> forcedLane_;   // registers given per-instance values by setRegisterAt
+    std::vector<uint8_t> intrinsicLane_; // registers per-instance because the program writes them (as of the last lowering)
     Lowered low_;
     bool lowDirty_ = true;
     bool loaded_ = false;
