@@ -1,0 +1,112 @@
+"""Random programs x random host call sequences against the oracle (default tier; FX_KERNEL pins another).
+
+    python tools/fuzz_api.py [first_seed] [count]
+"""
+import os
+import sys
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "fx8010-emulator-core_amd/python"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+
+import fx8010_amd as A  # noqa: E402
+import fx8010_programs as P  # noqa: E402
+import stress_fuzz  # noqa: E402
+from pyoracle import Oracle  # noqa: E402
+
+
+def same(ref, got):
+    ref = np.asarray(ref, dtype=np.float32).reshape(-1)
+    got = np.asarray(got, dtype=np.float32).reshape(-1)
+    rn, gn = np.isnan(ref), np.isnan(got)
+    return np.array_equal(rn, gn) and np.array_equal(ref.view(np.uint32)[~rn], got.view(np.uint32)[~gn])
+
+
+WILD = os.environ.get("FX_FUZZ_WILD") == "1"  # register values beyond [-1, 1] (state that breaks the bounded-row class)
+
+
+def value(rng):
+    if WILD and rng.uniform() < 0.3:
+        return float(np.float32(rng.choice([2.5, -3.0, 1.0000001, 100.0, 1e30, -1e-40])))
+    return float(np.float32(rng.uniform(-1.0, 1.0)))
+
+
+def run(seed, verbose=False):
+    rng = np.random.default_rng(880000 + seed)
+    gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
+    n_regs = int(rng.integers(3, 30))
+    text = gen(rng, int(rng.integers(6, 70)), n_regs)
+    N = int(rng.choice([1, 63, 64, 65, 130, 200]))
+    check = sorted(set([0, N - 1, N // 2]))
+    b = A.Batch(N, 1, 0)
+    if not b.load_text(text):
+        return True
+    oracles = {}
+    for n in check:
+        o = Oracle(1)
+        o.load_text(text)
+        oracles[n] = o
+    x = P.stimulus(N, 1200)
+    pos = 0
+    names = ["c", "r0", "r1", "r%d" % (n_regs - 1), "out"]
+    for step in range(30):
+        op = rng.integers(0, 12)
+        if op < 6:
+            S = int(rng.choice([1, 3, 8, 16, 40]))
+            xs = x[pos:pos + S]
+            pos += S
+            y = b.process_block(xs)
+            for n in check:
+                ref = oracles[n].process_block(xs[:, n].copy())
+                if oracles[n].ood_flags():
+                    return True  # left the parity domain: nothing to compare from here on
+                if not same(ref, y[:, n]):
+                    print("MISMATCH seed %d step %d instance %d kernel %d" % (seed, step, n, b.info("kernel")))
+                    return False
+        elif op < 8:
+            name, v = str(rng.choice(names)), value(rng)
+            b.set_register(name, v)
+            for o in oracles.values():
+                o.set_register(name, v)
+        elif op < 9:
+            name, n, v = str(rng.choice(names)), int(rng.choice(check)), value(rng)
+            b.set_register_i(name, n, v)
+            oracles[n].set_register(name, v)
+        elif op < 10:
+            name = str(rng.choice(names))
+            vals = np.array([value(rng) for _ in range(N)], dtype=np.float32)
+            b.set_register_array(name, vals)
+            for n in check:
+                oracles[n].set_register(name, float(vals[n]))
+        elif op < 11:
+            n = int(rng.choice(check))
+            s1, s2 = int(rng.integers(-2**31, 2**31)), int(rng.integers(-2**31, 2**31))
+            b.seed_noise_i(n, s1, s2)
+            oracles[n].seed_noise(s1, s2)
+        else:
+            for n in check:
+                for r in names + ["ccr"]:
+                    gb, rb = b.get_register_bits_i(r, n), oracles[n].get_register_bits(r)
+                    gf, rf = np.array([gb], dtype=np.uint32).view(np.float32)[0], np.array([rb], dtype=np.uint32).view(np.float32)[0]
+                    if gb != rb and not (np.isnan(gf) and np.isnan(rf)):
+                        print("REGISTER seed %d step %d %s[%d] %08x %08x kernel %d" % (seed, step, r, n, gb, rb, b.info("kernel")))
+                        return False
+    for n in check:
+        if b.instruction_counter_i(n) != oracles[n].instruction_counter():
+            print("COUNTER seed %d instance %d" % (seed, n))
+            return False
+    return True
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    bad = [s for s in range(first, first + count) if not run(s)]
+    print("api fuzz:", count, "sequences, failures", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
