@@ -187,7 +187,7 @@ Src imm32(uint32_t bits, bool forceLiteral = false) {
 
 // ---- instruction emitter -----------------------------------------------------------------------------------
 class Emitter {
-    static constexpr uint32_t DS_READ2_B32_OP = 0x37;
+    static constexpr uint32_t DS_READ2_B32_OP = 0x37, VOP2_ADDC_OP = 0x1c;
 
   public:
     Emitter(std::vector<uint32_t>* words, std::string* listing) : w_(*words), text_(listing) { tlsWantText = listing != nullptr; }
@@ -298,6 +298,27 @@ class Emitter {
         if (text_) line("ds_write_b128 v" + std::to_string(vaddr) + ", v[" + std::to_string(vdata) + ":" + std::to_string(vdata + 3) + "]" +
              (offset ? " offset:" + std::to_string(offset) : ""));
     }
+    void dsWriteB64(int vaddr, int vdata, uint32_t offset) {
+        w_.push_back(0xd8000000u | (0x4du << 17) | (offset & 0xffffu));
+        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
+        ++count_;
+        if (text_) line("ds_write_b64 v" + std::to_string(vaddr) + ", v[" + std::to_string(vdata) + ":" + std::to_string(vdata + 1) + "]" +
+                        (offset ? " offset:" + std::to_string(offset) : ""));
+    }
+    // v = v + carry (VCC in and out)
+    void addCarry(int v) {
+        w_.push_back((VOP2_ADDC_OP << 25) | ((uint32_t)v << 17) | ((uint32_t)v << 9) | 128u);
+        ++count_;
+        if (text_) line("v_addc_co_u32_e32 v" + std::to_string(v) + ", vcc, 0, v" + std::to_string(v) + ", vcc");
+    }
+    // v = v - borrow, borrow in from the SGPR pair `sin`, borrow out to the pair `sout`
+    void subBorrow(int v, int sin, int sout) {
+        w_.push_back(0xd0000000u | (0x11eu << 16) | ((uint32_t)sout << 8) | (uint32_t)v);
+        w_.push_back(128u | ((256u + (uint32_t)v) << 9) | ((uint32_t)sin << 18));
+        ++count_;
+        if (text_) line("v_subbrev_co_u32_e64 v" + std::to_string(v) + ", s[" + std::to_string(sout) + ":" + std::to_string(sout + 1) + "], 0, v" +
+                        std::to_string(v) + ", s[" + std::to_string(sin) + ":" + std::to_string(sin + 1) + "]");
+    }
     void waitLgkm0() {
         w_.push_back(0xbf8cc07fu);
         ++count_;
@@ -355,6 +376,7 @@ enum : uint32_t {
     VOP3P_PK_MUL_F32 = 0x31, VOP3P_PK_ADD_F32 = 0x32,
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
     SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
+    VOP2_ADDC_CO_U32 = 0x1c, VOP3B_SUBBREV_CO_U32 = 0x11e,
     VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49,
     VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
@@ -381,7 +403,8 @@ constexpr int kSPairConst = 28;   // s[28:29]: uniform operand of a packed instr
 constexpr int kSPairTile = 26;    // s26 / s27 = bytes of one iTRAM / xTRAM tile (half 1's tile follows half 0's)
 constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
 constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
-constexpr uint32_t kLdsXthr = 0, kLdsXdom = 264, kLdsX1 = 272, kLdsSeg = 784, kLdsSegBytes = 1024;  // LUT tables in LDS
+// LUT tables in LDS: fp32 thresholds (66) + domain bounds (2), then per table 64 entries {slope, y1, x1, pad} of 32 bytes
+constexpr uint32_t kLdsXthr = 0, kLdsXdom = 264, kLdsSeg = 272, kLdsSegBytes = 2048;
 constexpr int kSLut = 40;          // s[40:41] = LUT blob
 constexpr int kSLutXthr = 88, kSLutX1 = 90, kSLutSeg = 92;  // s[88:93]: bases of the fp32 thresholds, x1[] and the current table's segments
 constexpr int kSTramBase[2] = {36, 38}, kSTramSize[2] = {56, 57}, kSTramSlots[2] = {46, 47};  // [iTRAM, xTRAM]
@@ -521,11 +544,15 @@ class Translator {
             segKnown_ = true;
             segOff_ = r.w[3];
         }
+        // An operand of the BOUNDED class lies in [-1, 1] while the wave runs the fast stream: the guess and the corrected
+        // index are in 0..63 by construction and nothing can be out of the domain.  Everywhere else (wild operand, or the
+        // exact stream, which a wave enters precisely when that invariant broke) the index is clamped and the flag derived.
+        const bool guarded = operandWild || !fast_;
         e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x3f800000u), vA);
         e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 6, imm32(0x41fc0000u), 6);                  // * 31.5
         e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
-        Src zero = imm32(0), top = imm32(63);
-        e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
+        Src zero = imm32(0), top = imm32(63), vcc = named(106, "vcc");
+        if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
         e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
         if (lds) {
             e_.dsRead2B32(8, 7, kLdsXthr / 4, kLdsXthr / 4 + 1);
@@ -538,18 +565,15 @@ class Translator {
         e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));      // x <  xthr[g]  : one down
         // (two instructions between a VALU write of VCC / an SGPR pair and the VALU read of it)
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
-        Src one = imm32(1), vcc = named(106, "vcc"), tmp = sreg64(kSTemp);
-        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(10), zero, one, &vcc);
-        e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(11), zero, one, &tmp);
-        e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 6, vreg(6), 10);
-        e_.vop2(VOP2_SUB_U32, "v_sub_u32_e32", 6, vreg(6), 11);
-        e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
+        e_.addCarry(6);
+        e_.subBorrow(6, kSTemp, kSTemp + 2);
+        if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
         if (lds) {
-            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
-            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, kLdsX1);                        // x1[idx]
-            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
-            e_.dsRead(DS_READ_B128, "ds_read_b128", 4, 2, 7, kLdsSeg + (uint32_t)ldsTable * kLdsSegBytes);  // slope, y1
-            if (operandWild) {
+            const uint32_t table = kLdsSeg + (uint32_t)ldsTable * kLdsSegBytes;
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(5), 6);
+            e_.dsRead(DS_READ_B128, "ds_read_b128", 4, 2, 7, table);                        // slope, y1
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, table + 16);                    // x1[idx]
+            if (guarded) {
                 e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
                 e_.dsRead2B32(8, 7, kLdsXdom / 4, kLdsXdom / 4 + 1);
             }
@@ -559,8 +583,7 @@ class Translator {
             e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                     // x1[idx]
             e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
             e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                     // slope, y1
-            if (operandWild) {
-                // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it
+            if (guarded) {
                 e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutXdomOff * 8, true));
                 e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
                 e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
@@ -568,7 +591,8 @@ class Translator {
             }
             e_.waitVmcnt0();
         }
-        if (operandWild) {
+        if (guarded) {
+            // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it
             e_.vopc(VOPC_CMP_NGE_F32, "v_cmp_nge_f32_e32", vreg(vA), 8);
             e_.vop3cmpTo(VOP3_CMP_NLT_F32, "v_cmp_nlt_f32_e64", kSTemp, vreg(vA), vreg(9));
             e_.sop2(SOP2_OR_B64, "s_or_b64", named(106, "vcc"), named(106, "vcc"), sreg64(kSTemp));
@@ -1434,10 +1458,23 @@ void emitLdsCopy(Emitter& e, uint32_t blobOff, uint32_t ldsOff, uint32_t bytes) 
 
 void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string* listing) {
     Emitter e(code, listing);
-    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 2, imm32(4), 0);  // v0 = lane
+    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 2, imm32(4), 0);  // v2 = lane * 16 (v0 = lane)
     emitLdsCopy(e, (uint32_t)kLutXthrOff * 8, kLdsXthr, 272);    // fp32 thresholds + domain bounds (adjacent in the blob)
-    emitLdsCopy(e, (uint32_t)kLutX1Off * 8, kLdsX1, 512);
-    for (size_t k = 0; k < prog.lutTables.size(); ++k) emitLdsCopy(e, prog.lutTables[k], kLdsSeg + (uint32_t)k * kLdsSegBytes, kLdsSegBytes);
+    // x1[lane] once, then per table the lane's {slope, y1}: LDS entry lane = {slope, y1, x1, -}
+    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(3), 0);  // lane * 8
+    e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutX1Off * 8, true));
+    e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
+    e.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 3, kSAddr);
+    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(5), 0);  // lane * 32
+    for (size_t k = 0; k < prog.lutTables.size(); ++k) {
+        const uint32_t table = kLdsSeg + (uint32_t)k * kLdsSegBytes;
+        e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32(prog.lutTables[k], true));
+        e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
+        e.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 4, 2, kSAddr);
+        e.waitVmcnt0();
+        e.dsWriteB128(3, 4, table);
+        e.dsWriteB64(3, 8, table + 16);
+    }
     e.waitLgkm0();
     e.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSReturn));
 }
@@ -1465,12 +1502,12 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
     }
     p.uniformCursors = any && ok;
 
-    // LOG/EXP tables the inline code uses (per-lane operand): up to 8 of them go to LDS
+    // LOG/EXP tables the inline code uses (per-lane operand): up to 4 of them go to LDS (2 KB each per wavefront)
     for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords})
         for (const MicroOp& r : *recs)
             if (r.w[0] == AS_LUT && !(r.w[6] & 1u) && std::find(p.lutTables.begin(), p.lutTables.end(), r.w[3]) == p.lutTables.end())
                 p.lutTables.push_back(r.w[3]);
-    if (p.lutTables.size() > 8) p.lutTables.clear();
+    if (p.lutTables.size() > 4) p.lutTables.clear();
 
     // Row classes.  BOUNDED: every value the row can hold lies in [-1, 1] - its writers saturate, or pass a bounded
     // value on - given that it started there (the template checks the state rows of this class, and inline TRAM
