@@ -382,6 +382,37 @@ def test_saturation_elision_is_sound(gpu, k):
         assert b.info("xlate_unsaturated") >= 3
 
 
+def test_log_of_a_bounded_row_that_was_set_beyond_one(gpu, k):
+    """LOG/EXP of a register the program only ever saturates needs no clamps - unless the host put 5.0 there: the
+    taint check at block start moves the wave to the exact stream, whose LOG clamps the index and raises the
+    out-of-domain flag exactly as the oracle defines it (flag 16 on that instance only)."""
+    text = HDR + "static t\nlog b, a, 3, 0\nexp t, a, 7, 0\nmacs a, a, 0.25, in\nmacs out, b, t, 0.5\nend"
+    N, S = 130, 9
+    x = progs.stimulus(N, S)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    b.set_register_i("a", 70, 5.0)
+    b.set_register_i("a", 3, -1.5)
+    y = b.process_block(x)
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(text)
+        if n == 70:
+            o.set_register("a", 5.0)
+        if n == 3:
+            o.set_register("a", -1.5)
+        ref = o.process_block(x[:, n].copy())
+        assert np.array_equal(bits(ref), bits(y[:, n])), "instance %d" % n
+        assert (o.ood_flags() == 16) == (n in (3, 70))
+        for r in ("a", "b", "t"):
+            assert b.get_register_bits_i(r, n) == o.get_register_bits(r)
+    assert b.ood_flags() == 16  # the OR over all instances
+    clean = gpu.Batch(N, 1, 0)
+    assert clean.load_text(text)
+    clean.process_block(x)
+    assert clean.ood_flags() == 0
+
+
 def test_delay_line_exact(gpu, k):
     text = "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend"
     x = progs.stimulus(66, 64)
