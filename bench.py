@@ -210,10 +210,8 @@ def main():
         elif kid <= 8:
             kernel_kind = "fx_interp_v%d (gfx950 asm interpreter, VGPR register file)" % vg[kid]
         else:
-            pair = kid >= 16
-            kernel_kind = ("%s_v%d (program translated to gfx950 code%s: %d records inline, %d handler calls, %d saturations elided, %d code bytes)"
-                           % ("fx_pair" if pair else "fx_xlate", vg[kid - 15] if pair else vg[kid - 7],
-                              ", two instances per lane, packed fp32" if pair else "",
+            kernel_kind = ("fx_xlate_v%d (program translated to gfx950 code: %d records inline, %d handler calls, %d saturations elided, %d code bytes)"
+                           % (vg[kid - 7],
                               batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_unsaturated"), batch.info("xlate_code_bytes")))
         # algorithmic HBM bytes of ONE launch on ONE GPU: PCM in+out, every executed
         # TRAM read/write, and the once-per-block register-file spill/fill

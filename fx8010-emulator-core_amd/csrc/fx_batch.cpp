@@ -155,7 +155,6 @@ int Batch::ensureTram() {
     auto grow = [&](float*& buf, int& have, int want) -> int {
         if (want <= have) return 0;
         size_t waves = (size_t)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
-        if (instPerLane_ == 1) waves = (waves + 1) & ~(size_t)1;  // the pair frame owns the tiles of wavefronts 2w and 2w+1
         const size_t pitch = 256 * (size_t)instPerLane_;  // bytes of one slot of one wavefront
         float* fresh = nullptr;
         const size_t bytes = waves * (size_t)want * pitch;
@@ -281,30 +280,8 @@ int Batch::ensureLowered() {
         XlateImage image;
         const XlateTemplate* tmpl = nullptr;
         bool built = false;
-        // Two instances per lane (fx_pair_gfx950.S: v_pk_mul_f32 / v_pk_add_f32 over both) - opt-in with FX_KERNEL=xlate2
-        // for programs without SKIP and handler calls.  Measured on MI355X it is slower than one instance per lane
-        // (config5, 262144 instances: 13.5 vs 14.3 e12 instr/s): the packed instructions issue at half rate, so they
-        // save nothing, and the pair waves halve the occupancy.  Kept as a tested experiment.
-        const bool pairForced = forceHip && std::strcmp(forceHip, "xlate2") == 0;
-        if (pairForced) {
-            int pv = ASM_V96;
-            while (pv < ASM_V256 && 32 + 2 * low_.nRows > kAsmVgprRows[pv] + 32) ++pv;
-            std::string why;
-            const XlateTemplate* pt = (32 + 2 * low_.nRows <= kAsmVgprRows[pv] + 32) ? xlateTemplate((AsmVariant)pv, true, &why) : nullptr;
-            if (pt) {
-                XlateProgram pairProg = xprog;
-                pairProg.pair = true;
-                if (buildXlateImage(steadyRecords, lastRecords, *pt, pairProg, &image, &why)) {
-                    tmpl = pt;
-                    built = true;
-                    xlatePairVariant_ = (AsmVariant)pv;
-                }
-            }
-        }
-        if (!built) {
-            tmpl = xlateTemplate(asmVariant_, false, &xlateWhyNot_);
-            built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &xlateWhyNot_);
-        }
+        tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
+        built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &xlateWhyNot_);
         if (built) {
             if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still run the old code
             if (xlateModule_) (void)hipModuleUnload(xlateModule_);
@@ -322,7 +299,6 @@ int Batch::ensureLowered() {
             xlateUnsaturated_ = image.steady.unsaturated;
             xlateInlined_ = image.steady.inlined;
             xlateCalled_ = image.steady.called;
-            xlatePair_ = tmpl->pair;
             useXlate_ = true;
         }
     }
@@ -520,7 +496,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                 g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteady_);
                 g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLast_);
                 g.initOff = (int)xlateInitOff_;
-                e = launchAsmFunction(xlateFn_, g, (unsigned)((n_ + (xlatePair_ ? 127 : 63)) / (xlatePair_ ? 128 : 64)), xlateLdsBytes_, s);
+                e = launchAsmFunction(xlateFn_, g, (unsigned)((n_ + 63) / 64), xlateLdsBytes_, s);
             } else {
                 e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
             }
@@ -628,7 +604,7 @@ int64_t Batch::info(int what) {
     if (ensureLowered() != 0) return -1;
     switch (what) {
         case FXB_INFO_INST_PER_LANE: return instPerLane_;
-        case FXB_INFO_KERNEL: return useAsm_ ? (useXlate_ ? (xlatePair_ ? 16 + (int)xlatePairVariant_ : 8 + (int)asmVariant_) : 1 + (int)asmVariant_) : 0;
+        case FXB_INFO_KERNEL: return useAsm_ ? (useXlate_ ? 8 + (int)asmVariant_ : 1 + (int)asmVariant_) : 0;
         case FXB_INFO_XLATE_CODE_BYTES: return useXlate_ ? (int64_t)xlateCodeBytes_ : 0;
         case FXB_INFO_XLATE_INLINED: return useXlate_ ? xlateInlined_ : 0;
         case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;

@@ -89,8 +89,6 @@ private:
     std::string asmWhyNot_;
     // translated program (fx_xlate.hpp): a code object of its own per lowering
     bool useXlate_ = false;
-    bool xlatePair_ = false;                   // ... on the two-instances-per-lane frame
-    AsmVariant xlatePairVariant_ = ASM_V96;
     hipModule_t xlateModule_ = nullptr;
     hipFunction_t xlateFn_ = nullptr;
     uint64_t xlateSteady_ = 0, xlateLast_ = 0;  // {fast, exact} stream offsets as the kernel takes them

@@ -204,11 +204,8 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t 
     if (!low.error.empty()) { h->err = low.error; return FX_E_PROGRAM; }
     std::string why;
     if (!fx::asmEligible(low, &why)) { h->err = "not eligible: " + why; return FX_E_PROGRAM; }
-    const bool pair = stream >= 10;  // streams 10..14: the same five for the two-instances-per-lane frame
-    if (pair) stream -= 10;
-    int v = pair ? fx::ASM_V96 : fx::ASM_V64;
-    while (v < fx::ASM_V256 && (pair ? 2 * low.nRows : low.nRows) > fx::kAsmVgprRows[v]) ++v;
-    if ((pair ? 2 * low.nRows : low.nRows) > fx::kAsmVgprRows[v]) { h->err = "register file too large for this frame"; return FX_E_PROGRAM; }
+    int v = fx::ASM_V64;
+    while (v < fx::ASM_V256 && low.nRows > fx::kAsmVgprRows[v]) ++v;
     if (vgprs != 0) {
         int want = -1;
         for (int q = fx::ASM_V64; q < fx::ASM_VARIANTS; ++q)
@@ -216,15 +213,14 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t 
         if (want < v) { h->err = "no such VGPR build, or too small for the program"; return FX_E_ARG; }
         v = want;
     }
-    const fx::XlateTemplate* tmpl = fx::xlateTemplate((fx::AsmVariant)v, pair, &h->err);
+    const fx::XlateTemplate* tmpl = fx::xlateTemplate((fx::AsmVariant)v, &h->err);
     if (!tmpl) return FX_E_PROGRAM;
-    if (stream < 0 || stream > 4) { h->err = "stream: 0 steady fast, 1 steady exact, 2 last fast, 3 last exact, 4 run-once (+10: pair frame)"; return FX_E_ARG; }
+    if (stream < 0 || stream > 4) { h->err = "stream: 0 steady fast, 1 steady exact, 2 last fast, 3 last exact, 4 run-once"; return FX_E_ARG; }
     std::vector<uint32_t> code4[5];
     std::string text4[5];
     fx::XlateImage plan;
     const std::vector<fx::MicroOp> steadyRecords = fx::encodeAsmStream(low.steady, nullptr, true), lastRecords = fx::encodeAsmStream(low.last, nullptr, true);
     fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow);
-    xprog.pair = pair;
     if (!fx::planXlate(steadyRecords, lastRecords, *tmpl, xprog, &plan, code4, text4, &h->err)) return FX_E_PROGRAM;
     const std::vector<uint32_t>& words = code4[stream];
     const std::string& text = text4[stream];

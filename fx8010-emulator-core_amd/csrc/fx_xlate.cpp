@@ -35,28 +35,7 @@ const unsigned char kBlobV256[] = {
 #include "build/fx_xlate_v256_blob.inc"
 };
 
-const unsigned char kPairV96[] = {
-#include "build/fx_pair_v96_blob.inc"
-};
-const unsigned char kPairV128[] = {
-#include "build/fx_pair_v128_blob.inc"
-};
-const unsigned char kPairV168[] = {
-#include "build/fx_pair_v168_blob.inc"
-};
-const unsigned char kPairV256[] = {
-#include "build/fx_pair_v256_blob.inc"
-};
-
 struct BlobRef { const unsigned char* p; size_t n; const char* kernel; int vgprs; };
-// frames with two instances per lane (fx_pair_gfx950.S): rows = (vgprs - 32) / 2
-const BlobRef kPairBlobs[ASM_VARIANTS] = {
-    {nullptr, 0, "", 0}, {nullptr, 0, "", 0}, {nullptr, 0, "", 0}, {nullptr, 0, "", 0},
-    {kPairV96, sizeof(kPairV96), "fx_pair_v96", 96},
-    {kPairV128, sizeof(kPairV128), "fx_pair_v128", 128},
-    {kPairV168, sizeof(kPairV168), "fx_pair_v168", 168},
-    {kPairV256, sizeof(kPairV256), "fx_pair_v256", 256},
-};
 const BlobRef kBlobs[ASM_VARIANTS] = {
     {nullptr, 0, "", 0},
     {kBlobV64, sizeof(kBlobV64), "fx_xlate_v64", 64},
@@ -106,9 +85,9 @@ SymbolAt findSymbol(const unsigned char* img, size_t n, const std::string& name)
 }
 
 std::mutex g_mu;
-XlateTemplate g_templates[2][ASM_VARIANTS];
-bool g_parsed[2][ASM_VARIANTS] = {};
-std::string g_parseErr[2][ASM_VARIANTS];
+XlateTemplate g_templates[ASM_VARIANTS];
+bool g_parsed[ASM_VARIANTS] = {};
+std::string g_parseErr[ASM_VARIANTS];
 
 // ---- operands --------------------------------------------------------------------------------------------
 // operand texts are only needed for a listing; building them costs more than the encoding itself
@@ -261,21 +240,6 @@ class Emitter {
         if (text_) line("global_load_dwordx" + std::to_string(dwords) + " v[" + std::to_string(vdata) + ":" + std::to_string(vdata + dwords - 1) + "], v" +
              std::to_string(vaddr) + ", s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]");
     }
-    // packed fp32 (VOP3P): dst and sources are 64-bit; an SGPR source is broadcast from its low dword (op_sel_hi 0);
-    // negSrc: bit k negates both halves of source k
-    void vop3p(uint32_t op, const char* name, int vdst, const Src& s0, bool s0Broadcast, const Src& s1, uint32_t negSrc) {
-        w_.push_back(0xd3800000u | (op << 16) | 0x4000u | ((negSrc & 7u) << 8) | (uint32_t)vdst);
-        w_.push_back(s0.code | (s1.code << 9) | (s0Broadcast ? 0x10000000u : 0x18000000u) | ((negSrc & 7u) << 29));
-        ++count_;
-        if (!text_) return;
-        std::string t = std::string(name) + " v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], " + s0.text + ", " + s1.text;
-        if (s0Broadcast) t += " op_sel_hi:[0,1]";
-        if (negSrc) {
-            const std::string m = std::string("[") + ((negSrc & 1) ? "1" : "0") + "," + ((negSrc & 2) ? "1" : "0") + "]";
-            t += " neg_lo:" + m + " neg_hi:" + m;
-        }
-        if (text_) line(t);
-    }
     // LDS: reads return into v[vdst..], byte offset in the instruction (read2: two dword offsets)
     void dsRead(uint32_t op, const char* name, int dwords, int vdst, int vaddr, uint32_t offset) {
         w_.push_back(0xd8000000u | (op << 17) | (offset & 0xffffu));
@@ -373,7 +337,6 @@ enum : uint32_t {
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
-    VOP3P_PK_MUL_F32 = 0x31, VOP3P_PK_ADD_F32 = 0x32,
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
     SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
     VOP2_ADDC_CO_U32 = 0x1c, VOP3B_SUBBREV_CO_U32 = 0x11e,
@@ -396,11 +359,8 @@ constexpr int kSTemp = 62;        // s[62:63] scratch of the handlers, free betw
 constexpr int kSTaint = 78;       // s[78:79] lanes that hold a non-finite value (template prologue)
 constexpr int kVLane4 = 1;        // v1 = lane * 4
 constexpr int kVClassMask = 29;   // v29 = v_cmp_class mask of NaN and +-Inf
-constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane          (pair frame: v14 / v15 for half 0 / 1)
-constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read   (pair frame: v24..v27)
-constexpr int kVPairOod = 14, kVPairCursor = 24;
-constexpr int kSPairConst = 28;   // s[28:29]: uniform operand of a packed instruction; s[30:31]: address of half 1's TRAM slot
-constexpr int kSPairTile = 26;    // s26 / s27 = bytes of one iTRAM / xTRAM tile (half 1's tile follows half 0's)
+constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane
+constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read
 constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
 constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
 // LUT tables in LDS: fp32 thresholds (66) + domain bounds (2), then per table 64 entries {slope, y1, x1, pad} of 32 bytes
@@ -425,7 +385,7 @@ class Translator {
         returns_.assign(4 * records.size() + 4, 0);
         if (prog_.uniformCursors) {
             // every TRAM instruction runs on all lanes: the four cursors are the same in every lane, keep them in SGPRs
-            for (int c = 0; c < 4; ++c) e_.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSCursor + c), vreg(cursorVgpr() + c));
+            for (int c = 0; c < 4; ++c) e_.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSCursor + c), vreg(kVCursor + c));
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
         }
         bool anyLut = false;
@@ -449,8 +409,8 @@ class Translator {
         if (!flush()) { if (err) *err = err_; return false; }
         if (prog_.uniformCursors) {
             plainMode();
-            for (int c = 0; c < 4; ++c) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(cursorVgpr() + c), sreg(kSCursor + c));
-            for (int h = 0; h < halves(); ++h) e_.vop2(VOP2_OR_B32, "v_or_b32_e32", oodVgpr(h), sreg(kSOod), oodVgpr(h));
+            for (int c = 0; c < 4; ++c) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVCursor + c), sreg(kSCursor + c));
+            e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, sreg(kSOod), kVOod);
         }
         if (returns) *returns = returns_;
         // the end-of-sample frame sets up its own index mode; EXEC is reset there as well
@@ -462,15 +422,11 @@ class Translator {
   private:
     bool fail(const std::string& m) { err_ = m; return false; }
 
-    // pair frame (fx_pair_gfx950.S): two instances per lane, row r = v[32+2r] (half 0), v[33+2r] (half 1)
-    int halves() const { return prog_.pair ? 2 : 1; }
-    int vrow(uint32_t r, int h) const { return kRegFileBase + (prog_.pair ? 2 * (int)r + h : (int)r); }
-    int oodVgpr(int h) const { return prog_.pair ? kVPairOod + h : kVOod; }
-    int cursorVgpr() const { return prog_.pair ? kVPairCursor : kVCursor; }
+    static int vrow(uint32_t r) { return kRegFileBase + (int)r; }
 
     bool row(uint32_t r, int* v) {
-        if (vrow(r, halves() - 1) >= tmpl_.vgprs) return fail("register-file row beyond the VGPR budget of the build");
-        *v = vrow(r, half_);
+        if (vrow(r) >= tmpl_.vgprs) return fail("register-file row beyond the VGPR budget of the build");
+        *v = vrow(r);
         for (int p : pending_)
             if (p == *v) return fail("internal: row with a TRAM read in flight");
         return true;
@@ -496,7 +452,7 @@ class Translator {
         return true;
     }
     // sync points of a record: per half, [0] after the wait for pending TRAM reads, [1] after its call / inline LUT
-    size_t syncIndex(int kind) const { return 4 * index_ + 2 * (size_t)half_ + (size_t)kind; }
+    size_t syncIndex(int kind) const { return 4 * index_ + (size_t)kind; }
     bool leaveIfTainted(uint32_t target) {
         if (target == 0) return fail("internal: fast and exact streams differ in their sync points");
         e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTaint), imm32(0));
@@ -513,8 +469,7 @@ class Translator {
         for (int k = 0; k < 4; ++k)
             if (use[k])
                 for (int p : pending_)
-                    for (int h = 0; h < halves(); ++h)
-                        if (p == vrow(rows[k], h)) return flush();
+                    if (p == vrow(rows[k])) return flush();
         return true;
     }
 
@@ -598,7 +553,7 @@ class Translator {
             e_.sop2(SOP2_OR_B64, "s_or_b64", named(106, "vcc"), named(106, "vcc"), sreg64(kSTemp));
             Src flag = imm32(16);
             e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(7), zero, flag, &vcc);
-            e_.vop2(VOP2_OR_B32, "v_or_b32_e32", oodVgpr(half_), vreg(oodVgpr(half_)), 7);
+            e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, vreg(kVOod), 7);
         }
         e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
         e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(12), vreg64(2), vreg64(12), nullptr);
@@ -620,17 +575,12 @@ class Translator {
         const int t = (slot == AS_TRAM_IR || slot == AS_TRAM_IW) ? 0 : 1;
         const int cursor = kSCursor + 2 * t + (isRead ? 1 : 0);
         const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
-        const int nh = halves();
         if (!touch(r, !isRead && !(r.w[6] & 1u), false, false, isRead)) return false;
         plainMode();
-        int vR[2] = {0, 0};
-        if (isRead)
-            for (half_ = 0; half_ < nh; ++half_)
-                if (!row(r.w[5], &vR[half_])) { half_ = 0; return false; }
-        half_ = 0;
+        int vR = 0;
+        if (isRead && !row(r.w[5], &vR)) return false;
         if (size < 1) {  // the reference would divide by zero: flagged, the read yields 0
-            if (isRead)
-                for (int h = 0; h < nh; ++h) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR[h]), imm32(0));
+            if (isRead) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
             e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
             return true;
         }
@@ -638,12 +588,6 @@ class Translator {
         p = p > size - 1 ? size - 1 : p;
         p = p < 0 ? 0 : p;
         const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
-        // the pair frame's second half uses the next tile: address + tile bytes, in s[30:31]
-        const uint32_t extra = nh == 2 ? 4u : 0u;  // s_add_u32, s_addc_u32 and a 2-dword memory instruction more to skip
-        auto secondAddress = [&]() {
-            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSPairConst + 2), sreg(kSAddr), sreg(kSPairTile + t));
-            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSPairConst + 3), sreg(kSAddr + 1), imm32(0));
-        };
         if (isRead) {
             if (p != 0) {
                 e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
@@ -653,39 +597,26 @@ class Translator {
                 e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(1));
             }
             e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSTramSlots[t]));
-            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6 + extra, true);
+            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6, true);
             e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSPos), pos, imm32(8));
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSTramBase[t]), sreg(kSPos));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSTramBase[t] + 1), imm32(0));
-            e_.global(GLOBAL_LOAD_DWORD, true, vR[0], kVLane4, kSAddr);
-            if (nh == 2) {
-                secondAddress();
-                e_.global(GLOBAL_LOAD_DWORD, true, vR[1], kVLane4, kSPairConst + 2);
-            }
-            e_.sopp(SOPP_BRANCH, "s_branch", (uint32_t)nh, true);
-            for (int h = 0; h < nh; ++h) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR[h]), imm32(0));
-            for (int h = 0; h < nh; ++h) pending_.push_back(vR[h]);
+            e_.global(GLOBAL_LOAD_DWORD, true, vR, kVLane4, kSAddr);
+            e_.sopp(SOPP_BRANCH, "s_branch", 1, true);
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+            pending_.push_back(vR);
         } else {
-            int vA[2] = {2, 2};
-            if (r.w[6] & 1u) {
-                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));
-            } else {
-                for (half_ = 0; half_ < nh; ++half_)
-                    if (!row(r.w[2], &vA[half_])) { half_ = 0; return false; }
-                half_ = 0;
-            }
+            int vA = 2;
+            if (r.w[6] & 1u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));
+            else if (!row(r.w[2], &vA)) return false;
             if (p != 0) e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
             e_.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSAddr), sreg(kSTramSlots[t]), imm32(t == 0 ? 8192u : 1048576u, true));
             e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSAddr));
-            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6 + extra, true);
+            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6, true);
             e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSPos), pos, imm32(8));
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSTramBase[t]), sreg(kSPos));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSTramBase[t] + 1), imm32(0));
-            e_.global(GLOBAL_STORE_DWORD, false, vA[0], kVLane4, kSAddr);
-            if (nh == 2) {
-                secondAddress();
-                e_.global(GLOBAL_STORE_DWORD, false, vA[1], kVLane4, kSPairConst + 2);
-            }
+            e_.global(GLOBAL_STORE_DWORD, false, vA, kVLane4, kSAddr);
             e_.sopp(SOPP_BRANCH, "s_branch", 1, true);
             e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
         }
@@ -706,7 +637,7 @@ class Translator {
     }
 
     bool isBoundedVgpr(int v) const {
-        const int r = (v - kRegFileBase) / halves();
+        const int r = v - kRegFileBase;
         return v >= kRegFileBase && r >= 0 && r < (int)prog_.wildRow.size() && !prog_.wildRow[r];
     }
     // upper bound of |operand| that the fast stream may rely on: |c| of a uniform, 1 for a row of the bounded
@@ -884,7 +815,7 @@ class Translator {
         if (!product(r, kind, &inV3)) return false;
         return interpTail(r, kind, inV3 ? vreg(3) : value(r.w[3]), vR);
     }
-    // p = fp32 product X*Y (a VGPR or the folded constant); the row lookups follow half_
+    // p = fp32 product X*Y (a VGPR or the folded constant)
     bool interpTail(const MicroOp& r, uint32_t kind, const Src& p, int vR) {
         const bool within = resultWithinUnit(3, kind, r);
         const int d = within ? vR : 2;
@@ -926,107 +857,6 @@ class Translator {
         return true;
     }
 
-    // ---- pair frame: packed multiply / add over both halves ---------------------------------------------------
-    Src pairRow(uint32_t r) const { return pairTemp(vrow(r, 0)); }
-    Src pairTemp(int v) const {
-        Src s;
-        s.code = 256u + (uint32_t)v;
-        if (tlsWantText) s.text = "v[" + std::to_string(v) + ":" + std::to_string(v + 1) + "]";
-        return s;
-    }
-    // a uniform as the (broadcast) SGPR source of a packed instruction
-    Src pairUniform(uint32_t bits) {
-        if ((bits & 0x7f800000u) == 0x7f800000u) nonFinite_ = true;
-        if (!pairConstKnown_ || pairConst_ != bits) {
-            e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSPairConst), imm32(bits));
-            pairConstKnown_ = true;
-            pairConst_ = bits;
-        }
-        return sreg64(kSPairConst);
-    }
-    bool rowsFit(const MicroOp& r, bool a, bool x, bool y) {
-        const uint32_t rows[4] = {r.w[2], r.w[3], r.w[4], r.w[5]};
-        const bool use[4] = {a, x, y, true};
-        for (int k = 0; k < 4; ++k)
-            if (use[k] && vrow(rows[k], 1) >= tmpl_.vgprs) return fail("register-file row beyond the VGPR budget of the build");
-        return true;
-    }
-    // v[2:3] = X * Y for both halves, unless both are uniform (folded product in the X word)
-    bool productPair(const MicroOp& r, uint32_t kind, bool* inTemp) {
-        const bool uX = kind & 2, uY = kind & 4;
-        *inTemp = !(uX && uY);
-        if (uX && uY) return true;
-        if (!uX && !uY) e_.vop3p(VOP3P_PK_MUL_F32, "v_pk_mul_f32", 2, pairRow(r.w[3]), false, pairRow(r.w[4]), 0);
-        else if (uX) e_.vop3p(VOP3P_PK_MUL_F32, "v_pk_mul_f32", 2, pairUniform(r.w[3]), true, pairRow(r.w[4]), 0);
-        else e_.vop3p(VOP3P_PK_MUL_F32, "v_pk_mul_f32", 2, pairUniform(r.w[4]), true, pairRow(r.w[3]), 0);
-        return true;
-    }
-    void satStorePair(int vLo, uint32_t rowR) {  // v[vLo], v[vLo+1] -> saturate -> row R of half 0, 1
-        for (int h = 0; h < 2; ++h) {
-            const int vR = vrow(rowR, h), src = vLo + h;
-            Src m1 = imm32(0xbf800000u), p1 = imm32(0x3f800000u);
-            if (fast_) {
-                e_.vop3(VOP3_MED3_F32, "v_med3_f32", vreg(vR), vreg(src), m1, &p1);
-                continue;
-            }
-            e_.vopc(VOPC_CMP_U_F32, "v_cmp_u_f32_e32", vreg(src), src);
-            e_.vop3(VOP3_MED3_F32, "v_med3_f32", vreg(6), vreg(src), m1, &p1);
-            e_.sopp(SOPP_NOP, "s_nop", 0, true);
-            e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", vR, vreg(6), src, ", vcc");
-        }
-    }
-    void constPair(uint32_t rowR, uint32_t bits) {
-        for (int h = 0; h < 2; ++h) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vrow(rowR, h)), value(bits));
-    }
-    bool macsPair(const MicroOp& r, uint32_t kind, bool neg) {
-        if (!rowsFit(r, !(kind & 1u), !(kind & 2u), !(kind & 4u))) return false;
-        if (kind == 7) { constPair(r.w[5], r.w[2]); return true; }
-        bool inTemp;
-        if (!productPair(r, kind, &inTemp)) return false;
-        const bool within = resultWithinUnit(neg ? 1 : 0, kind, r);
-        const int d = within ? vrow(r.w[5], 0) : 4;
-        if (inTemp) {   // A +- p:  p is source 1
-            if (kind & 1u) e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", d, pairUniform(r.w[2]), true, pairTemp(2), neg ? 2u : 0u);
-            else e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", d, pairRow(r.w[2]), false, pairTemp(2), neg ? 2u : 0u);
-        } else {        // folded product (source 0, uniform) and a row A
-            e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", d, pairUniform(r.w[3]), true, pairRow(r.w[2]), neg ? 1u : 0u);
-        }
-        if (within) ++stats_.unsaturated;
-        else satStorePair(4, r.w[5]);
-        return true;
-    }
-    bool acc3Pair(const MicroOp& r, uint32_t kind) {
-        if (!rowsFit(r, !(kind & 1u), !(kind & 2u), !(kind & 4u))) return false;
-        if (kind == 7) { constPair(r.w[5], r.w[2]); return true; }
-        const bool uA = kind & 1, uX = kind & 2, uY = kind & 4;
-        const bool within = resultWithinUnit(2, kind, r);
-        const int d = within ? vrow(r.w[5], 0) : 4;
-        if (uA && uX) {  // t = A + X folded into the A word
-            e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", d, pairUniform(r.w[2]), true, pairRow(r.w[4]), 0);
-        } else {
-            if (uA) e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", 2, pairUniform(r.w[2]), true, pairRow(r.w[3]), 0);
-            else if (uX) e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", 2, pairUniform(r.w[3]), true, pairRow(r.w[2]), 0);
-            else e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", 2, pairRow(r.w[2]), false, pairRow(r.w[3]), 0);
-            if (uY) e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", d, pairUniform(r.w[4]), true, pairTemp(2), 0);
-            else e_.vop3p(VOP3P_PK_ADD_F32, "v_pk_add_f32", d, pairRow(r.w[4]), false, pairTemp(2), 0);
-        }
-        if (within) ++stats_.unsaturated;
-        else satStorePair(4, r.w[5]);
-        return true;
-    }
-    bool interpPair(const MicroOp& r, uint32_t kind) {
-        if (!rowsFit(r, !(kind & 1u), !(kind & 2u), !(kind & 4u))) return false;
-        if (kind == 7) { constPair(r.w[5], r.w[2]); return true; }
-        bool inTemp;
-        if (!productPair(r, kind, &inTemp)) return false;
-        for (half_ = 0; half_ < 2; ++half_) {
-            int vR;
-            if (!row(r.w[5], &vR) || !interpTail(r, kind, inTemp ? vreg(2 + half_) : value(r.w[3]), vR)) { half_ = 0; return false; }
-        }
-        half_ = 0;
-        return true;
-    }
-
     // Is d * (double)f exact for every float f?  A float has 24 significant bits, a double 53: yes when d has at
     // most 29 (zero, or a normal number whose low 24 mantissa bits are clear; subnormal d: no claim).
     static bool productWithFloatIsExact(uint64_t dbits) {
@@ -1047,7 +877,6 @@ class Translator {
     // run the interpreter's handler for this record: operands in s18..s23, return address in s[24:25]
     bool call(const MicroOp& r, uint32_t slot, uint32_t wordMask) {
         if (slot >= (uint32_t)kAsmSlots) return fail("record with an unknown handler slot");
-        if (prog_.pair) return fail("pair frame: the program needs a handler call");
         if (!flush()) return false;  // the handler addresses rows by index
         for (int k = 2; k < 8; ++k)
             if (wordMask & (1u << k)) setRecordWord(k, r.w[k]);
@@ -1085,7 +914,7 @@ class Translator {
         e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 7, imm32(4), 6);
         e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", v6, v6, v7, &t1);
         e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", v6, v6, eight, &t2);          // zero: 8
-        e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(vrow(0, half_)), v6);
+        e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(vrow(0)), v6);
     }
 
     static float asFloat(uint32_t bits) {
@@ -1204,62 +1033,7 @@ class Translator {
         ccrFrom(vR);
     }
 
-    // pair frame: everything inline, both halves; SKIP and handler calls are not available there
-    bool onePair(const MicroOp& r, uint32_t slot) {
-        if (slot == AS_NOP) return true;
-        if (slot == AS_PRED || slot == AS_UNPRED || slot == AS_SKIP) return fail("pair frame: the program uses SKIP");
-        plainMode();
-        if (slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
-            if (!prog_.uniformCursors) return fail("pair frame: per-lane TRAM cursors");
-            ++stats_.inlined;
-            return tram(r, slot);
-        }
-        bool ok = true;
-        const bool genericCcr = slot < AS_MACS && ((r.w[6] >> 3) & 1u) && !ccrDeadAfter(index_);
-        if (slot == AS_LUT && !(r.w[6] & 1u)) {
-            for (half_ = 0; half_ < 2 && ok; ++half_) {
-                ok = lut(r);
-                if (ok && genericCcr) ccrFrom(vrow(r.w[5], half_));
-            }
-            half_ = 0;
-            ++stats_.inlined;
-            return ok;
-        }
-        if (slot >= AS_MACS && slot < (uint32_t)kAsmSlots) {
-            const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2;
-            const uint32_t ccr = (rel & 1u) && !ccrDeadAfter(index_) ? 1u : 0u;
-            if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
-            ++stats_.inlined;
-            switch (family) {
-                case 0: ok = macsPair(r, kind, false); break;
-                case 1: ok = macsPair(r, kind, true); break;
-                case 2: ok = acc3Pair(r, kind); break;
-                default: ok = interpPair(r, kind); break;
-            }
-            if (ok && ccr)
-                for (half_ = 0; half_ < 2; ++half_) ccrFrom(vrow(r.w[5], half_));
-            half_ = 0;
-            return ok;
-        }
-        if (slot == AS_MOV) {
-            if (!touch(r, !(r.w[6] & 1u), false, false, true)) return false;
-            for (half_ = 0; half_ < 2 && ok; ++half_) {
-                int vR;
-                Src a;
-                ok = row(r.w[5], &vR) && operand(r.w[2], r.w[6] & 1u, &a);
-                if (!ok) break;
-                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), a);
-                if (genericCcr) ccrFrom(vR);
-            }
-            half_ = 0;
-            ++stats_.inlined;
-            return ok;
-        }
-        return fail("pair frame: the program needs a handler call");
-    }
-
     bool one(const MicroOp& r, uint32_t slot) {
-        if (prog_.pair) return onePair(r, slot);
         // (generic records carry their CCR flag in w6; a write the stream overwrites before anything reads it is dead)
         const uint32_t ccrLive = (slot < AS_MACS && ((r.w[6] >> 3) & 1u) && !ccrDeadAfter(index_)) ? 1u : 0u;
         if (slot == AS_NOP) return true;  // END / NOP only count (staticCount)
@@ -1299,7 +1073,7 @@ class Translator {
         if (slot == AS_LUT && !(r.w[6] & 1u) && !(ccrLive && prog_.compactCcr)) {
             ++stats_.inlined;
             if (!lut(r)) return false;
-            if (ccrLive) ccrFrom(vrow(r.w[5], 0));
+            if (ccrLive) ccrFrom(vrow(r.w[5]));
             return true;
         }
         if (prog_.uniformCursors && slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
@@ -1335,7 +1109,7 @@ class Translator {
                 default: ok = interp(r, kind); break;
             }
             if (!ok) return false;
-            ccrOrSkip(vrow(r.w[5], half_));
+            ccrOrSkip(vrow(r.w[5]));
             return true;
         }
         if (slot == AS_MOV && !(ccrLive && prog_.compactCcr)) {
@@ -1371,12 +1145,9 @@ class Translator {
     size_t consumed_ = (size_t)-1;   // record already translated together with its predecessor
     bool predOpen_ = false;          // EXEC is restricted by a PRED / a simple shadow
     int32_t regionPreds_ = 0;        // PRED records of the current simple shadow still to come
-    bool pairConstKnown_ = false;    // s28 holds pairConst_
-    uint32_t pairConst_ = 0;
     bool segKnown_ = false;          // s[92:93] holds the segment base of table offset segOff_
     uint32_t segOff_ = 0;
     size_t index_ = 0;
-    int half_ = 0;                   // pair frame: the half the scalar emitters work on
     bool nonFinite_ = false;
     bool indexModeUnknown_ = false;  // the per-sample frame enters the stream with index mode off
     bool known_[8] = {};
@@ -1385,27 +1156,25 @@ class Translator {
 
 }  // namespace
 
-const XlateTemplate* xlateTemplate(AsmVariant variant, bool pair, std::string* err) {
-    const int k = pair ? 1 : 0;
-    if (variant <= ASM_LDS || variant >= ASM_VARIANTS || (pair && !kPairBlobs[variant].p)) {
+const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
+    if (variant <= ASM_LDS || variant >= ASM_VARIANTS) {
         if (err) *err = "no translation template for this build";
         return nullptr;
     }
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_parsed[k][variant]) {
-        g_parsed[k][variant] = true;
-        const BlobRef& b = pair ? kPairBlobs[variant] : kBlobs[variant];
+    if (!g_parsed[variant]) {
+        g_parsed[variant] = true;
+        const BlobRef& b = kBlobs[variant];
         XlateTemplate t;
         t.image = b.p;
         t.imageBytes = b.n;
         t.kernelName = b.kernel;
         t.vgprs = b.vgprs;
-        t.pair = pair;
         const SymbolAt kn = findSymbol(b.p, b.n, t.kernelName);
         const SymbolAt tab = findSymbol(b.p, b.n, t.kernelName + "_table");
         const SymbolAt hole = findSymbol(b.p, b.n, t.kernelName + "_hole");
         if (!kn.found || !tab.found || !hole.found || tab.fileOff + (kAsmSlots + 2) * 4 > b.n) {
-            g_parseErr[k][variant] = "translation template " + t.kernelName + ": symbols not found in the code object";
+            g_parseErr[variant] = "translation template " + t.kernelName + ": symbols not found in the code object";
         } else {
             uint32_t table[kAsmSlots + 2];
             std::memcpy(table, b.p + tab.fileOff, sizeof(table));
@@ -1414,16 +1183,16 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, bool pair, std::string* e
             t.holeBytes = table[kAsmSlots + 1];
             t.holeFileOff = hole.fileOff;
             if ((uint64_t)t.holeOff != hole.value - kn.value || t.holeFileOff + t.holeBytes > b.n || (t.holeBytes & 3u))
-                g_parseErr[k][variant] = "translation template " + t.kernelName + ": inconsistent hole";
+                g_parseErr[variant] = "translation template " + t.kernelName + ": inconsistent hole";
             else
-                g_templates[k][variant] = t;
+                g_templates[variant] = t;
         }
     }
-    if (!g_parseErr[k][variant].empty()) {
-        if (err) *err = g_parseErr[k][variant];
+    if (!g_parseErr[variant].empty()) {
+        if (err) *err = g_parseErr[variant];
         return nullptr;
     }
-    return &g_templates[k][variant];
+    return &g_templates[variant];
 }
 
 bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, const XlateProgram& prog, uint32_t codeBase,
@@ -1564,7 +1333,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     uint32_t at = tmpl.holeOff;
     for (int k = 0; k < 2; ++k) {
         XlateProgram prog = program;
-        prog.compactCcr = k == 1 && !program.pair;  // the pair frame has no handlers: CCR inline everywhere
+        prog.compactCcr = k == 1;
         std::vector<uint32_t> exactRet, scratch, dummy(4 * recs[k]->size() + 4, at);
         XlateStats fastStats, exactStats;
         // pass 1: size of the fast stream (targets = its own base: in range, value irrelevant)

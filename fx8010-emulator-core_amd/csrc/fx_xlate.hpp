@@ -29,16 +29,14 @@ struct XlateTemplate {
     size_t imageBytes = 0;
     std::string kernelName;
     int vgprs = 0;                        // VGPR budget of the build (register file = v32 .. v[vgprs-1])
-    bool pair = false;                    // two instances per lane (fx_pair_gfx950.S): row r = v[32+2r : 33+2r]
     uint32_t handlerOff[kAsmSlots] = {};  // byte offset of each handler (register set _a) from the kernel entry
     uint32_t holeOff = 0;                 // byte offset of the hole from the kernel entry
     uint32_t holeBytes = 0;
     size_t holeFileOff = 0;               // where the hole sits in the ELF file
 };
 
-// The template of a VGPR build (ASM_V64 .. ASM_V256; pair frames: ASM_V96 .. ASM_V256); nullptr + err when there is
-// none or the image is malformed.
-const XlateTemplate* xlateTemplate(AsmVariant variant, bool pair, std::string* err);
+// The template of a VGPR build (ASM_V64 .. ASM_V256); nullptr + err when there is none or the image is malformed.
+const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err);
 
 // What the translator needs to know about the program beyond its records.
 struct XlateProgram {
@@ -47,7 +45,6 @@ struct XlateProgram {
     // LOG/EXP tables in LDS: the fp32 thresholds, x1[] and the {slope, y1} arrays of the tables the program uses
     // (lutTables = their byte offsets in the LUT blob, in LDS order); empty = tables are read from global memory
     std::vector<uint32_t> lutTables;
-    bool pair = false;            // translate for the two-instances-per-lane frame (fx_pair_gfx950.S): packed fp32, no handler calls
     bool compactCcr = false;      // set by planXlate for the last-sample streams: live-CCR instructions call the handler
     std::vector<uint8_t> wildRow; // per register-file row: 0 = BOUNDED class (always inside [-1, 1]), 1 = WILD
 };

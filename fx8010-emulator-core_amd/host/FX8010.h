@@ -1,34 +1,76 @@
-// FX8010.h — host-side mirror of the reference's public class, over the C ABI of libfx8010_amd.so.
+// FX8010.h — host-side mirror of the reference's public header, over the C ABI of libfx8010_amd.so.
 //
 // Same namespace, class name, member names, argument meaning and return conventions as the
-// reference (include/FX8010.h:47-75), so a caller written against the reference — its console
-// harness source/main.cpp, or the VST block loop it is meant for — compiles unchanged against
-// this header and runs the instruction loop on an MI355X instead of the host CPU.
+// reference (include/FX8010.h:47-75), plus everything else that header hands to a translation unit
+// that includes it (include/FX8010.h:12-25 the standard headers and `using namespace std`, :33-42 the
+// macros E, PI, SAMPLERATE, AUDIOBLOCKSIZE, DEBUG, PRINT_REGISTERS, MAX_IDELAY_SIZE, MAX_XDELAY_SIZE,
+// :50 the default constructor), so that a caller written against the reference - its console harness
+// source/main.cpp, or the VST block loop it is meant for - compiles unchanged against this header and
+// runs the instruction loop on an MI355X instead of the host CPU.  tests/test_dropin_harness.py compiles
+// and links the reference's own source/main.cpp + source/helpers.cpp, where they lie, against it:
+//     g++ -std=c++17 -include fx8010-emulator-core_amd/host/FX8010.h -I include \
+//         /root/reference/source/main.cpp /root/reference/source/helpers.cpp -L fx8010-emulator-core_amd -lfx8010_amd
+// (this header defines the reference's include guard FX8010_H, so main.cpp's own
+// #include "../include/FX8010.h" contributes nothing).
 //
-//   Klangraum::FX8010       one emulated DSP, one process() call per sample period
-//   Klangraum::FX8010Batch  N independent DSPs stepping one program (the data-parallel path)
+//   Klangraum::FX8010         one emulated DSP, one process() call per sample period
+//   Klangraum::FX8010Batch    N independent DSPs stepping one program on one GPU (the data-parallel path)
+//   Klangraum::FX8010Sharded  the same over several GPUs of one node (contiguous instance ranges, one host
+//                             thread + stream per device, no collective)
 //
 // Header-only; link with -lfx8010_amd.  Differences that remain, by design:
 //   * construction prints no banner (the reference prints ~7 lines, source/FX8010.cpp:18-24);
-//   * when no HIP device is usable the constructor throws std::runtime_error — there is no CPU path;
-//   * getInstructionCounter() is computed in 64 bits and truncated to int like the reference's field.
+//   * when no HIP device is usable the constructor throws std::runtime_error - there is no CPU path;
+//   * getInstructionCounter() is computed in 64 bits and truncated to int like the reference's field;
+//   * the default constructor, declared but never defined by the reference (include/FX8010.h:50), makes a
+//     one-channel DSP.
 #ifndef FX8010_AMD_HOST_FX8010_H
 #define FX8010_AMD_HOST_FX8010_H
+// the reference header's own guard: whoever includes this file has "included FX8010.h"
+#ifndef FX8010_H
+#define FX8010_H
+#endif
+
+// what include/FX8010.h:12-24 pulls in for its includers
+#include <stdio.h>
+#include <vector>
+#include <string>
+#include <iostream>
+#include <chrono>
+#include <math.h>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+#include <regex>
+#include <map>
+#include <array>
+#include <unordered_map>
 
 #include <cstdint>
 #include <stdexcept>
-#include <string>
-#include <unordered_map>
-#include <vector>
 
 #include "fx8010_amd.h"
 
-// the reference's compile-time settings that callers use (include/FX8010.h:37-42)
+using namespace std;  // include/FX8010.h:25 - part of what the reference header exports (main.cpp relies on it)
+
+// the reference's compile-time settings (include/FX8010.h:33-42)
+#ifndef E
+#define E 2.71828182845
+#endif
+#ifndef PI
+#define PI 3.14159265359
+#endif
 #ifndef SAMPLERATE
 #define SAMPLERATE 48000
 #endif
 #ifndef AUDIOBLOCKSIZE
 #define AUDIOBLOCKSIZE 32
+#endif
+#ifndef DEBUG
+#define DEBUG 0
+#endif
+#ifndef PRINT_REGISTERS
+#define PRINT_REGISTERS 0
 #endif
 #ifndef MAX_IDELAY_SIZE
 #define MAX_IDELAY_SIZE 8192
@@ -41,8 +83,10 @@ namespace Klangraum {
 
 class FX8010 {
 public:
+    // reference: FX8010(), include/FX8010.h:50 (declared only there)
+    FX8010() : FX8010(1) {}
     // reference: FX8010(int numChannels), include/FX8010.h:51
-    explicit FX8010(int numChannels) : h_(fx_create(numChannels)) {
+    FX8010(int numChannels) : h_(fx_create(numChannels)) {
         if (!h_) throw std::runtime_error(std::string("FX8010: ") + fx_last_create_error());
     }
     ~FX8010() { fx_destroy(h_); }

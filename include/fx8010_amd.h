@@ -152,8 +152,7 @@ enum {
     FXB_INFO_INST_PER_LANE = 15,   /* instances one lane steps (kernel variant)           */
     FXB_INFO_KERNEL = 16,          /* 0 = HIP C++ kernel; hand-written gfx950 interpreter: 1 = register file in LDS,
                                       2..8 = register file in VGPRs (64/72/80/96/128/168/256-VGPR build);
-                                      9..15 = program translated to gfx950 code, same seven VGPR builds;
-                                      20..23 = translated, two instances per lane (96/128/168/256-VGPR frame) */
+                                      9..15 = program translated to gfx950 code, same seven VGPR builds */
     FXB_INFO_NUM_ROWS = 17,        /* rows of the per-instance register file               */
     FXB_INFO_XLATE_CODE_BYTES = 18,/* translated program: bytes of machine code (both streams), else 0 */
     FXB_INFO_XLATE_INLINED = 19,   /* records of the steady stream turned into straight-line code */
@@ -198,8 +197,7 @@ int64_t fxp_lower_info(fxp_handle* h, int what);
  * build with `vgprs` registers (64/72/80/96/128/168/256; 0 = the smallest build that holds the program).
  * stream: 0 = steady fast, 1 = steady exact, 2 = last-sample fast, 3 = last-sample exact (fast streams assume a
  * finite register file and leave for the exact one when a non-finite value appears; a program with a non-finite
- * uniform operand has no fast streams: size 0); 4 = run-once code (LDS tables); +10 = the same for the frame with two
- * instances per lane (packed fp32; fails for programs that need SKIP or a handler call).  Returns the code size in bytes (negative FX_E_* when the program
+ * uniform operand has no fast streams: size 0); 4 = run-once code (LDS tables).  Returns the code size in bytes (negative FX_E_* when the program
  * cannot be translated, see fxp_last_error) and copies at most `cap` bytes of code and at most listing_cap-1
  * characters of the assembler listing (one instruction per line). */
 int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap);

@@ -13,12 +13,11 @@ from pyoracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["default", "xlate2", "xlate_v256", "asm", "asm_v256", "asm_lds", 1, 2, 4],
-                ids=["xlate", "xlate2", "xlate_v256", "asm", "asm_v256", "asm_lds", "k1", "k2", "k4"])
+@pytest.fixture(params=["default", "xlate_v256", "asm", "asm_v256", "asm_lds", 1, 2, 4],
+                ids=["xlate", "xlate_v256", "asm", "asm_v256", "asm_lds", "k1", "k2", "k4"])
 def k(request, monkeypatch):
     """kernel variant: the default choice (program translated to gfx950 code in the smallest VGPR build that
-    fits), the translation for the two-instances-per-lane frame where the program qualifies (packed fp32; others fall
-    back to one instance per lane), the translation forced into the 256-VGPR build, the hand-written interpreter (smallest VGPR build,
+    fits), the translation forced into the 256-VGPR build, the hand-written interpreter (smallest VGPR build,
     forced 256-VGPR build, forced LDS build), or the HIP C++ kernel with 1/2/4 instances per lane
     (FX_INST_PER_LANE pins it)"""
     monkeypatch.delenv("FX_KERNEL", raising=False)
@@ -86,10 +85,8 @@ def test_config_programs_bit_exact(gpu, name, k):
     regs = {"config2": ("t", "s30", "in", "out", "ccr"), "config3": ("rd", "a", "t", "ccr"), "config4": ("x", "a", "b", "o", "ccr"),
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
     b, _ = check_batch(gpu, text, x, regs=regs)
-    if k == "xlate2" and name in ("config2", "config3", "config5", "tram_bound"):
-        assert b.info("kernel") >= 20  # these translate for the pair frame
     if isinstance(k, str):
-        want = {"default": tuple(range(9, 16)), "xlate2": tuple(range(9, 24)), "xlate_v256": (15,), "asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
+        want = {"default": tuple(range(9, 16)), "xlate_v256": (15,), "asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
         assert b.info("kernel") in want and b.info("inst_per_lane") == 1
     else:
         assert b.info("kernel") == 0 and b.info("inst_per_lane") == k
@@ -156,7 +153,7 @@ def test_opcode_programs(gpu, name, k):
 
 
 @pytest.mark.parametrize("op,table", [("log", 1), ("log", 3), ("log", 16), ("log", 31), ("exp", 0), ("exp", 2), ("exp", 7), ("exp", 31)])
-@pytest.mark.parametrize("kern", ["xlate", "xlate2", "asm", "asm_lds", "hip"])
+@pytest.mark.parametrize("kern", ["xlate", "asm", "asm_lds", "hip"])
 def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
     """LOG/EXP on the device use precomputed thresholds/slopes instead of the reference's two fp64
     divisions: sweep random x, every table knot and its float neighbours, the domain edges."""
@@ -227,7 +224,7 @@ macs out, rd, b, 0.5
 end"""
 
 
-NONFINITE_PAIR_PROGRAM = HDR + """static t
+NONFINITE_PLAIN_PROGRAM = HDR + """static t
 static u
 static w
 itramsize 6 
@@ -243,15 +240,15 @@ end"""
 
 
 @pytest.mark.parametrize("case", ["nan_input", "inf_input", "nan_state", "inf_uniform", "plain"])
-def test_non_finite_values_in_the_pair_frame(gpu, k, case):
-    """as test_non_finite_values_follow_the_reference, with a program that qualifies for the two-instances-per-lane
-    frame (no wrap-around instruction, no SKIP): its own prologue / input / TRAM taint checks and both halves"""
-    N, S = 200, 40  # two pair waves, the second one ragged (72 instances: half 1 has 8)
+def test_non_finite_values_without_wrap_or_skip(gpu, k, case):
+    """as test_non_finite_values_follow_the_reference, with a program made of saturating instructions and TRAM only
+    (no wrap-around instruction, no SKIP, no handler call): prologue / input / TRAM taint checks"""
+    N, S = 200, 40  # four wavefronts, the last one ragged (8 instances)
     x = progs.stimulus(N, S).copy()
     if case == "nan_input":
         x[7, 3] = np.nan
-        x[20, 70] = -np.nan      # lane 6 of half 1
-        x[25, 199] = np.nan      # last instance: pair wave 1, half 1
+        x[20, 70] = -np.nan
+        x[25, 199] = np.nan      # last instance
     elif case == "inf_input":
         x[5, 64] = np.inf
         x[9, 1] = -np.inf
@@ -260,7 +257,7 @@ def test_non_finite_values_in_the_pair_frame(gpu, k, case):
         x[4, 10] = 0.0
         x[4, 75] = 0.0
     b = gpu.Batch(N, 1, 0)
-    assert b.load_text(NONFINITE_PAIR_PROGRAM), b.errors()
+    assert b.load_text(NONFINITE_PLAIN_PROGRAM), b.errors()
     if case == "nan_state":
         b.set_register_i("a", 33, float("nan"))
         b.set_register_i("a", 65, float("inf"))
@@ -268,12 +265,10 @@ def test_non_finite_values_in_the_pair_frame(gpu, k, case):
     elif case == "inf_uniform":
         b.set_register("vol", float("inf"))
     y = b.process_block(x)
-    if k == "xlate2":
-        assert b.info("kernel") >= 20
     saw_nan = False
     for n in range(N):
         o = Oracle(1)
-        assert o.load_text(NONFINITE_PAIR_PROGRAM)
+        assert o.load_text(NONFINITE_PLAIN_PROGRAM)
         if case == "nan_state" and n in (33, 197):
             o.set_register("a", float("nan"))
         if case == "nan_state" and n == 65:

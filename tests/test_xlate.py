@@ -71,48 +71,6 @@ def test_listing_reassembles_to_the_same_bytes(last):
     assert seen > 0
 
 
-@needs_llvm
-@pytest.mark.parametrize("stream", [10, 11, 12, 13, 14], ids=["steady_fast", "steady_exact", "last_fast", "last_exact", "run_once"])
-def test_pair_frame_listing_reassembles_to_the_same_bytes(stream):
-    """the streams for the two-instances-per-lane frame (v_pk_mul_f32 / v_pk_add_f32 and their modifiers)"""
-    seen = 0
-    for name, text in program_texts() + [("macsn_acc3", PAIR_MIX)]:
-        fe = A.FrontEnd(1)
-        assert fe.load_text(text), name
-        try:
-            code, listing = fe.translate(0, stream)
-        except RuntimeError:
-            continue  # SKIP or a handler call: not for this frame
-        if stream == 14 and not code:
-            continue
-        seen += 1
-        assert assemble(listing) == code, "%s: encoder and assembler disagree" % name
-        assert "s_setpc_b64 s[6" not in listing  # no handler calls (s[62:63]) in this frame
-    assert seen > 0
-
-
-PAIR_MIX = """static a = 0.25
-static b
-static c
-control g = 0.3
-input in 0
-output out 0
-macsn a, a, in, g
-macsn b, 0.5, a, in
-macs c, b, 0.25, 0.5
-acc3 b, a, in, c
-acc3 c, 0.125, 0.25, b
-acc3 a, in, 0.5, 0.0625
-interp b, a, in, c
-interp c, b, 0.0001, a
-interp out, c, g, in
-log b, out, 3, 0
-exp c, b, 7, 0
-log a, in, 5, 0
-macs out, out, b, a
-end"""
-
-
 def test_structure_of_translated_code():
     for name, text in program_texts():
         fe = A.FrontEnd(1)

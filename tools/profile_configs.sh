@@ -1,0 +1,25 @@
+#!/bin/bash
+# Evidence pass for the single-GPU configurations (run on the GPU box through gpurun):
+#   tools/profile_configs.sh <tag> [configs...]
+# Per config: the bench line without a profiler, rocprofv3 --kernel-trace --stats of the same command,
+# and the SQ counter passes (tools/pmc_sq.txt; fewer launches - counters serialise the kernel).
+# Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
+set -o pipefail
+TAG=${1:-r02}
+shift
+CONFIGS=${@:-config2 config3 config4 config5}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for c in $CONFIGS; do
+  echo "== $c: bench" 
+  python3 $ROOT/bench.py --config $c --cpu-seconds 0 > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err || exit 1
+  cat $OUT/${c}_bench.json
+  echo "== $c: kernel trace"
+  rocprofv3 --kernel-trace --stats -d $OUT/${c}_trace -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 > $OUT/${c}_bench_under_rocprof.json 2> $OUT/${c}_trace.err || exit 1
+  echo "== $c: SQ counters"
+  rocprofv3 -i $ROOT/tools/pmc_sq.txt -d $OUT/${c}_pmc -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 2 --warmup 1 > $OUT/${c}_pmc.json 2> $OUT/${c}_pmc.err || exit 1
+done
+find $OUT -name "*kernel_stats.csv" | head
+echo done
