@@ -276,7 +276,7 @@ int Batch::ensureLowered() {
     } else if (useAsm_ && asmVariant_ != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
         // first choice for a VGPR build: translate the program into gfx950 code (FX_KERNEL=asm* pins the interpreter)
         const std::vector<MicroOp> steadyRecords = encodeAsmStream(low_.steady, nullptr, true), lastRecords = encodeAsmStream(low_.last, nullptr, true);
-        XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow);
+        XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow, low_.latchRow);
         XlateImage image;
         const XlateTemplate* tmpl = nullptr;
         bool built = false;

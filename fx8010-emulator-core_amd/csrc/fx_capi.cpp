@@ -220,7 +220,7 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t 
     std::string text4[5];
     fx::XlateImage plan;
     const std::vector<fx::MicroOp> steadyRecords = fx::encodeAsmStream(low.steady, nullptr, true), lastRecords = fx::encodeAsmStream(low.last, nullptr, true);
-    fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow);
+    fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow);
     if (!fx::planXlate(steadyRecords, lastRecords, *tmpl, xprog, &plan, code4, text4, &h->err)) return FX_E_PROGRAM;
     const std::vector<uint32_t>& words = code4[stream];
     const std::string& text = text4[stream];

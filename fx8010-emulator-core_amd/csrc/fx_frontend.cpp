@@ -320,6 +320,22 @@ Luts::Luts() {
     }
 }
 
+namespace {
+// smallest float x whose t = (double)x - -1.0 reaches the bound
+float firstFloatReaching(double bound) {
+    float x = (float)(bound - 1.0);
+    while ((double)x - -1.0 >= bound) x = std::nextafterf(x, -4.0f);
+    while ((double)x - -1.0 < bound) x = std::nextafterf(x, 4.0f);
+    return x;
+}
+}  // namespace
+
+void lutDomainBounds(float out[2]) {
+    const double step = (1.0 - -1.0) / 63.0;
+    out[0] = firstFloatReaching(-step);
+    out[1] = firstFloatReaching(64.0 * step);
+}
+
 LutDevice::LutDevice(const Luts& l) : blob(kLutBlobDoubles, 0.0), invStep(63.0 / 2.0) {
     const double step = (1.0 - -1.0) / 63.0;
     auto indexOf = [&](double t) { return (int)(t / step); };  // t in [0, 2]: in range, plain truncation
@@ -344,20 +360,13 @@ LutDevice::LutDevice(const Luts& l) : blob(kLutBlobDoubles, 0.0), invStep(63.0 /
             blob[kLutSegOff + (tsel * 64 + k) * 2 + 1] = y1;
         }
     }
-    // fp32 thresholds: smallest float x whose t = (double)x - -1.0 reaches the bound
-    auto firstFloatReaching = [](double bound) {
-        float x = (float)(bound - 1.0);
-        while ((double)x - -1.0 >= bound) x = std::nextafterf(x, -4.0f);
-        while ((double)x - -1.0 < bound) x = std::nextafterf(x, 4.0f);
-        return x;
-    };
+    // fp32 thresholds
     float* xthr = reinterpret_cast<float*>(&blob[kLutXthrOff]);
     xthr[0] = -HUGE_VALF;
     for (int k = 1; k <= 63; ++k) xthr[k] = firstFloatReaching(blob[kLutThrOff + k]);
     xthr[64] = xthr[65] = HUGE_VALF;
     float* xdom = reinterpret_cast<float*>(&blob[kLutXdomOff]);
-    xdom[0] = firstFloatReaching(-step);
-    xdom[1] = firstFloatReaching(64.0 * step);
+    lutDomainBounds(xdom);
 }
 
 }  // namespace fx

@@ -184,8 +184,10 @@ KNAME:
 	// FX8010.cpp:275-279).
 	s_mov_b64 s[78:79], 0
 	v_mov_b32 v29, 0x207                                  // v_cmp_class mask: sNaN | qNaN | -Inf | +Inf
-	s_add_u32 s34, s32, (h_endsample_a-KNAME)
-	s_addc_u32 s35, s33, 0                                // s[34:35] = end-of-sample code (translated streams end with s_setpc_b64 s[34:35])
+	s_add_u32 s34, s32, (.Lepilogue-KNAME)
+	s_addc_u32 s35, s33, 0                                // s[34:35] = epilogue (the translated last-sample stream ends with s_setpc_b64 s[34:35])
+	s_mov_b32 s94, 0                                      // no TRAM read of the first sample is in flight yet
+	s_mov_b32 s95, 0                                      // early TRAM reads: allowed only if the run-once code says so
 #endif
 	s_load_dwordx8  s[48:55], s[0:1], KA_INOFF            // inOff[4] latchOff[4]
 	s_load_dwordx4  s[64:67], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
@@ -271,9 +273,10 @@ KNAME:
 	s_addc_u32 s67, s67, 0
 	global_load_dword v21, v27, s[66:67]
 #ifdef XLATE
-	// run-once code of the translated program (copies the LOG/EXP tables it uses into LDS); returns through s[24:25]
+	// run-once code of the translated program (copies the LOG/EXP tables it uses into LDS, decides from the TRAM
+	// cursors whether reads may be issued a sample ahead); returns through s[24:25]
 	s_load_dword s62, s[0:1], KA_INIT
-	s_waitcnt lgkmcnt(0)
+	s_waitcnt vmcnt(0) lgkmcnt(0)
 	s_cmp_eq_u32 s62, 0
 	s_cbranch_scc1 .Lno_init
 	s_add_u32 s62, s62, s32
@@ -326,18 +329,21 @@ KNAME:
 	s_mov_b64 exec, -1
 	s_waitcnt vmcnt(0)
 
+#ifdef XLATE
+	// The translated program IS the sample loop (fx_xlate.cpp: input rows, program, PCM out, next sample); it comes
+	// back at the epilogue.  Cold entries: `steady` = {fast, exact} while more than one sample is left, else `last`;
+	// a wave tainted by its state rows starts in the exact stream.
+	s_cmp_eq_u32 s9, 1
+	s_cselect_b32 s4, s42, s6
+	s_cselect_b32 s5, s43, s7
+	s_cmp_lg_u64 s[78:79], 0
+	s_cselect_b32 s4, s5, s4
+	s_add_u32 s4, s4, s32
+	s_addc_u32 s5, s33, 0
+	s_setpc_b64 s[4:5]
+#else
 	// ---- one sample period
 .Lsample:
-#ifdef XLATE
-	v_cmp_class_f32 vcc, v23, v29                         // non-finite PCM input taints (unused channels hold 0)
-	s_or_b64 s[78:79], s[78:79], vcc
-	v_cmp_class_f32 vcc, v24, v29
-	s_or_b64 s[78:79], s[78:79], vcc
-	v_cmp_class_f32 vcc, v25, v29
-	s_or_b64 s[78:79], s[78:79], vcc
-	v_cmp_class_f32 vcc, v26, v29
-	s_or_b64 s[78:79], s[78:79], vcc
-#endif
 	// this sample's input -> LDS rows
 	s_cmp_lt_i32 s48, 0
 	s_cbranch_scc1 .Ls_w1
@@ -404,13 +410,6 @@ KNAME:
 	s_cselect_b32 s4, s42, s6
 	s_cselect_b32 s5, s43, s7
 	v_mov_b32 v14, 0                                      // numSkip is local to process() (FX8010.cpp:1030)
-#ifdef XLATE
-	s_cmp_lg_u64 s[78:79], 0                              // tainted wave: exact stream (high dword), else fast stream
-	s_cselect_b32 s4, s5, s4
-	s_add_u32 s4, s4, s32
-	s_addc_u32 s5, s33, 0
-	s_setpc_b64 s[4:5]                                    // the translated program of this sample
-#else
 	s_load_dwordx16 s[16:31], s[4:5], 0x0                 // records 0, 1
 	s_load_dwordx16 s[80:95], s[4:5], 0x40                // records 2, 3
 	s_mov_b32 s8, 128
@@ -548,7 +547,11 @@ OTABLE:
 
 #endif
 
-// ---- end of the program for this sample: latch rows -> PCM out, next sample
+// ---- end of the program for this sample: latch rows -> PCM out, next sample (interpreter builds; a translated
+// program has its own)
+#ifdef XLATE
+h_endsample_a:
+#else
 h_endsample_a:
 h_endsample_b:
 h_endsample_c:
@@ -589,6 +592,7 @@ h_endsample_d:
 	s_cmp_lt_i32 s3, s9
 	s_waitcnt vmcnt(0)
 	s_cbranch_scc1 .Lsample
+#endif
 
 	// ---- epilogue: LDS rows and VGPR state -> state rows
 .Lepilogue:

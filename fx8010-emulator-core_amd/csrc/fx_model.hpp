@@ -104,6 +104,8 @@ constexpr int kLutSegOff = 66 + 64;
 constexpr int kLutXthrOff = kLutSegOff + 64 * 64 * 2;  // 66 floats = 33 doubles
 constexpr int kLutXdomOff = kLutXthrOff + 33;          // 2 floats = 1 double
 constexpr int kLutBlobDoubles = kLutXdomOff + 1;
+// xdom[2] of the blob: the fp32 operand range [xdom[0], xdom[1]) inside which the segment index is 0..63
+void lutDomainBounds(float out[2]);
 struct LutDevice {
     std::vector<double> blob;
     double invStep;  // 63/2: only used to guess idx, the thresholds decide

@@ -173,6 +173,46 @@ class Emitter {
 
     size_t bytes() const { return w_.size() * 4; }
     int count() const { return count_; }
+    // the listing is kept as lines until the stream is complete (forward branches are patched in place)
+    void finish() {
+        if (!text_) return;
+        for (const std::string& l : lines_) { *text_ += l; *text_ += '\n'; }
+        lines_.clear();
+    }
+
+    // a SOPP branch whose target is not known yet; bind() fixes it to the then-current position
+    struct Fixup { size_t word = 0, lineNo = 0; std::string name; };
+    Fixup branchForward(uint32_t op, const char* name) {
+        Fixup f;
+        f.word = w_.size();
+        f.lineNo = lines_.size();
+        f.name = name;
+        w_.push_back(0xbf800000u | (op << 16));
+        ++count_;
+        if (text_) lines_.push_back(std::string(name) + " 0");
+        return f;
+    }
+    void bind(const Fixup& f) {
+        const size_t delta = w_.size() - (f.word + 1);
+        w_[f.word] = (w_[f.word] & 0xffff0000u) | (uint32_t)(delta & 0xffffu);
+        if (text_) lines_[f.lineNo] = f.name + " " + std::to_string(delta);
+    }
+    // branch to a position already emitted (word index inside this stream)
+    bool branchBack(uint32_t op, const char* name, size_t targetWord) {
+        const int64_t delta = (int64_t)targetWord - ((int64_t)w_.size() + 1);
+        if (delta < -32768) return false;
+        sopp(op, name, (uint32_t)delta & 0xffffu, true);
+        return true;
+    }
+    size_t words() const { return w_.size(); }
+    // s_waitcnt vmcnt(n), the other counters left alone (n <= 63: bits 3:0 and 15:14)
+    void waitVmcnt(int n) {
+        if (n > 63) n = 63;
+        if (n < 0) n = 0;
+        w_.push_back(0xbf8c0000u | 0x0f70u | (uint32_t)(n & 15) | ((uint32_t)(n >> 4) << 14));
+        ++count_;
+        if (text_) line("s_waitcnt vmcnt(" + std::to_string(n) + ")");
+    }
 
     void vop2(uint32_t op, const char* name, int vdst, const Src& src0, int vsrc1, const char* tail = "") {
         put((op << 25) | ((uint32_t)vdst << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
@@ -227,11 +267,7 @@ class Emitter {
         if (load) line("global_load_dword v" + std::to_string(vdata) + ", v" + std::to_string(vaddr) + ", " + base);
         else line("global_store_dword v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + ", " + base);
     }
-    void waitVmcnt0() {
-        w_.push_back(0xbf8c0f70u);
-        ++count_;
-        if (text_) line("s_waitcnt vmcnt(0)");
-    }
+    void waitVmcnt0() { waitVmcnt(0); }
     // global_load_dwordx2 / x4 into v[vdata ..], VGPR byte offset, SGPR base pair
     void globalLoadWide(uint32_t op, int dwords, int vdata, int vaddr, int sbase) {
         w_.push_back(0xdc008000u | (op << 18));
@@ -304,6 +340,8 @@ class Emitter {
     }
     void sopc(uint32_t op, const char* name, const Src& s0, const Src& s1) {
         w_.push_back(0xbf000000u | (op << 16) | (s1.code << 8) | s0.code);
+        if (s1.hasLit) w_.push_back(s1.lit);
+        else if (s0.hasLit) w_.push_back(s0.lit);
         ++count_;
         if (text_) line(std::string(name) + " " + s0.text + ", " + s1.text);
     }
@@ -320,11 +358,12 @@ class Emitter {
         ++count_;
     }
     void line(const std::string& t) {
-        if (text_) { *text_ += t; *text_ += '\n'; }
+        if (text_) lines_.push_back(t);
     }
     bool listing() const { return text_ != nullptr; }
     std::vector<uint32_t>& w_;
     std::string* text_;
+    std::vector<std::string> lines_;
     int count_ = 0;
 };
 
@@ -335,12 +374,12 @@ enum : uint32_t {
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
-    SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
+    SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_LT_U32 = 0x0a, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
     SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
     VOP2_ADDC_CO_U32 = 0x1c, VOP3B_SUBBREV_CO_U32 = 0x11e,
-    VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49,
+    VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49, VOPC_CMP_NGT_F32 = 0x4b, VOPC_CMP_NLE_F32 = 0x4c,
     VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
@@ -363,58 +402,149 @@ constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane
 constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read
 constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
 constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
-// LUT tables in LDS: fp32 thresholds (66) + domain bounds (2), then per table 64 entries {slope, y1, x1, pad} of 32 bytes
-constexpr uint32_t kLdsXthr = 0, kLdsXdom = 264, kLdsSeg = 272, kLdsSegBytes = 2048;
+// LUT tables in LDS, every array indexed by segment * 8 bytes (ds_read_b64: at most two lanes of a 32-lane group share
+// a bank): {xthr[g], xthr[g+1]} fp32 pairs | x1[64] fp64 | per table slope[64] fp64, y1[64] fp64
+constexpr uint32_t kLdsThr = 0, kLdsX1 = 512, kLdsTables = 1024, kLdsTableBytes = 1024;
 constexpr int kSLut = 40;          // s[40:41] = LUT blob
 constexpr int kSLutXthr = 88, kSLutX1 = 90, kSLutSeg = 92;  // s[88:93]: bases of the fp32 thresholds, x1[] and the current table's segments
 constexpr int kSTramBase[2] = {36, 38}, kSTramSize[2] = {56, 57}, kSTramSlots[2] = {46, 47};  // [iTRAM, xTRAM]
+// the sample loop (frame registers of fx_interp_gfx950.S)
+constexpr int kSSample = 3, kSNumSamples = 9;       // sample index, block length
+constexpr int kSPcmIn = 12, kSPcmOut = 14;          // s[12:13] / s[14:15]: PCM in / out of the current sample
+constexpr int kSSampleBytes = 45, kSChannelBytes = 68;  // bytes per sample (channels * N * 4) and per channel-sample (N * 4)
+constexpr int kSValidLanes = 58;                    // s[58:59]: lanes that hold an instance
+constexpr int kVInput = 23;                         // v23..v26: PCM input of the current sample, channel 0..3 (requested one sample ahead)
+constexpr int kVInstance4 = 27;                     // v27 = instance * 4: byte offset into a PCM / state row
+constexpr int kSPrefetched = 94;                    // s94 = 1: the leading TRAM reads of this sample are already in flight
+constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
 
 class Translator {
   public:
     // exactReturns == nullptr: the exact stream (NaN passes every saturation).  Otherwise the fast stream, which
-    // assumes finite register contents and leaves for the exact stream - at the return address of the same
-    // call there, exactReturns[i] for record i - as soon as a handler has tainted the wave.
-    Translator(const XlateTemplate& t, const XlateProgram& prog, uint32_t codeBase, std::vector<uint32_t>* code, std::string* listing,
-               const std::vector<uint32_t>* exactReturns)
-        : tmpl_(t), prog_(prog), base_(codeBase), e_(code, listing), fast_(exactReturns != nullptr), exactReturns_(exactReturns) {}
+    // assumes finite register contents and leaves for the exact stream - at the same point there,
+    // exactReturns[key] - as soon as the wave is tainted.
+    Translator(const XlateTemplate& t, const XlateProgram& prog, uint32_t codeBase, bool isLast, uint32_t nextBase, std::vector<uint32_t>* code,
+               std::string* listing, const std::vector<uint32_t>* exactReturns)
+        : tmpl_(t), prog_(prog), base_(codeBase), isLast_(isLast), nextBase_(nextBase), e_(code, listing), fast_(exactReturns != nullptr),
+          exactReturns_(exactReturns) {}
 
-    bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::vector<uint32_t>* returns, std::string* err) {
-        bool ended = false;
-        // sync points, two per record (+ the stream end): [2i] after the wait for TRAM reads pending before record i,
-        // [2i+1] the return address of record i's handler call
+    // Layout of a stream:  head (hot entry) | program | PCM out, advance, loop branch / exit | cold entry stub
+    bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::vector<uint32_t>* returns, uint32_t* coldEntry, std::string* err) {
+        // sync points: per record i [4i] after the wait for TRAM reads pending before it, [4i+1] behind its handler call /
+        // inline LUT, [4i+2] after the wait in front of the early reads that follow it; [4n] the head of the loop body
+        // (inputs and leading reads consumed, next input requested)
         returns_.assign(4 * records.size() + 4, 0);
+        records_ = &records;
+        const HoistPlan& H = prog_.hoist;
+        const int channels = (int)prog_.latchRows.size();
+        if (channels < 1 || prog_.inRows.size() != prog_.latchRows.size()) { if (err) *err = "internal: channel rows missing"; return false; }
+        bool usesSkipCounter = false, anyLut = false;
+        for (const MicroOp& r : records) {
+            usesSkipCounter = usesSkipCounter || r.w[0] == AS_PRED || r.w[0] == AS_SKIP;
+            anyLut = anyLut || r.w[0] == AS_LUT;
+        }
+        // ---- head: this sample's operands that come from memory
+        const size_t headWord = e_.words();
+        const int storesPerSample = channels;
+        if (H.leadCount > 0) {
+            // the leading TRAM reads were issued one sample ago (s94 = 1) or are issued here (first sample of a launch, or
+            // a launch whose cursor distance rules the early issue out)
+            e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSPrefetched), imm32(1));
+            Emitter::Fixup toHot = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
+            for (int k = 0; k < H.leadCount; ++k)
+                if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false)) { if (err) *err = err_; return false; }
+            e_.waitVmcnt(0);
+            Emitter::Fixup toJoin = e_.branchForward(SOPP_BRANCH, "s_branch");
+            e_.bind(toHot);
+            e_.waitVmcnt(H.vmemAfterHoist + storesPerSample);  // younger than the reads: the rest of that sample's TRAM traffic and its PCM stores
+            e_.bind(toJoin);
+            e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSPrefetched), imm32(0));
+        } else {
+            e_.waitVmcnt(prog_.tramOpsInline + storesPerSample);  // the PCM input requested one sample ago
+        }
+        if (fast_) {
+            for (int c = 0; c < channels; ++c)
+                if (prog_.inRows[(size_t)c] >= 0) taintIfNonFinite(kVInput + c);
+            for (int k = 0; k < H.leadCount; ++k) taintCheckRow(vrow(records[(size_t)k].w[5]));
+        }
+        for (int c = 0; c < channels; ++c) {
+            int v;
+            if (prog_.inRows[(size_t)c] < 0) continue;
+            if (!row((uint32_t)prog_.inRows[(size_t)c], &v)) { if (err) *err = err_; return false; }
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(v), vreg(kVInput + c));
+        }
+        if (!isLast_) pcmAccess(true, kSPcmIn, true);  // next sample's input; it lands behind this sample's program
+        if (usesSkipCounter) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVNumSkip), imm32(0));  // numSkip is local to process() (FX8010.cpp:1030)
+        index_ = records.size();
+        returns_[syncIndex(0)] = base_ + (uint32_t)e_.bytes();
+        if (fast_ && !leaveIfTainted((*exactReturns_)[syncIndex(0)])) { if (err) *err = err_; return false; }
+
+        // ---- the program
+        bool ended = false;
+        for (size_t i = 0; i < records.size(); ++i) {
+            const MicroOp& r = records[i];
+            const uint32_t slot = r.w[0];
+            index_ = i;
+            if (slot == AS_ENDSAMPLE) { ended = true; break; }
+            if ((int)i >= H.leadCount && i != consumed_ && !one(r, slot)) { if (err) *err = err_; return false; }
+            if (!isLast_ && H.leadCount > 0 && (int)i == std::max(H.hoistAfter, H.leadCount - 1)) {
+                // the next sample's leading reads, unless this launch keeps them in place (s95 = 0, see emitInit)
+                if (predOpen_ || regionPreds_ > 0) { if (err) *err = "internal: hoist point inside a SKIP shadow"; return false; }
+                if (!flush(2)) { if (err) *err = err_; return false; }
+                plainMode();
+                e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSHoistOk), imm32(0));
+                Emitter::Fixup skip = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
+                for (int k = 0; k < H.leadCount; ++k)
+                    if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false)) { if (err) *err = err_; return false; }
+                e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSPrefetched), imm32(1));
+                e_.bind(skip);
+            }
+        }
+        if (!ended) { if (err) *err = "record stream without ENDSAMPLE"; return false; }
+        index_ = records.size();
+        if (!flush()) { if (err) *err = err_; return false; }
+
+        // ---- PCM out, next sample
+        plainMode();
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+        pcmAccess(false, kSPcmOut, false);
+        for (int q : {kSPcmIn, kSPcmOut}) {
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(q), sreg(q), sreg(kSSampleBytes));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(q + 1), sreg(q + 1), imm32(0));
+        }
+        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSample), sreg(kSSample), imm32(1));
+        if (!isLast_) {
+            // loop while the sample after this one is not the block's last, then on to the last-sample stream
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSSample), imm32(1));
+            e_.sopc(SOPC_CMP_LT_U32, "s_cmp_lt_u32", sreg(kSTemp), sreg(kSNumSamples));
+            if (!e_.branchBack(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
+            const int64_t delta = ((int64_t)nextBase_ - ((int64_t)base_ + (int64_t)e_.bytes() + 4)) / 4;
+            if (delta < -32768 || delta > 32767) { if (err) *err = "last-sample stream out of branch range"; return false; }
+            e_.sopp(SOPP_BRANCH, "s_branch", (uint32_t)delta & 0xffffu, true);
+        } else {
+            if (prog_.uniformCursors) {
+                for (int c = 0; c < 4; ++c) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVCursor + c), sreg(kSCursor + c));
+                e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, sreg(kSOod), kVOod);
+            }
+            e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSEndSample));  // the template's epilogue
+        }
+
+        // ---- cold entry (from the template): scalar copies of what the loop keeps in SGPRs
+        if (coldEntry) *coldEntry = base_ + (uint32_t)e_.bytes();
         if (prog_.uniformCursors) {
             // every TRAM instruction runs on all lanes: the four cursors are the same in every lane, keep them in SGPRs
             for (int c = 0; c < 4; ++c) e_.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSCursor + c), vreg(kVCursor + c));
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
         }
-        bool anyLut = false;
-        for (const MicroOp& r : records) anyLut = anyLut || r.w[0] == AS_LUT;
         if (anyLut && prog_.lutTables.empty()) {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutXthr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutXthr + 1), sreg(kSLut + 1), imm32(0));
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutX1), sreg(kSLut), imm32((uint32_t)kLutX1Off * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutX1 + 1), sreg(kSLut + 1), imm32(0));
         }
-        records_ = &records;
-        for (size_t i = 0; i < records.size(); ++i) {
-            const MicroOp& r = records[i];
-            const uint32_t slot = r.w[0];
-            index_ = i;
-            if (slot == AS_ENDSAMPLE) { ended = true; break; }
-            if (i == consumed_) continue;  // a SKIP fused into the instruction that set its CCR
-            if (!one(r, slot)) { if (err) *err = err_; return false; }
-        }
-        if (!ended) { if (err) *err = "record stream without ENDSAMPLE"; return false; }
-        if (!flush()) { if (err) *err = err_; return false; }
-        if (prog_.uniformCursors) {
-            plainMode();
-            for (int c = 0; c < 4; ++c) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVCursor + c), sreg(kSCursor + c));
-            e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, sreg(kSOod), kVOod);
-        }
+        if (!e_.branchBack(SOPP_BRANCH, "s_branch", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
+        e_.finish();
         if (returns) *returns = returns_;
-        // the end-of-sample frame sets up its own index mode; EXEC is reset there as well
-        e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSEndSample));
         if (stats) { *stats = stats_; stats->instructions = e_.count(); stats->nonFiniteImmediate = nonFinite_; }
         return true;
     }
@@ -432,21 +562,52 @@ class Translator {
         return true;
     }
 
-    // TRAM reads are issued without waiting; the wait (and, in the fast stream, the taint check of what arrived
-    // and the hand-over to the exact stream) happens here, before the first use of such a row
-    bool flush() {
+    // the fast stream's entrance checks (fx_xlate.hpp "taint"): a value that came from memory into register v
+    void taintIfNonFinite(int v) {
+        e_.vopc(VOPC_CMP_CLASS_F32, "v_cmp_class_f32_e32", vreg(v), kVClassMask);
+        e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
+    }
+    // a row of the bounded class must stay inside [-1, 1] (NaN fails the test as well); any other must stay finite
+    void taintCheckRow(int v) {
+        if (!isBoundedVgpr(v)) { taintIfNonFinite(v); return; }
+        e_.vop3cmp(VOP3_CMP_NLE_F32, "v_cmp_nle_f32_e64", vreg(v), true, imm32(0x3f800000u));
+        e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
+    }
+
+    // PCM rows of all channels: load v23.. (of the NEXT sample when `next`) or store the output latch rows
+    void pcmAccess(bool load, int sbase, bool next) {
+        const int channels = (int)prog_.latchRows.size();
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), sreg64(kSValidLanes));
+        if (next) {
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(sbase), sreg(kSSampleBytes));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(sbase + 1), imm32(0));
+        } else {
+            e_.sop1(SOP1_MOV_B64, "s_mov_b64", sreg64(kSAddr), sreg64(sbase));
+        }
+        for (int c = 0; c < channels; ++c) {
+            if (load) {
+                if (prog_.inRows[(size_t)c] >= 0) e_.global(GLOBAL_LOAD_DWORD, true, kVInput + c, kVInstance4, kSAddr);
+            } else {
+                e_.global(GLOBAL_STORE_DWORD, false, vrow((uint32_t)prog_.latchRows[(size_t)c]), kVInstance4, kSAddr);
+            }
+            if (c + 1 < channels) {
+                e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSAddr), sreg(kSChannelBytes));
+                e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSAddr + 1), imm32(0));
+            }
+        }
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+    }
+
+    // TRAM reads in the middle of a program are issued without waiting; the wait (and, in the fast stream, the taint
+    // check of what arrived and the hand-over to the exact stream) happens here, before the first use of such a row
+    bool flush(int key = 0) {
         if (pending_.empty()) return true;
-        e_.waitVmcnt0();
-        returns_[syncIndex(0)] = base_ + (uint32_t)e_.bytes();
+        e_.waitVmcnt(0);
+        returns_[syncIndex(key)] = base_ + (uint32_t)e_.bytes();
         if (fast_) {
             plainMode();
-            for (int v : pending_) {
-                // a row of the bounded class must stay inside [-1, 1] (NaN fails the test as well); any other finite
-                if (isBoundedVgpr(v)) e_.vop3cmp(VOP3_CMP_NLE_F32, "v_cmp_nle_f32_e64", vreg(v), true, imm32(0x3f800000u));
-                else e_.vopc(VOPC_CMP_CLASS_F32, "v_cmp_class_f32_e32", vreg(v), kVClassMask);
-                e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
-            }
-            if (!leaveIfTainted((*exactReturns_)[syncIndex(0)])) return false;
+            for (int v : pending_) taintCheckRow(v);
+            if (!leaveIfTainted((*exactReturns_)[syncIndex(key)])) return false;
         }
         pending_.clear();
         return true;
@@ -481,9 +642,12 @@ class Translator {
     }
 
     // LOG / EXP with a per-lane operand and a uniform table (FX8010.cpp:1113-1125, linearInterpolate :283-296), from
-    // the host tables of fx_model.hpp: idx is found from the fp32 operand itself (guess (x+1)*31.5, corrected
-    // against the two neighbouring fp32 thresholds), then y = slope * ((double)x - x1) + y1, two roundings as the
-    // reference's.  Bit-identical to the interpreter's h_lut (dense sweep in tests/test_gpu_parity.py).
+    // the host tables of fx_model.hpp.  The segment index is a monotone step function of the fp32 operand: guess
+    // g = (int)((x + 1) * 31.5), then y = slope[g] * ((double)x - x1[g]) + y1[g] with the reference's two roundings.
+    // The guess is off by one only within a few ulp of a threshold, so everything segment g needs - its two fp32
+    // thresholds included - is fetched in ONE round trip (LDS: four conflict-light ds_read_b64), the thresholds
+    // check the guess, and the rare miss takes a second trip with the corrected index.
+    // Bit-identical to the interpreter's h_lut (dense sweep in tests/test_gpu_parity.py).
     bool lut(const MicroOp& r) {
         int vA, vR;
         if (!touch(r, true, false, false, true) || !row(r.w[2], &vA) || !row(r.w[5], &vR)) return false;
@@ -503,54 +667,57 @@ class Translator {
         // index are in 0..63 by construction and nothing can be out of the domain.  Everywhere else (wild operand, or the
         // exact stream, which a wave enters precisely when that invariant broke) the index is clamped and the flag derived.
         const bool guarded = operandWild || !fast_;
+        Src zero = imm32(0), top = imm32(63), vcc = named(106, "vcc");
         e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x3f800000u), vA);
         e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 6, imm32(0x41fc0000u), 6);                  // * 31.5
         e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
-        Src zero = imm32(0), top = imm32(63), vcc = named(106, "vcc");
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
-        e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
-        if (lds) {
-            e_.dsRead2B32(8, 7, kLdsXthr / 4, kLdsXthr / 4 + 1);
-            e_.waitLgkm0();
-        } else {
-            e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSLutXthr);                    // xthr[g], xthr[g+1]
-            e_.waitVmcnt0();
-        }
+        const uint32_t slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes, y1Off = slopeOff + 512;
+        auto fetchSegment = [&](bool withThresholds) {
+            if (lds) {
+                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+                if (withThresholds) e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);   // xthr[g], xthr[g+1]
+                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, kLdsX1);                       // x1[g]
+                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 2, 7, slopeOff);
+                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 4, 7, y1Off);
+            } else {
+                if (withThresholds) {
+                    e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
+                    e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSLutXthr);                // xthr[g], xthr[g+1]
+                }
+                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+                e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                     // x1[g]
+                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
+                e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                     // slope, y1
+            }
+        };
+        fetchSegment(true);
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
+        if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
         e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // x >= xthr[g+1]: one up
         e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));      // x <  xthr[g]  : one down
-        // (two instructions between a VALU write of VCC / an SGPR pair and the VALU read of it)
-        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
+        e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTemp + 2), vcc, sreg64(kSTemp));
+        e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTemp + 2), imm32(0));
+        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        // (two instructions lie between the VALU writes of VCC / the SGPR pair and the VALU reads below)
         e_.addCarry(6);
         e_.subBorrow(6, kSTemp, kSTemp + 2);
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
-        if (lds) {
-            const uint32_t table = kLdsSeg + (uint32_t)ldsTable * kLdsSegBytes;
-            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(5), 6);
-            e_.dsRead(DS_READ_B128, "ds_read_b128", 4, 2, 7, table);                        // slope, y1
-            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, table + 16);                    // x1[idx]
-            if (guarded) {
-                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
-                e_.dsRead2B32(8, 7, kLdsXdom / 4, kLdsXdom / 4 + 1);
-            }
-            e_.waitLgkm0();
-        } else {
-            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
-            e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                     // x1[idx]
-            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
-            e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                     // slope, y1
-            if (guarded) {
-                e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutXdomOff * 8, true));
-                e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
-                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(7), imm32(0));
-                e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSAddr);
-            }
-            e_.waitVmcnt0();
-        }
+        fetchSegment(false);
+        if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
+        e_.bind(hit);
         if (guarded) {
-            // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it
-            e_.vopc(VOPC_CMP_NGE_F32, "v_cmp_nge_f32_e32", vreg(vA), 8);
-            e_.vop3cmpTo(VOP3_CMP_NLT_F32, "v_cmp_nlt_f32_e64", kSTemp, vreg(vA), vreg(9));
-            e_.sop2(SOP2_OR_B64, "s_or_b64", named(106, "vcc"), named(106, "vcc"), sreg64(kSTemp));
+            // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it.  The two
+            // bounds are constants of the table grid (fx_model.hpp xdom): !(lo <= x) or !(hi > x)
+            float dom[2];
+            lutDomainBounds(dom);
+            uint32_t lo, hi;
+            std::memcpy(&lo, &dom[0], 4);
+            std::memcpy(&hi, &dom[1], 4);
+            e_.vopc(VOPC_CMP_NLE_F32, "v_cmp_nle_f32_e32", imm32(lo, true), vA);
+            e_.sop1(SOP1_MOV_B64, "s_mov_b64", sreg64(kSTemp), vcc);
+            e_.vopc(VOPC_CMP_NGT_F32, "v_cmp_ngt_f32_e32", imm32(hi, true), vA);
+            e_.sop2(SOP2_OR_B64, "s_or_b64", vcc, vcc, sreg64(kSTemp));
             Src flag = imm32(16);
             e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(7), zero, flag, &vcc);
             e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, vreg(kVOod), 7);
@@ -561,8 +728,7 @@ class Translator {
         e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
         returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
         if (operandWild && fast_) {  // a wild operand can be Inf / NaN, and then so is the result
-            e_.vopc(VOPC_CMP_CLASS_F32, "v_cmp_class_f32_e32", vreg(vR), kVClassMask);
-            e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
+            taintIfNonFinite(vR);
             if (!leaveIfTainted((*exactReturns_)[syncIndex(1)])) return false;
         }
         return true;
@@ -570,61 +736,95 @@ class Translator {
 
     // IDELAY / XDELAY with uniform cursors (fx_interp_handlers.inc TRAM_READ / TRAM_WRITE are the per-lane versions;
     // FX8010.cpp:909-967).  Slot arithmetic, bounds and cursor update are scalar; the lanes only move data.
-    bool tram(const MicroOp& r, uint32_t slot) {
-        const bool isRead = slot == AS_TRAM_IR || slot == AS_TRAM_XR;
-        const int t = (slot == AS_TRAM_IR || slot == AS_TRAM_IW) ? 0 : 1;
-        const int cursor = kSCursor + 2 * t + (isRead ? 1 : 0);
-        const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
-        if (!touch(r, !isRead && !(r.w[6] & 1u), false, false, isRead)) return false;
-        plainMode();
-        int vR = 0;
-        if (isRead && !row(r.w[5], &vR)) return false;
-        if (size < 1) {  // the reference would divide by zero: flagged, the read yields 0
-            if (isRead) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
-            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
-            return true;
-        }
+    // Every path issues exactly one vector memory operation or waits for all of them (s_waitcnt vmcnt(0) on the
+    // out-of-range path), so that "operations issued after this one" can be counted when the code is generated.
+    static int tramOf(uint32_t slot) { return (slot == AS_TRAM_IR || slot == AS_TRAM_IW) ? 0 : 1; }
+    int32_t tramOffset(const MicroOp& r, int32_t size) const {
         int32_t p = x86Trunc(r.w[4]);
         p = p > size - 1 ? size - 1 : p;
-        p = p < 0 ? 0 : p;
-        const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
-        if (isRead) {
-            if (p != 0) {
-                e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
-                e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", sreg(kSPos), imm32(0));
-                e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 2, true);
-                e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(kSPos), sreg(kSTramSize[t]));  // C's % keeps it negative: flagged
-                e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(1));
-            }
-            e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSTramSlots[t]));
-            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6, true);
-            e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSPos), pos, imm32(8));
-            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSTramBase[t]), sreg(kSPos));
-            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSTramBase[t] + 1), imm32(0));
-            e_.global(GLOBAL_LOAD_DWORD, true, vR, kVLane4, kSAddr);
-            e_.sopp(SOPP_BRANCH, "s_branch", 1, true);
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
-            pending_.push_back(vR);
-        } else {
-            int vA = 2;
-            if (r.w[6] & 1u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));
-            else if (!row(r.w[2], &vA)) return false;
-            if (p != 0) e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
-            e_.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSAddr), sreg(kSTramSlots[t]), imm32(t == 0 ? 8192u : 1048576u, true));
-            e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSAddr));
-            e_.sopp(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", 6, true);
-            e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSPos), pos, imm32(8));
-            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSTramBase[t]), sreg(kSPos));
-            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSTramBase[t] + 1), imm32(0));
-            e_.global(GLOBAL_STORE_DWORD, false, vA, kVLane4, kSAddr);
-            e_.sopp(SOPP_BRANCH, "s_branch", 1, true);
-            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
-        }
-        // cursor = (cursor + 1) % size
+        return p < 0 ? 0 : p;
+    }
+    void advanceCursor(int cursor, int t) {  // cursor = (cursor + 1) % size
         e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(cursor), sreg(cursor), imm32(1));
         e_.sopc(SOPC_CMP_GE_I32, "s_cmp_ge_i32", sreg(cursor), sreg(kSTramSize[t]));
         e_.sop2(SOP2_CSELECT_B32, "s_cselect_b32", sreg(cursor), imm32(0), sreg(cursor));
+    }
+    void slotAddress(const Src& pos, int t) {
+        e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSPos), pos, imm32(8));
+        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSTramBase[t]), sreg(kSPos));
+        e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSTramBase[t] + 1), imm32(0));
+    }
+    // deferred: a read in the middle of the program (its row is waited for at its first use); otherwise a leading read,
+    // whose wait is the head of the sample loop
+    bool tramRead(const MicroOp& r, uint32_t slot, bool deferred) {
+        const int t = tramOf(slot);
+        const int cursor = kSCursor + 2 * t + 1;
+        const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
+        if (deferred && !touch(r, false, false, false, true)) return false;
+        plainMode();
+        int vR = 0;
+        if (deferred ? !row(r.w[5], &vR) : false) return false;
+        if (!deferred) vR = vrow(r.w[5]);
+        if (vR >= tmpl_.vgprs) return fail("register-file row beyond the VGPR budget of the build");
+        if (size < 1) {  // the reference would divide by zero: flagged, the read yields 0
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
+            return true;
+        }
+        const int32_t p = tramOffset(r, size);
+        const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
+        if (p != 0) {
+            e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
+            e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", sreg(kSPos), imm32(0));
+            Emitter::Fixup inRange = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+            e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(kSPos), sreg(kSTramSize[t]));  // C's % keeps it negative: flagged
+            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(1));
+            e_.bind(inRange);
+        }
+        e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSTramSlots[t]));
+        Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        slotAddress(pos, t);
+        e_.global(GLOBAL_LOAD_DWORD, true, vR, kVLane4, kSAddr);
+        Emitter::Fixup done = e_.branchForward(SOPP_BRANCH, "s_branch");
+        e_.bind(outside);
+        e_.waitVmcnt(0);
+        e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+        e_.bind(done);
+        if (deferred) pending_.push_back(vR);
+        advanceCursor(cursor, t);
         return true;
+    }
+    bool tramWrite(const MicroOp& r, uint32_t slot) {
+        const int t = tramOf(slot);
+        const int cursor = kSCursor + 2 * t;
+        const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
+        if (!touch(r, !(r.w[6] & 1u), false, false, false)) return false;
+        plainMode();
+        if (size < 1) {
+            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
+            return true;
+        }
+        const int32_t p = tramOffset(r, size);
+        const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
+        int vA = 2;
+        if (r.w[6] & 1u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));
+        else if (!row(r.w[2], &vA)) return false;
+        if (p != 0) e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
+        e_.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSAddr), sreg(kSTramSlots[t]), imm32(t == 0 ? 8192u : 1048576u, true));
+        e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSAddr));
+        Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        slotAddress(pos, t);
+        e_.global(GLOBAL_STORE_DWORD, false, vA, kVLane4, kSAddr);
+        Emitter::Fixup done = e_.branchForward(SOPP_BRANCH, "s_branch");
+        e_.bind(outside);
+        e_.waitVmcnt(0);
+        e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
+        e_.bind(done);
+        advanceCursor(cursor, t);
+        return true;
+    }
+    bool tram(const MicroOp& r, uint32_t slot) {
+        return (slot == AS_TRAM_IR || slot == AS_TRAM_XR) ? tramRead(r, slot, true) : tramWrite(r, slot);
     }
 
     // operand word -> source: a register-file row (VGPR) or the uniform's bit pattern
@@ -1134,6 +1334,8 @@ class Translator {
     const XlateTemplate& tmpl_;
     const XlateProgram prog_;
     uint32_t base_;
+    bool isLast_;
+    uint32_t nextBase_;  // steady streams: where the last-sample stream of the same flavour starts
     Emitter e_;
     XlateStats stats_;
     std::string err_;
@@ -1196,64 +1398,184 @@ const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
 }
 
 bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, const XlateProgram& prog, uint32_t codeBase,
-                     const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code, std::string* listing,
-                     XlateStats* stats, std::vector<uint32_t>* returns, std::string* err) {
+                     bool isLast, uint32_t nextBase, const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code,
+                     std::string* listing, XlateStats* stats, std::vector<uint32_t>* returns, uint32_t* coldEntry, std::string* err) {
     code->clear();
-    Translator t(tmpl, prog, codeBase, code, listing, exactReturns);
-    return t.run(records, stats, returns, err);
+    Translator t(tmpl, prog, codeBase, isLast, nextBase, code, listing, exactReturns);
+    return t.run(records, stats, returns, coldEntry, err);
 }
 
 namespace {
 inline uint32_t align64(uint32_t v) { return (v + 63u) & ~63u; }
 
-// Run-once code: copy [blobOff, blobOff + bytes) of the LUT blob to LDS [ldsOff, ..), 16 bytes per lane and round;
-// bytes is a multiple of 16.  v2 = lane * 16.
-void emitLdsCopy(Emitter& e, uint32_t blobOff, uint32_t ldsOff, uint32_t bytes) {
-    for (uint32_t done = 0; done < bytes; done += 1024) {
-        const uint32_t lanes = std::min<uint32_t>(64, (bytes - done) / 16);
-        e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32(blobOff + done, true));
-        e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
-        if (lanes < 64) {
-            const uint64_t mask = (1ull << lanes) - 1;
-            e.sop1(SOP1_MOV_B32, "s_mov_b32", named(126, "exec_lo"), imm32((uint32_t)mask));
-            e.sop1(SOP1_MOV_B32, "s_mov_b32", named(127, "exec_hi"), imm32((uint32_t)(mask >> 32)));
-        }
-        e.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 4, 2, kSAddr);
-        e.waitVmcnt0();
-        e.dsWriteB128(2, 4, ldsOff + done);
-        if (lanes < 64) e.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
-    }
-}
-
+// Run-once code (one wavefront = one workgroup; entered from the template with the TRAM cursors in v16..v19 and
+// s95 = 0, returns through s[24:25]):
+//  * the LOG/EXP tables the program uses -> LDS, lane g writing segment g of every array (layout: kLds*);
+//  * s95 = 1 when this launch may issue its leading TRAM reads one sample ahead (HoistPlan).
 void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string* listing) {
     Emitter e(code, listing);
-    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 2, imm32(4), 0);  // v2 = lane * 16 (v0 = lane)
-    emitLdsCopy(e, (uint32_t)kLutXthrOff * 8, kLdsXthr, 272);    // fp32 thresholds + domain bounds (adjacent in the blob)
-    // x1[lane] once, then per table the lane's {slope, y1}: LDS entry lane = {slope, y1, x1, -}
-    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(3), 0);  // lane * 8
-    e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutX1Off * 8, true));
-    e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
-    e.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 3, kSAddr);
-    e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(5), 0);  // lane * 32
-    for (size_t k = 0; k < prog.lutTables.size(); ++k) {
-        const uint32_t table = kLdsSeg + (uint32_t)k * kLdsSegBytes;
-        e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32(prog.lutTables[k], true));
+    if (!prog.lutTables.empty()) {
+        e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 2, imm32(2), 0);  // v2 = lane * 4 (v0 = lane)
+        e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(3), 0);  // v3 = lane * 8
+        e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 12, imm32(4), 0); // v12 = lane * 16
+        e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
         e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
-        e.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 4, 2, kSAddr);
-        e.waitVmcnt0();
-        e.dsWriteB128(3, 4, table);
-        e.dsWriteB64(3, 8, table + 16);
+        e.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 4, 2, kSAddr);        // xthr[lane], xthr[lane + 1]
+        e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutX1Off * 8, true));
+        e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
+        e.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 6, 3, kSAddr);        // x1[lane]
+        e.waitVmcnt(0);
+        e.dsWriteB64(3, 4, kLdsThr);
+        e.dsWriteB64(3, 6, kLdsX1);
+        for (size_t k = 0; k < prog.lutTables.size(); ++k) {
+            const uint32_t table = kLdsTables + (uint32_t)k * kLdsTableBytes;
+            e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32(prog.lutTables[k], true));
+            e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
+            e.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 4, 12, kSAddr);   // {slope, y1} of segment lane
+            e.waitVmcnt(0);
+            e.dsWriteB64(3, 4, table);
+            e.dsWriteB64(3, 6, table + 512);
+        }
+        e.waitLgkm0();
     }
-    e.waitLgkm0();
+    const HoistPlan& H = prog.hoist;
+    if (H.leadCount > 0) {
+        e.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSHoistOk), imm32(1));
+        for (int t = 0; t < 2; ++t) {
+            if (H.forbidden[t].empty()) continue;
+            // distance = (read cursor - write cursor) mod size; any listed value: keep the reads in place
+            e.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSPos), vreg(kVCursor + 2 * t + 1));
+            e.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSAddr), vreg(kVCursor + 2 * t));
+            e.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSPos), sreg(kSPos), sreg(kSAddr));
+            e.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", sreg(kSPos), imm32(0));
+            Emitter::Fixup pos = e.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+            e.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(kSPos), sreg(kSTramSize[t]));
+            e.bind(pos);
+            for (uint32_t d : H.forbidden[t]) {
+                e.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSPos), imm32(d));
+                e.sop2(SOP2_CSELECT_B32, "s_cselect_b32", sreg(kSHoistOk), imm32(0), sreg(kSHoistOk));
+            }
+        }
+    }
     e.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSReturn));
+    e.finish();
 }
 }
 
+namespace {
+int32_t truncX86(uint32_t bits) {  // cvttss2si: 0x80000000 for NaN and anything outside int32
+    float f;
+    std::memcpy(&f, &bits, 4);
+    if (!(f > -2147483904.0f && f < 2147483648.0f)) return INT32_MIN;
+    return (int32_t)f;
+}
+
+// Which TRAM reads can be issued one sample ahead, where, and for which cursor distances that is unsafe (fx_xlate.hpp HoistPlan)
+HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, const XlateProgram& p) {
+    HoistPlan H;
+    if (!p.uniformCursors) return H;
+    auto isRead = [](uint32_t slot) { return slot == AS_TRAM_IR || slot == AS_TRAM_XR; };
+    auto isWrite = [](uint32_t slot) { return slot == AS_TRAM_IW || slot == AS_TRAM_XW; };
+    auto tramOf = [](uint32_t slot) { return (slot == AS_TRAM_IR || slot == AS_TRAM_IW) ? 0 : 1; };
+    auto sizeOf = [&](int t) { return t == 0 ? p.iSize : p.xSize; };
+    auto offsetOf = [&](const MicroOp& r) {
+        const int32_t size = sizeOf(tramOf(r.w[0]));
+        int32_t q = truncX86(r.w[4]);
+        q = q > size - 1 ? size - 1 : q;
+        return q < 0 ? 0 : q;
+    };
+    // leading reads: the maximal prefix of offset-0 reads into distinct rows, the same in both streams
+    int lead = 0;
+    std::vector<uint32_t> rows;
+    while ((size_t)lead < steady.size() && (size_t)lead < last.size() && lead < 32) {
+        const MicroOp& r = steady[(size_t)lead];
+        if (!isRead(r.w[0]) || last[(size_t)lead].w[0] != r.w[0] || last[(size_t)lead].w[5] != r.w[5] || last[(size_t)lead].w[4] != r.w[4]) break;
+        if (sizeOf(tramOf(r.w[0])) < 1 || offsetOf(r) != 0 || std::find(rows.begin(), rows.end(), r.w[5]) != rows.end()) break;
+        rows.push_back(r.w[5]);
+        ++lead;
+    }
+    if (lead == 0) return H;
+    // per TRAM: reads and writes per sample, leading reads
+    int nRead[2] = {0, 0}, nWrite[2] = {0, 0}, nLead[2] = {0, 0};
+    for (size_t i = 0; i < steady.size(); ++i) {
+        const uint32_t slot = steady[i].w[0];
+        if (isRead(slot)) ++nRead[tramOf(slot)];
+        if (isWrite(slot)) ++nWrite[tramOf(slot)];
+        if ((int)i < lead) ++nLead[tramOf(slot)];
+    }
+    // the hoist point: behind the last record that touches a destination row of a leading read, behind every other read
+    // of a TRAM that has leading reads (the cursor order of its reads must not change), and outside every SKIP shadow
+    auto touches = [&](const MicroOp& r) {
+        const uint32_t slot = r.w[0];
+        if (slot == AS_NOP || slot == AS_PRED || slot == AS_UNPRED || slot == AS_ENDSAMPLE) return false;
+        uint32_t kind;
+        if (slot >= AS_MACS) kind = ((slot - AS_MACS) % 16) / 2;
+        else kind = r.w[6] & 7u;
+        for (uint32_t row : rows) {
+            if (!(kind & 1u) && r.w[2] == row) return true;
+            if (!(kind & 2u) && r.w[3] == row && slot != AS_LUT) return true;
+            if (!(kind & 4u) && r.w[4] == row) return true;
+            if (r.w[5] == row) return true;
+        }
+        return false;
+    };
+    int at = lead - 1;
+    for (size_t i = (size_t)lead; i < steady.size(); ++i) {
+        const uint32_t slot = steady[i].w[0];
+        if (slot == AS_ENDSAMPLE) break;
+        if (touches(steady[i]) || (isRead(slot) && nLead[tramOf(slot)] > 0)) at = (int)i;
+    }
+    {
+        bool shadow = false;
+        for (size_t i = 0; i < steady.size() && steady[i].w[0] != AS_ENDSAMPLE; ++i) {
+            const uint32_t slot = steady[i].w[0];
+            if (slot == AS_PRED) shadow = true;
+            else if (slot == AS_UNPRED) shadow = false;
+            // a SKIP (or the instruction it is fused with) restricts EXEC before the first PRED of its shadow: never stop
+            // between an instruction and the SKIP / PRED that follows it
+            const uint32_t next = i + 1 < steady.size() ? steady[i + 1].w[0] : (uint32_t)AS_ENDSAMPLE;
+            if ((int)i >= at && !shadow && slot != AS_SKIP && next != AS_SKIP && next != AS_PRED && next != AS_NOP) { at = (int)i; break; }
+            if (next == AS_ENDSAMPLE) { at = (int)i; if (shadow) return H; break; }
+        }
+    }
+    // writes the early reads overtake: those behind the hoist point
+    for (int t = 0; t < 2; ++t) {
+        if (nLead[t] == 0) continue;
+        std::vector<int> later;  // index among the TRAM's writes of a sample
+        int w = 0;
+        bool plainOffsets = true;
+        for (size_t i = 0; i < steady.size(); ++i) {
+            if (!isWrite(steady[i].w[0]) || tramOf(steady[i].w[0]) != t) continue;
+            if ((int)i > at) { later.push_back(w); plainOffsets = plainOffsets && offsetOf(steady[i]) == 0; }
+            ++w;
+        }
+        if (later.empty()) continue;
+        if (nRead[t] != nWrite[t] || !plainOffsets) return H;  // the cursor distance drifts, or slots are offset: reads stay in place
+        const int64_t size = sizeOf(t);
+        for (int ir = 0; ir < nLead[t]; ++ir)
+            for (int jw : later) {
+                const uint32_t d = (uint32_t)((((int64_t)jw - nRead[t] - ir) % size + size) % size);
+                if (std::find(H.forbidden[t].begin(), H.forbidden[t].end(), d) == H.forbidden[t].end()) H.forbidden[t].push_back(d);
+            }
+        if (H.forbidden[t].size() > 64) { H.forbidden[0].clear(); H.forbidden[1].clear(); return H; }
+    }
+    H.leadCount = lead;
+    H.hoistAfter = at;
+    for (size_t i = (size_t)at + 1; i < steady.size(); ++i) {
+        const uint32_t slot = steady[i].w[0];
+        if ((isRead(slot) || isWrite(slot)) && sizeOf(tramOf(slot)) >= 1) ++H.vmemAfterHoist;
+    }
+    return H;
+}
+}  // namespace
+
 XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
-                            int nRows, const std::vector<int>& inputRows) {
+                            int nRows, const std::vector<int>& inputRows, const std::vector<int>& latchRows) {
     XlateProgram p;
     p.iSize = iSize;
     p.xSize = xSize;
+    p.inRows = inputRows;
+    p.latchRows = latchRows;
     // uniform cursors: no TRAM instruction inside a SKIP shadow (every lane executes every one of them, so all
     // lanes' cursors move together) and every TRAM offset operand uniform
     bool any = false, ok = true;
@@ -1270,8 +1592,13 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
         }
     }
     p.uniformCursors = any && ok;
+    if (p.uniformCursors) {
+        for (const MicroOp& r : steadyRecords)
+            if (r.w[0] >= AS_TRAM_IR && r.w[0] <= AS_TRAM_XW && ((r.w[0] == AS_TRAM_IR || r.w[0] == AS_TRAM_IW) ? iSize : xSize) >= 1) ++p.tramOpsInline;
+        p.hoist = planHoist(steadyRecords, lastRecords, p);
+    }
 
-    // LOG/EXP tables the inline code uses (per-lane operand): up to 4 of them go to LDS (2 KB each per wavefront)
+    // LOG/EXP tables the inline code uses (per-lane operand): up to 4 of them go to LDS (1 KB each per wavefront, + 1 KB shared)
     for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords})
         for (const MicroOp& r : *recs)
             if (r.w[0] == AS_LUT && !(r.w[6] & 1u) && std::find(p.lutTables.begin(), p.lutTables.end(), r.w[3]) == p.lutTables.end())
@@ -1326,42 +1653,60 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
 
 bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
                const XlateProgram& program, XlateImage* out, std::vector<uint32_t> code[5], std::string listing[5], std::string* err) {
-    // hole: [steady fast][steady exact][last fast][last exact], each on a cache line.  The exact stream of a pair
-    // is translated first (its call return addresses are the fast stream's escape targets); its position depends
-    // on the fast stream's size, which does not depend on the targets - so: size the fast stream with dummy targets.
+    // hole: [steady fast][last fast][steady exact][last exact][run-once], each on a cache line.  The steady streams
+    // branch to their last-sample streams, the fast streams to the exact ones; sizes do not depend on the targets, so:
+    // size everything with dummy targets, lay out, translate the exact streams (their sync points are the fast
+    // streams' escape targets), then the fast ones.
     const std::vector<MicroOp>* recs[2] = {&steadyRecords, &lastRecords};
-    uint32_t at = tmpl.holeOff;
+    XlateProgram prog[2] = {program, program};
+    prog[1].compactCcr = true;  // last-sample streams materialise every CCR write and run once: handler calls (compact code)
+    uint32_t bytes[4] = {0, 0, 0, 0};  // steady fast, steady exact, last fast, last exact
+    bool fastOk = true;
     for (int k = 0; k < 2; ++k) {
-        XlateProgram prog = program;
-        prog.compactCcr = k == 1;
-        std::vector<uint32_t> exactRet, scratch, dummy(4 * recs[k]->size() + 4, at);
-        XlateStats fastStats, exactStats;
-        // pass 1: size of the fast stream (targets = its own base: in range, value irrelevant)
-        if (!translateStream(*recs[k], tmpl, prog, at, &dummy, &scratch, nullptr, &fastStats, nullptr, err)) return false;
-        const uint32_t fastBytes = align64((uint32_t)scratch.size() * 4);
-        const bool fastOk = !fastStats.nonFiniteImmediate;
-        const uint32_t exactAt = fastOk ? at + fastBytes : at;
-        if (!translateStream(*recs[k], tmpl, prog, exactAt, nullptr, &code[2 * k + 1], listing ? &listing[2 * k + 1] : nullptr, &exactStats, &exactRet, err))
-            return false;
-        if (fastOk) {
-            if (!translateStream(*recs[k], tmpl, prog, at, &exactRet, &code[2 * k], listing ? &listing[2 * k] : nullptr, &fastStats, nullptr, err)) return false;
-            if (align64((uint32_t)code[2 * k].size() * 4) != fastBytes) { if (err) *err = "internal: fast stream changed size"; return false; }
-        } else {
-            code[2 * k].clear();  // a non-finite uniform operand: every wave runs the exact stream
-        }
-        (k == 0 ? out->steadyFastOff : out->lastFastOff) = fastOk ? at : exactAt;
-        (k == 0 ? out->steadyOff : out->lastOff) = exactAt;
-        (k == 0 ? out->steady : out->last) = fastOk ? fastStats : exactStats;
-        at = exactAt + align64((uint32_t)code[2 * k + 1].size() * 4);
+        std::vector<uint32_t> scratch, dummy(4 * recs[k]->size() + 4, tmpl.holeOff);
+        XlateStats st;
+        if (!translateStream(*recs[k], tmpl, prog[k], tmpl.holeOff, k == 1, tmpl.holeOff, &dummy, &scratch, nullptr, &st, nullptr, nullptr, err)) return false;
+        bytes[2 * k] = align64((uint32_t)scratch.size() * 4);
+        fastOk = fastOk && !st.nonFiniteImmediate;
+        if (!translateStream(*recs[k], tmpl, prog[k], tmpl.holeOff, k == 1, tmpl.holeOff, nullptr, &scratch, nullptr, &st, nullptr, nullptr, err)) return false;
+        bytes[2 * k + 1] = align64((uint32_t)scratch.size() * 4);
     }
+    uint32_t at = tmpl.holeOff;
+    if (fastOk) { out->base[0] = at; at += bytes[0]; out->base[2] = at; at += bytes[2]; }
+    out->base[1] = at; at += bytes[1];
+    out->base[3] = at; at += bytes[3];
+    if (!fastOk) { out->base[0] = out->base[1]; out->base[2] = out->base[3]; }
+    std::vector<uint32_t> exactRet[2];
+    XlateStats stats[4];
+    uint32_t cold[4] = {0, 0, 0, 0};
+    for (int k = 1; k >= 0; --k)
+        if (!translateStream(*recs[k], tmpl, prog[k], out->base[2 * k + 1], k == 1, out->base[3], nullptr, &code[2 * k + 1],
+                             listing ? &listing[2 * k + 1] : nullptr, &stats[2 * k + 1], &exactRet[k], &cold[2 * k + 1], err))
+            return false;
+    for (int k = 1; k >= 0; --k) {
+        code[2 * k].clear();  // (a non-finite uniform operand: every wave runs the exact streams)
+        if (!fastOk) { cold[2 * k] = cold[2 * k + 1]; stats[2 * k] = stats[2 * k + 1]; continue; }
+        if (!translateStream(*recs[k], tmpl, prog[k], out->base[2 * k], k == 1, out->base[2], &exactRet[k], &code[2 * k],
+                             listing ? &listing[2 * k] : nullptr, &stats[2 * k], nullptr, &cold[2 * k], err))
+            return false;
+        if (align64((uint32_t)code[2 * k].size() * 4) != bytes[2 * k]) { if (err) *err = "internal: fast stream changed size"; return false; }
+    }
+    for (int k = 0; k < 2; ++k)
+        if (align64((uint32_t)code[2 * k + 1].size() * 4) != bytes[2 * k + 1]) { if (err) *err = "internal: exact stream changed size"; return false; }
+    out->steadyFastOff = cold[0];
+    out->steadyOff = cold[1];
+    out->lastFastOff = cold[2];
+    out->lastOff = cold[3];
+    out->steady = stats[0];
+    out->last = stats[2];
     out->wildRow = program.wildRow;
     out->initOff = 0;
     out->ldsBytes = 0;
     code[4].clear();
-    if (!program.lutTables.empty()) {
+    if (!program.lutTables.empty() || program.hoist.leadCount > 0) {
         emitInit(program, &code[4], listing ? &listing[4] : nullptr);
         out->initOff = at;
-        out->ldsBytes = kLdsSeg + (uint32_t)program.lutTables.size() * kLdsSegBytes;
+        out->ldsBytes = program.lutTables.empty() ? 0 : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
         at += align64((uint32_t)code[4].size() * 4);
     }
     out->codeBytes = at - tmpl.holeOff;
@@ -1377,7 +1722,7 @@ bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vecto
     std::vector<uint32_t> code[5];
     if (!planXlate(steadyRecords, lastRecords, tmpl, prog, out, code, nullptr, err)) return false;
     out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
-    const uint32_t offs[5] = {out->steadyFastOff, out->steadyOff, out->lastFastOff, out->lastOff, out->initOff};
+    const uint32_t offs[5] = {out->base[0], out->base[1], out->base[2], out->base[3], out->initOff};
     for (int k = 0; k < 5; ++k)
         if (!code[k].empty()) std::memcpy(out->elf.data() + tmpl.holeFileOff + (offs[k] - tmpl.holeOff), code[k].data(), code[k].size() * 4);
     return true;

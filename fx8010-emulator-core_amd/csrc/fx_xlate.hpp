@@ -38,6 +38,21 @@ struct XlateTemplate {
 // The template of a VGPR build (ASM_V64 .. ASM_V256); nullptr + err when there is none or the image is malformed.
 const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err);
 
+// Software pipelining of delay-line reads.  The TRAM reads a program starts with ("leading reads": records
+// [0, leadCount) of both streams, offset 0, uniform cursors) are issued one sample period AHEAD - in the steady
+// stream, right after the last instruction that touches their destination rows - so that their HBM latency
+// hides behind the rest of the current sample instead of stalling the next one.  A read issued early overtakes
+// the writes that follow it in the current sample; it would see stale data if one of them hit the same slot.
+// With as many reads as writes per sample the distance (read cursor - write cursor) mod size is the same at
+// every sample start, so that is decided once per launch: run-once code compares it with `forbidden` and keeps
+// the reads in place (s95 = 0) when a pair would collide.
+struct HoistPlan {
+    int leadCount = 0;    // 0 = no read is issued ahead
+    int hoistAfter = -1;  // steady stream: the next sample's leading reads follow this record
+    int vmemAfterHoist = 0;  // inline TRAM instructions of the steady stream behind the hoist point
+    std::vector<uint32_t> forbidden[2];  // [iTRAM, xTRAM]: cursor distances for which a hoisted read and a later write share a slot
+};
+
 // What the translator needs to know about the program beyond its records.
 struct XlateProgram {
     int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
@@ -47,10 +62,15 @@ struct XlateProgram {
     std::vector<uint32_t> lutTables;
     bool compactCcr = false;      // set by planXlate for the last-sample streams: live-CCR instructions call the handler
     std::vector<uint8_t> wildRow; // per register-file row: 0 = BOUNDED class (always inside [-1, 1]), 1 = WILD
+    // PCM I/O of the generated sample loop: row the input of channel c is copied to (-1: unused), row of its output latch
+    std::vector<int> inRows, latchRows;
+    int tramOpsInline = 0;        // inline TRAM instructions per sample of the steady stream (each issues one VMEM operation)
+    HoistPlan hoist;
 };
-// nRows = rows of the register file, inputRows = the rows the frame writes the PCM input to (-1: unused channel)
+// nRows = rows of the register file, inputRows = the rows the PCM input goes to (-1: unused channel), latchRows = the
+// rows the PCM output comes from; one entry per channel
 XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
-                            int nRows, const std::vector<int>& inputRows);
+                            int nRows, const std::vector<int>& inputRows, const std::vector<int>& latchRows);
 
 struct XlateStats {
     int inlined = 0;     // records translated to straight-line code
@@ -63,8 +83,13 @@ struct XlateStats {
     bool nonFiniteImmediate = false;  // a NaN / Inf among the uniform operands: no fast stream for this program
 };
 
-// Translate one stream of records (encodeAsmStream(ops, nullptr, true): w0 = handler slot) into code that
-// starts `codeBase` bytes after the kernel entry.  The code ends with the jump to the end-of-sample frame.
+// Translate one stream of records (encodeAsmStream(ops, nullptr, true): w0 = handler slot) into the code of a
+// whole sample LOOP that starts `codeBase` bytes after the kernel entry: PCM input of the sample (prefetched one
+// sample ahead), the program, PCM output, pointer advance and the branch back.  A steady stream loops while the
+// next sample is not the block's last and then continues at `nextBase` (the hot entry of the matching last-sample
+// stream); a last-sample stream (isLast) runs once and leaves through s[34:35] (the template's epilogue).  Entry
+// points: offset 0 ("hot": from the previous sample) and *coldEntry ("cold": from the template; sets up the
+// scalar TRAM cursors first).
 //
 // Two flavours.  exactReturns == nullptr: the EXACT stream, whose saturation lets a NaN pass as the reference's
 // does (FX8010.cpp:275-279: 3 VALU instructions).  exactReturns != nullptr: the FAST stream, whose saturation is
@@ -76,14 +101,15 @@ struct XlateStats {
 // The same hand-over follows the wait for in-flight TRAM reads of programs with uniform cursors (inline TRAM code).
 // listing (optional) receives one assembler line per instruction, in llvm-mc syntax.
 bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, const XlateProgram& prog, uint32_t codeBase,
-                     const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code, std::string* listing,
-                     XlateStats* stats, std::vector<uint32_t>* returns, std::string* err);
+                     bool isLast, uint32_t nextBase, const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code,
+                     std::string* listing, XlateStats* stats, std::vector<uint32_t>* returns, uint32_t* coldEntry, std::string* err);
 
 // A loadable code object: the template with the four streams in its hole.
 struct XlateImage {
     std::vector<unsigned char> elf;
-    // entry offsets from the kernel entry; AsmArgs.steady = steadyFastOff | steadyOff << 32, .last likewise
+    // COLD entry offsets from the kernel entry; AsmArgs.steady = steadyFastOff | steadyOff << 32, .last likewise
     uint32_t steadyFastOff = 0, steadyOff = 0, lastFastOff = 0, lastOff = 0;
+    uint32_t base[4] = {0, 0, 0, 0};  // where the streams start: steady fast, steady exact, last fast, last exact
     uint32_t initOff = 0;   // run-once code (AsmArgs.initOff), 0 = none
     uint32_t ldsBytes = 0;  // dynamic LDS per workgroup
     uint32_t codeBytes = 0;

@@ -71,33 +71,71 @@ def test_listing_reassembles_to_the_same_bytes(last):
     assert seen > 0
 
 
+def branch_targets(listing):
+    """(line index, target line index) of every SOPP branch of a listing (targets resolved through instruction sizes)"""
+    lines = listing.strip().split("\n")
+    code = assemble(listing)
+    # byte offset of every line: assemble prefixes to find instruction sizes cheaply via a single pass of llvm-mc output is
+    # overkill - every instruction here is 4 or 8 bytes, and a literal or a VOP3/DS/global encoding makes it 8
+    sizes = []
+    for l in lines:
+        op = l.split()[0]
+        eight = (op.endswith("_e64") or op in ("v_med3_f32", "v_med3_i32", "v_fma_f64", "v_add_f64", "v_mul_f64") or op.startswith(("global_", "ds_"))
+                 or re.search(r"0x[0-9a-f]+", l) is not None)
+        sizes.append(8 if eight else 4)
+    assert sum(sizes) == len(code), "instruction size model"
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    out = []
+    for k, l in enumerate(lines):
+        m = re.match(r"^(s_branch|s_cbranch_\w+) (\d+)$", l)
+        if not m:
+            continue
+        simm = int(m.group(2))
+        simm = simm - 65536 if simm >= 32768 else simm
+        target = int(offs[k + 1]) + 4 * simm
+        out.append((k, target, int(offs[-1])))
+    return lines, offs, out
+
+
+@needs_llvm
 def test_structure_of_translated_code():
+    """A stream is a whole sample loop: head, program, PCM out, loop branch (steady) or the jump to the epilogue (last),
+    then the cold-entry stub that branches back to the head."""
     for name, text in program_texts():
         fe = A.FrontEnd(1)
         assert fe.load_text(text), name
-        for vgprs, stream in ((0, 0), (0, 1), (256, 0), (0, 3)):
+        for vgprs, stream in ((0, 0), (0, 1), (256, 0), (0, 2), (0, 3)):
             code, listing = fe.translate(vgprs, stream)
-            lines = listing.strip().split("\n")
-            assert lines[-1] == "s_setpc_b64 s[34:35]", name  # back to the end-of-sample frame, nothing after it
+            if not code:
+                continue  # no fast stream (non-finite uniform)
+            lines, offs, branches = branch_targets(listing)
+            last = stream >= 2
+            assert lines[-1].startswith("s_branch "), name  # the cold stub ends with the branch to the head
+            assert branches[-1][1] == 0, (name, "cold stub must enter at the head")
+            # the jump to the template's epilogue appears exactly once, in last-sample streams only
+            assert listing.count("s_setpc_b64 s[34:35]") == (1 if last else 0), name
             # every VGPR named is inside the build's budget (the smallest build is at least 64)
             budget = vgprs if vgprs else 256
             for m in re.finditer(r"\bv(\d+)\b", listing):
                 assert int(m.group(1)) < budget
             for m in re.finditer(r"v\[(\d+):(\d+)\]", listing):
                 assert int(m.group(2)) < 14  # temporaries only (v[2:5] .. v[12:13])
-            # SGPR writes stay inside the record window, the return address, the scratch pair, the TRAM cursor and LUT base blocks
-            allowed = set(range(18, 26)) | {62, 63} | set(range(80, 94))  # + s[88:93]: LUT table bases
-            for m in re.finditer(r"^(s_[a-z0-9_]+) s(\d+),", listing, re.M):
-                if not m.group(1).startswith(("s_cmp", "s_setpc")):
-                    assert int(m.group(2)) in allowed, (name, m.group(0))
-            # branches inside a stream are the fixed skips of the inline TRAM code
-            for m in re.finditer(r"^(s_branch|s_cbranch_scc0) (\d+)$", listing, re.M):
-                assert int(m.group(2)) in (1, 2, 6), (name, m.group(0))
+            # SGPR writes: sample index, PCM pointers, the record window, return address, scratch, TRAM cursors / LUT bases,
+            # the two flags of the early TRAM reads
+            allowed = {3, 12, 13, 14, 15} | set(range(18, 26)) | set(range(62, 68)) | set(range(80, 96))
+            for m in re.finditer(r"^(s_[a-z0-9_]+) s\[?(\d+)", listing, re.M):
+                if not m.group(1).startswith(("s_cmp", "s_setpc", "s_waitcnt", "s_cbranch", "s_branch", "s_nop", "s_set_gpr")):
+                    assert int(m.group(2)) in allowed | {78}, (name, m.group(0))
+            # branches stay inside the stream, except the fast streams' escapes (forward, into an exact stream) and a
+            # steady stream's hand-over to its last-sample stream
+            outside = [(k, t) for k, t, end in branches if not (0 <= t <= end)]
+            for k, t in outside:
+                assert lines[k].startswith("s_cbranch_scc1") or (not last and lines[k].startswith("s_branch")), (name, lines[k])
             if stream in (1, 3):
-                assert "s_cbranch_scc1" not in listing  # only the fast streams leave (for the exact ones)
-            # a call's return address is the instruction after its s_setpc_b64
-            words = np.frombuffer(code, dtype=np.uint32)
-            assert words[-1] == 0xBE801D22  # s_setpc_b64 s[34:35]
+                assert all(lines[k].startswith("s_branch") for k, t in outside), name  # exact streams never leave for another flavour
+            if not last:
+                back = [k for k, t, end in branches if t == 0 and lines[k].startswith("s_cbranch_scc1")]
+                assert len(back) == 1, (name, "one loop branch to the head")
 
 
 def test_translate_reports_ineligible_programs():

@@ -195,11 +195,7 @@ idxmode_probe:
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 8
-        .value_kind: global_buffer
-        .address_space: global
-      - .offset: 8
-        .size: 4
+        .size: 16
         .value_kind: by_value
     .group_segment_fixed_size: 0
     .kernarg_segment_align: 8
