@@ -73,6 +73,12 @@ Batch::~Batch() {
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+// The caller's stream may be gone by the time we need the previous launch to have finished (a torch stream that was
+// garbage-collected): wait on the event recorded behind that launch instead of holding the foreign handle.
+void Batch::waitLastLaunch() {
+    if (launched_) (void)hipEventSynchronize(ev1_);
+}
+
 int Batch::fail(int code, const std::string& what) {
     lastError_ = what;
     return code;
@@ -92,7 +98,13 @@ int Batch::afterLoad(bool ok) {
     forcedLane_.resize(prog_.regs.size(), 0);
     for (size_t r = old; r < prog_.regs.size(); ++r) hostValue_[r] = prog_.regs[r].value;
     lowDirty_ = true;
-    if (!ok) return 0;
+    // a load that failed after an earlier good one has still appended registers (literals and declarations are created
+    // before the error, as in the reference): the state block must follow, or set_register of a new one would land in
+    // the rows behind the registers (output latches, cursors, LFSR, counter)
+    if (!ok) {
+        if (dState_) (void)ensureState();
+        return 0;
+    }
     loaded_ = true;
     if (ensureState() != 0) return 0;
     return 1;
@@ -128,7 +140,7 @@ int Batch::ensureState() {
     dState_ = fresh;
     int firstNew = 0;
     if (old) {
-        if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+        waitLastLaunch();
         auto copyRow = [&](int dst, int src) {
             return hipMemcpyAsync(fresh + (size_t)dst * nPad_, old + (size_t)src * nPad_, rowBytes, hipMemcpyDeviceToDevice, stream_);
         };
@@ -162,7 +174,7 @@ int Batch::ensureTram() {
         if (e != hipSuccess) return hipFail(e, "hipMalloc TRAM");
         e = hipMemsetAsync(fresh, 0, bytes, stream_);  // the parity domain assumes zeroed delay memory
         if (e == hipSuccess && buf && have > 0) {
-            if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+            waitLastLaunch();
             e = hipMemcpy2DAsync(fresh, (size_t)want * pitch, buf, (size_t)have * pitch, (size_t)have * pitch, waves, hipMemcpyDeviceToDevice, stream_);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(stream_);
@@ -283,7 +295,7 @@ int Batch::ensureLowered() {
         tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
         built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &xlateWhyNot_);
         if (built) {
-            if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still run the old code
+            waitLastLaunch();  // the previous launch may still run the old code
             if (xlateModule_) (void)hipModuleUnload(xlateModule_);
             xlateModule_ = nullptr;
             xlateFn_ = nullptr;
@@ -313,7 +325,7 @@ int Batch::ensureLowered() {
     const size_t nOps = low_.steady.size();
     const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size();
     if (words > streamCap_) {
-        if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+        waitLastLaunch();
         (void)hipFree(dStream_);
         dStream_ = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&dStream_), words * 4 + 256);
@@ -331,7 +343,7 @@ int Batch::ensureLowered() {
     }
     for (const RowCopy& rcp : low_.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
     for (int zr : low_.zeroRows) host[p++] = (uint32_t)zr;
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);  // the previous launch may still read the old stream
+    waitLastLaunch();  // the previous launch may still read the old stream
     hipError_t e = hipMemcpy(dStream_, host.data(), words * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipFail(e, "stream upload");
     lowDirty_ = false;
@@ -350,7 +362,7 @@ int Batch::setRegister(const std::string& key, float v) {
         // Invariant: the state row of EVERY register holds its current value for every instance, also while the
         // register is uniform (folded into the code) - so that a later per-instance write only has to force the
         // register per-lane, whatever the lowering in force says about it.
-        if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+        waitLastLaunch();
         int rc = fillRows({(uint32_t)r}, {bitsOf(v)});
         if (rc != 0) return rc;
     }
@@ -363,7 +375,7 @@ int Batch::setRegisterAt(const std::string& key, int64_t inst, float v) {
     if (r < 0) return 1;
     if (inst < 0 || inst >= n_) return fail(FX_E_ARG, "instance out of range");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     if (!forcedLane_[r] && !intrinsicLane(r)) {  // (the row is valid, see setRegister; the next lowering keeps the register per-lane)
         forcedLane_[r] = 1;
         lowDirty_ = true;
@@ -379,7 +391,7 @@ int Batch::setRegisterArray(const std::string& key, const float* values) {
     if (r < 0) return 1;
     if (!values) return fail(FX_E_ARG, "null buffer");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     if (!forcedLane_[r] && !intrinsicLane(r)) {  // from now on a per-instance row (every lane is overwritten below)
         forcedLane_[r] = 1;
         lowDirty_ = true;
@@ -398,7 +410,7 @@ int Batch::getRegisterArray(const std::string& key, float* values) {
         for (int64_t i = 0; i < n_; ++i) values[i] = hostValue_[r];
         return 0;
     }
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     hipError_t e = hipMemcpy(values, dState_ + (size_t)r * nPad_, sizeof(float) * (size_t)n_, hipMemcpyDeviceToHost);
     return e == hipSuccess ? 0 : hipFail(e, "getRegisterArray");
 }
@@ -408,7 +420,7 @@ float Batch::getRegisterAt(const std::string& key, int64_t inst) {
     const int r = prog_.findRegister(key);
     if (r < 0) return 1.0f;  // reference getRegisterValue default, source/FX8010.cpp:265
     if (inst < 0 || inst >= n_ || !dState_ || !laneResident(r)) return hostValue_[r];
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     float v = 0.0f;
     if (hipMemcpy(&v, dState_ + (size_t)r * nPad_ + inst, 4, hipMemcpyDeviceToHost) != hipSuccess) return hostValue_[r];
     return v;
@@ -418,7 +430,7 @@ int Batch::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
     (void)hipSetDevice(device_);
     if (inst < 0 || inst >= n_) return fail(FX_E_ARG, "instance out of range");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     hipError_t e = hipMemcpy(dState_ + (size_t)(stateLayout_.noiseBase + 0) * nPad_ + inst, &x1, 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dState_ + (size_t)(stateLayout_.noiseBase + 1) * nPad_ + inst, &x2, 4, hipMemcpyHostToDevice);
     return e == hipSuccess ? 0 : hipFail(e, "seedNoiseAt");
@@ -506,14 +518,18 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     }
     if (e == hipSuccess) e = hipEventRecord(ev1_, s);
     if (e != hipSuccess) return hipFail(e, "launch fx_step_block");
-    lastStream_ = s;
+    launched_ = true;
     timed_ = true;
     lastGrid_ = (unsigned)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
     return 0;
 }
 
-int Batch::processHost(const float* in, float* out, int nSamples) {
+// pitch: instances per PCM row of the HOST buffers (>= n_); a shard of a larger batch reads / writes its columns of the
+// caller's [sample][channel][all instances] arrays in place (fx_shard.cpp)
+int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch) {
     (void)hipSetDevice(device_);
+    if (pitch <= 0) pitch = n_;
+    if (pitch < n_) return fail(FX_E_ARG, "host row pitch below the instance count");
     if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
     if (nSamples == 0) return ensureLowered();
     if (!in || !out) return fail(FX_E_ARG, "null buffer");
@@ -529,11 +545,14 @@ int Batch::processHost(const float* in, float* out, int nSamples) {
         if (e != hipSuccess) return hipFail(e, "hipMalloc io");
         ioCap_ = count;
     }
-    hipError_t e = hipMemcpyAsync(dIn_, in, count * 4, hipMemcpyHostToDevice, stream_);
+    const size_t rows = (size_t)nSamples * prog_.numChannels, width = (size_t)n_ * 4;
+    hipError_t e = pitch == n_ ? hipMemcpyAsync(dIn_, in, count * 4, hipMemcpyHostToDevice, stream_)
+                               : hipMemcpy2DAsync(dIn_, width, in, (size_t)pitch * 4, width, rows, hipMemcpyHostToDevice, stream_);
     if (e != hipSuccess) return hipFail(e, "H2D");
     int rc = processDevice(dIn_, dOut_, nSamples, stream_);
     if (rc != 0) return rc;
-    e = hipMemcpyAsync(out, dOut_, count * 4, hipMemcpyDeviceToHost, stream_);
+    e = pitch == n_ ? hipMemcpyAsync(out, dOut_, count * 4, hipMemcpyDeviceToHost, stream_)
+                    : hipMemcpy2DAsync(out, (size_t)pitch * 4, dOut_, width, width, rows, hipMemcpyDeviceToHost, stream_);
     if (e == hipSuccess) e = hipStreamSynchronize(stream_);
     if (e != hipSuccess) return hipFail(e, "D2H");
     return 0;
@@ -542,14 +561,14 @@ int Batch::processHost(const float* in, float* out, int nSamples) {
 int Batch::sync() {
     (void)hipSetDevice(device_);
     hipError_t e = hipStreamSynchronize(stream_);
-    if (e == hipSuccess && lastStream_ && lastStream_ != stream_) e = hipStreamSynchronize(lastStream_);
+    if (e == hipSuccess && launched_) e = hipEventSynchronize(ev1_);
     return e == hipSuccess ? 0 : hipFail(e, "sync");
 }
 
 int64_t Batch::instructionCounter() {
     (void)hipSetDevice(device_);
     if (!dState_) return 0;
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     unsigned long long zero[2] = {0, 0};
     unsigned long long* dSum = reinterpret_cast<unsigned long long*>(dScratch_);
     uint32_t* dOr = dScratch_ + 2;
@@ -564,7 +583,7 @@ int64_t Batch::instructionCounter() {
 uint32_t Batch::oodFlags() {
     (void)hipSetDevice(device_);
     if (!dState_) return 0;
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     unsigned long long zero[2] = {0, 0};
     unsigned long long* dSum = reinterpret_cast<unsigned long long*>(dScratch_);
     uint32_t* dOr = dScratch_ + 2;
@@ -579,7 +598,7 @@ uint32_t Batch::oodFlags() {
 int64_t Batch::instructionCounterAt(int64_t inst) {
     (void)hipSetDevice(device_);
     if (!dState_ || inst < 0 || inst >= n_) return 0;
-    if (lastStream_) (void)hipStreamSynchronize(lastStream_);
+    waitLastLaunch();
     uint32_t lo = 0, hi = 0;
     (void)hipMemcpy(&lo, dState_ + (size_t)stateLayout_.countLo * nPad_ + inst, 4, hipMemcpyDeviceToHost);
     (void)hipMemcpy(&hi, dState_ + (size_t)stateLayout_.countHi * nPad_ + inst, 4, hipMemcpyDeviceToHost);

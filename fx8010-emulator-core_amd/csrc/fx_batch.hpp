@@ -34,7 +34,7 @@ public:
     int getRegisterArray(const std::string& key, float* values);
     int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
 
-    int processHost(const float* in, float* out, int nSamples);           // synchronous
+    int processHost(const float* in, float* out, int nSamples, int64_t pitch = 0);  // synchronous; pitch: instances per host PCM row (0 = n)
     int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
     int sync();
 
@@ -45,9 +45,14 @@ public:
     int64_t info(int what);
 
     const Program& program() const { return prog_; }
+    int64_t instances() const { return n_; }
+    int device() const { return device_; }
     const std::string& lastError() const { return lastError_; }
-    int channels() const { return prog_.numChannels; }
-    void setChannels(int c) { prog_.numChannels = c; }
+    int channels() const { return prog_.numChannels; }        // fixed at construction: PCM layout of process()
+    int loaderChannels() const { return prog_.loaderChannels; }  // reference getChannels()
+    // reference setChannels(): only the loader's I/O-index bound changes (include/FX8010.h:73, source/FX8010.cpp:447)
+    void setChannels(int c) { prog_.loaderChannels = c; }
+    void noteError(const std::string& what) { lastError_ = what; }
 
 private:
     int fail(int code, const std::string& what);
@@ -61,6 +66,7 @@ private:
     bool intrinsicLane(int reg) const;
     int chooseInstPerLane() const;
     hipStream_t pick(hipStream_t s) const { return s ? s : stream_; }
+    void waitLastLaunch();        // host waits for the most recent kernel (an event of ours, not the caller's stream handle)
 
     Program prog_;
     std::vector<float> hostValue_;      // current value of every register as the host knows it
@@ -74,7 +80,7 @@ private:
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
-    hipStream_t lastStream_ = nullptr;
+    bool launched_ = false;  // ev1_ marks the end of the most recent launch (on whatever stream it ran)
     bool timed_ = false;
 
     uint32_t* dState_ = nullptr;

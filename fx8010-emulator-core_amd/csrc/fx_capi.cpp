@@ -10,11 +10,13 @@
 #include <vector>
 
 #include "fx_batch.hpp"
+#include "fx_shard.hpp"
 #include "fx_xlate.hpp"
 
+// a batch is one shard (fxb_create) or several (fxb_create_sharded / fxb_create_on_devices)
 struct fxb_handle {
-    fx::Batch batch;
-    fxb_handle(int64_t n, int ch, int dev) : batch(n, ch, dev) {}
+    fx::Sharded batch;
+    fxb_handle(int64_t n, int ch, const std::vector<int>& devices) : batch(n, ch, devices) {}
 };
 struct fx_handle {
     fx::Batch batch;
@@ -27,6 +29,7 @@ struct fxp_handle {
     bool lowered = false;
     std::string err;
     explicit fxp_handle(int ch) : prog(ch) {}
+    void noteError(const std::string& what) { err = what; }
 };
 
 namespace {
@@ -68,6 +71,34 @@ int metaGet(fx::Batch& b, const char* key, char* buf, int buflen) {
         }
     return 0;
 }
+
+
+// No exception may cross the C boundary (the caller may be C, ctypes or a DAW host): every entry point runs its body
+// through one of these; the message lands where fx*_last_error() finds it.
+int codeOf(const std::exception& e) { return dynamic_cast<const std::bad_alloc*>(&e) ? FX_E_MEMORY : FX_E_PROGRAM; }
+template <class H, class F>
+auto guard(H* h, decltype(std::declval<F>()()) onError, F f) -> decltype(f()) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        if (h) h->noteError(e.what());
+    } catch (...) {
+        if (h) h->noteError("unknown error");
+    }
+    return onError;
+}
+template <class H, class F>
+int guardCode(H* h, F f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        if (h) h->noteError(e.what());
+        return codeOf(e);
+    } catch (...) {
+        if (h) h->noteError("unknown error");
+        return FX_E_PROGRAM;
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -83,59 +114,81 @@ int fxb_device_count(void) {
 /* ---- single instance ---- */
 fx_handle* fx_create(int num_channels) { return create<fx_handle>(num_channels); }
 void fx_destroy(fx_handle* h) { delete h; }
-int fx_load_file(fx_handle* h, const char* path) { return (h && path && h->batch.loadFile(path)) ? 1 : 0; }
-int fx_process(fx_handle* h, const float* in, float* out) { return h ? h->batch.processHost(in, out, 1) : FX_E_ARG; }
-int fx_process_block(fx_handle* h, const float* in, float* out, int n) { return h ? h->batch.processHost(in, out, n) : FX_E_ARG; }
-int fx_set_register(fx_handle* h, const char* key, float v) { return (h && key) ? h->batch.setRegister(key, v) : 1; }
-float fx_get_register(fx_handle* h, const char* key) { return (h && key) ? h->batch.getRegisterAt(key, 0) : 1.0f; }
-int64_t fx_instruction_counter(fx_handle* h) { return h ? h->batch.instructionCounterAt(0) : 0; }
+int fx_load_file(fx_handle* h, const char* path) { return (h && path) ? guard(&h->batch, 0, [&] { return h->batch.loadFile(path) ? 1 : 0; }) : 0; }
+int fx_process(fx_handle* h, const float* in, float* out) { return h ? guardCode(&h->batch, [&] { return h->batch.processHost(in, out, 1); }) : FX_E_ARG; }
+int fx_process_block(fx_handle* h, const float* in, float* out, int n) { return h ? guardCode(&h->batch, [&] { return h->batch.processHost(in, out, n); }) : FX_E_ARG; }
+int fx_set_register(fx_handle* h, const char* key, float v) { return (h && key) ? guardCode(&h->batch, [&] { return h->batch.setRegister(key, v); }) : 1; }
+float fx_get_register(fx_handle* h, const char* key) { return (h && key) ? guard(&h->batch, 1.0f, [&] { return h->batch.getRegisterAt(key, 0); }) : 1.0f; }
+int64_t fx_instruction_counter(fx_handle* h) { return h ? guard(&h->batch, (int64_t)0, [&] { return h->batch.instructionCounterAt(0); }) : 0; }
 int fx_error_count(fx_handle* h) { return h ? errorCount(h->batch) : 0; }
 const char* fx_error_desc(fx_handle* h, int i) { return h ? errorDesc(h->batch, i) : ""; }
 int fx_error_row(fx_handle* h, int i) { return h ? errorRow(h->batch, i) : -1; }
 int fx_control_count(fx_handle* h) { return h ? controlCount(h->batch) : 0; }
 const char* fx_control_at(fx_handle* h, int i) { return h ? controlAt(h->batch, i) : ""; }
-int fx_meta_get(fx_handle* h, const char* key, char* buf, int buflen) { return h ? metaGet(h->batch, key, buf, buflen) : 0; }
+int fx_meta_get(fx_handle* h, const char* key, char* buf, int buflen) { return h ? guard(&h->batch, 0, [&] { return metaGet(h->batch, key, buf, buflen); }) : 0; }
 void fx_set_channels(fx_handle* h, int c) { if (h) h->batch.setChannels(c); }
-int fx_get_channels(fx_handle* h) { return h ? h->batch.channels() : 0; }
+int fx_get_channels(fx_handle* h) { return h ? h->batch.loaderChannels() : 0; }
 int fx_ready(fx_handle* h) { return (h && h->batch.program().ready) ? 1 : 0; }
 const char* fx_last_error(fx_handle* h) { return h ? h->batch.lastError().c_str() : "null handle"; }
 
 /* ---- batch ---- */
-fxb_handle* fxb_create(int64_t n, int ch, int device) { return create<fxb_handle>(n, ch, device); }
-void fxb_destroy(fxb_handle* h) { delete h; }
-int fxb_load_file(fxb_handle* h, const char* path) { return (h && path && h->batch.loadFile(path)) ? 1 : 0; }
-int fxb_load_text(fxb_handle* h, const char* text) { return (h && text && h->batch.loadText(text)) ? 1 : 0; }
-int fxb_set_register(fxb_handle* h, const char* key, float v) { return (h && key) ? h->batch.setRegister(key, v) : 1; }
-int fxb_set_register_i(fxb_handle* h, const char* key, int64_t inst, float v) { return (h && key) ? h->batch.setRegisterAt(key, inst, v) : 1; }
-float fxb_get_register_i(fxb_handle* h, const char* key, int64_t inst) { return (h && key) ? h->batch.getRegisterAt(key, inst) : 1.0f; }
-int fxb_set_register_array(fxb_handle* h, const char* key, const float* values) { return (h && key) ? h->batch.setRegisterArray(key, values) : 1; }
-int fxb_get_register_array(fxb_handle* h, const char* key, float* values) { return (h && key) ? h->batch.getRegisterArray(key, values) : 1; }
-int fxb_seed_noise_i(fxb_handle* h, int64_t inst, int32_t x1, int32_t x2) { return h ? h->batch.seedNoiseAt(inst, x1, x2) : FX_E_ARG; }
-int fxb_process_block(fxb_handle* h, const float* in, float* out, int n) { return h ? h->batch.processHost(in, out, n) : FX_E_ARG; }
-int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n, void* stream) {
-    return h ? h->batch.processDevice(d_in, d_out, n, static_cast<hipStream_t>(stream)) : FX_E_ARG;
+fxb_handle* fxb_create(int64_t n, int ch, int device) { return create<fxb_handle>(n, ch, std::vector<int>{device}); }
+fxb_handle* fxb_create_on_devices(int64_t n, int ch, const int* devices, int n_devices) {
+    if (!devices || n_devices < 1) { g_createError = "no device given"; return nullptr; }
+    return create<fxb_handle>(n, ch, std::vector<int>(devices, devices + n_devices));
 }
-int fxb_sync(fxb_handle* h) { return h ? h->batch.sync() : FX_E_ARG; }
-int64_t fxb_instruction_counter(fxb_handle* h) { return h ? h->batch.instructionCounter() : 0; }
-int64_t fxb_instruction_counter_i(fxb_handle* h, int64_t inst) { return h ? h->batch.instructionCounterAt(inst) : 0; }
-uint32_t fxb_ood_flags(fxb_handle* h) { return h ? h->batch.oodFlags() : 0; }
-int fxb_error_count(fxb_handle* h) { return h ? errorCount(h->batch) : 0; }
-const char* fxb_error_desc(fxb_handle* h, int i) { return h ? errorDesc(h->batch, i) : ""; }
-int fxb_error_row(fxb_handle* h, int i) { return h ? errorRow(h->batch, i) : -1; }
-int fxb_control_count(fxb_handle* h) { return h ? controlCount(h->batch) : 0; }
-const char* fxb_control_at(fxb_handle* h, int i) { return h ? controlAt(h->batch, i) : ""; }
-int fxb_meta_get(fxb_handle* h, const char* key, char* buf, int buflen) { return h ? metaGet(h->batch, key, buf, buflen) : 0; }
-int fxb_ready(fxb_handle* h) { return (h && h->batch.program().ready) ? 1 : 0; }
+fxb_handle* fxb_create_sharded(int64_t n, int ch, uint64_t device_mask) {
+    std::vector<int> devices;
+    for (int d = 0; d < 64; ++d)
+        if (device_mask & (1ull << d)) devices.push_back(d);
+    if (devices.empty()) { g_createError = "empty device mask"; return nullptr; }
+    return create<fxb_handle>(n, ch, devices);
+}
+int fxb_shard_count(fxb_handle* h) { return h ? h->batch.shards() : 0; }
+int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instance, int64_t* n_instances) {
+    if (!h || shard < 0 || shard >= h->batch.shards()) return FX_E_ARG;
+    if (device) *device = h->batch.deviceOf(shard);
+    if (first_instance) *first_instance = h->batch.firstOf(shard);
+    if (n_instances) *n_instances = h->batch.countOf(shard);
+    return 0;
+}
+void fxb_destroy(fxb_handle* h) { delete h; }
+int fxb_load_file(fxb_handle* h, const char* path) { return (h && path) ? guard(&h->batch.front(), 0, [&] { return h->batch.loadFile(path) ? 1 : 0; }) : 0; }
+int fxb_load_text(fxb_handle* h, const char* text) { return (h && text) ? guard(&h->batch.front(), 0, [&] { return h->batch.loadText(text) ? 1 : 0; }) : 0; }
+int fxb_set_register(fxb_handle* h, const char* key, float v) { return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.setRegister(key, v); }) : 1; }
+int fxb_set_register_i(fxb_handle* h, const char* key, int64_t inst, float v) { return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.setRegisterAt(key, inst, v); }) : 1; }
+float fxb_get_register_i(fxb_handle* h, const char* key, int64_t inst) { return (h && key) ? guard(&h->batch.front(), 1.0f, [&] { return h->batch.getRegisterAt(key, inst); }) : 1.0f; }
+int fxb_set_register_array(fxb_handle* h, const char* key, const float* values) { return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.setRegisterArray(key, values); }) : 1; }
+int fxb_get_register_array(fxb_handle* h, const char* key, float* values) { return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.getRegisterArray(key, values); }) : 1; }
+int fxb_seed_noise_i(fxb_handle* h, int64_t inst, int32_t x1, int32_t x2) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.seedNoiseAt(inst, x1, x2); }) : FX_E_ARG; }
+int fxb_process_block(fxb_handle* h, const float* in, float* out, int n) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.processHost(in, out, n); }) : FX_E_ARG; }
+int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n, void* stream) {
+    return h ? guardCode(&h->batch.front(), [&] { return h->batch.processDevice(d_in, d_out, n, static_cast<hipStream_t>(stream)); }) : FX_E_ARG;
+}
+int fxb_process_block_dev_shards(fxb_handle* h, const float* const* d_in, float* const* d_out, int n) {
+    return h ? guardCode(&h->batch.front(), [&] { return h->batch.processDeviceShards(d_in, d_out, n); }) : FX_E_ARG;
+}
+int fxb_sync(fxb_handle* h) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.sync(); }) : FX_E_ARG; }
+int64_t fxb_instruction_counter(fxb_handle* h) { return h ? guard(&h->batch.front(), (int64_t)-1, [&] { return h->batch.instructionCounter(); }) : 0; }
+int64_t fxb_instruction_counter_i(fxb_handle* h, int64_t inst) { return h ? guard(&h->batch.front(), (int64_t)0, [&] { return h->batch.instructionCounterAt(inst); }) : 0; }
+uint32_t fxb_ood_flags(fxb_handle* h) { return h ? guard(&h->batch.front(), ~0u, [&] { return h->batch.oodFlags(); }) : 0; }
+int fxb_error_count(fxb_handle* h) { return h ? errorCount(h->batch.front()) : 0; }
+const char* fxb_error_desc(fxb_handle* h, int i) { return h ? errorDesc(h->batch.front(), i) : ""; }
+int fxb_error_row(fxb_handle* h, int i) { return h ? errorRow(h->batch.front(), i) : -1; }
+int fxb_control_count(fxb_handle* h) { return h ? controlCount(h->batch.front()) : 0; }
+const char* fxb_control_at(fxb_handle* h, int i) { return h ? controlAt(h->batch.front(), i) : ""; }
+int fxb_meta_get(fxb_handle* h, const char* key, char* buf, int buflen) { return h ? guard(&h->batch.front(), 0, [&] { return metaGet(h->batch.front(), key, buf, buflen); }) : 0; }
+int fxb_ready(fxb_handle* h) { return (h && h->batch.front().program().ready) ? 1 : 0; }
 const char* fxb_last_error(fxb_handle* h) { return h ? h->batch.lastError().c_str() : "null handle"; }
-float fxb_last_kernel_ms(fxb_handle* h) { return h ? h->batch.lastKernelMs() : -1.0f; }
-int64_t fxb_info(fxb_handle* h, int what) { return h ? h->batch.info(what) : -1; }
+float fxb_last_kernel_ms(fxb_handle* h) { return h ? guard(&h->batch.front(), -1.0f, [&] { return h->batch.lastKernelMs(); }) : -1.0f; }
+int64_t fxb_info(fxb_handle* h, int what) { return h ? guard(&h->batch.front(), (int64_t)-1, [&] { return h->batch.info(what); }) : -1; }
 
 
 /* ---- front-end only ---- */
 fxp_handle* fxp_create(int ch) { return create<fxp_handle>(ch); }
 void fxp_destroy(fxp_handle* h) { delete h; }
-int fxp_load_file(fxp_handle* h, const char* path) { if (!h || !path) return 0; h->lowered = false; return h->prog.loadFile(path) ? 1 : 0; }
-int fxp_load_text(fxp_handle* h, const char* text) { if (!h || !text) return 0; h->lowered = false; return h->prog.loadText(text) ? 1 : 0; }
+int fxp_load_file(fxp_handle* h, const char* path) { if (!h || !path) return 0; h->lowered = false; return guard(h, 0, [&] { return h->prog.loadFile(path) ? 1 : 0; }); }
+int fxp_load_text(fxp_handle* h, const char* text) { if (!h || !text) return 0; h->lowered = false; return guard(h, 0, [&] { return h->prog.loadText(text) ? 1 : 0; }); }
 int fxp_num_registers(fxp_handle* h) { return h ? (int)h->prog.regs.size() : 0; }
 const char* fxp_register_name(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.regs.size()) ? h->prog.regs[i].name.c_str() : ""; }
 int fxp_register_type(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.regs.size()) ? h->prog.regs[i].type : -1; }
@@ -143,7 +196,7 @@ int fxp_register_ioindex(fxp_handle* h, int i) { return (h && i >= 0 && i < (int
 float fxp_register_value(fxp_handle* h, int i) { return (h && i >= 0 && i < (int)h->prog.regs.size()) ? h->prog.regs[i].value : 0.0f; }
 int fxp_num_instructions(fxp_handle* h) { return h ? (int)h->prog.instrs.size() : 0; }
 void fxp_instruction(fxp_handle* h, int i, int o[8]) {
-    if (!h || i < 0 || i >= (int)h->prog.instrs.size()) return;
+    if (!h || !o || i < 0 || i >= (int)h->prog.instrs.size()) return;
     const fx::Instr& I = h->prog.instrs[i];
     o[0] = I.op; o[1] = I.r; o[2] = I.a; o[3] = I.x; o[4] = I.y; o[5] = I.hasInput; o[6] = I.hasOutput; o[7] = I.hasNoise;
 }
@@ -165,8 +218,12 @@ const double* fxp_lut(int kind, int exponent) {
     static const fx::Luts luts;
     return kind ? luts.exp_[exponent & 31] : luts.log_[exponent & 31];
 }
+static int lowerImpl(fxp_handle* h);
 int fxp_lower(fxp_handle* h) {
     if (!h) return FX_E_ARG;
+    return guardCode(h, [&] { return lowerImpl(h); });
+}
+static int lowerImpl(fxp_handle* h) {
     if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
     std::vector<float> values(h->prog.regs.size());
     for (size_t r = 0; r < values.size(); ++r) values[r] = h->prog.regs[r].value;
@@ -193,8 +250,20 @@ int64_t fxp_lower_info(fxp_handle* h, int what) {
         default: return -1;
     }
 }
+static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap);
 int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap) {
     if (!h) return FX_E_ARG;
+    try {
+        return translateImpl(h, vgprs, stream, code, cap, listing, listing_cap);
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return codeOf(e);
+    } catch (...) {
+        h->err = "unknown error";
+        return FX_E_PROGRAM;
+    }
+}
+static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap) {
     if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
     if (listing && listing_cap > 0) listing[0] = 0;
     std::vector<float> values(h->prog.regs.size());

@@ -45,6 +45,13 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
     out.layout = makeLayout(nRegs, CH);
     if (P == 0) { out.error = "program has no instructions"; return out; }
     if (CH < 1 || CH > 4) { out.error = "1..4 channels supported by the device path"; return out; }
+    // setChannels() can raise the loader's bound after construction (reference FX8010.h:73); the reference would then index
+    // its one-sample buffers out of bounds (FX8010.cpp:1056,1231): outside the parity domain, refused here
+    for (const Gpr& g : prog.regs)
+        if ((g.type == R_INPUT || g.type == R_OUTPUT) && (g.io < 0 || g.io >= CH)) {
+            out.error = "register '" + g.name + "' uses I/O index " + std::to_string(g.io) + " but the object was constructed with " + std::to_string(CH) + " channel(s)";
+            return out;
+        }
 
     auto isReadDelay = [&](const Instr& I) { return (I.op == IDELAY || I.op == XDELAY) && prog.regs[I.r].type == R_READ; };
     auto isWriteDelay = [&](const Instr& I) { return (I.op == IDELAY || I.op == XDELAY) && prog.regs[I.r].type == R_WRITE; };

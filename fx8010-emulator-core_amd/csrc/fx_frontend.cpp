@@ -94,7 +94,7 @@ bool declRemainder(const std::string& s, size_t from, std::string& number) {
 
 }  // namespace
 
-Program::Program(int channels) : numChannels(channels) {
+Program::Program(int channels) : numChannels(channels), loaderChannels(channels) {
     errors.push_back({kNoError, 1});          // source/FX8010.cpp:38-42
     regs.push_back({R_CCR, "ccr", 0.0f, 0});      // index 0, source/FX8010.cpp:50
     regs.push_back({R_READ, "read", 0.0f, 0});    // index 1, :53
@@ -153,7 +153,7 @@ void Program::checkLine(const std::string& line) {
                 // the number is the channel; stoi semantics ("1.5" -> 1)
                 long long ch = 0;
                 for (char c : number) { if (!isDigit(c)) break; ch = ch * 10 + (c - '0'); if (ch > 2147483647LL) { ch = 2147483647LL; sawUnparsable = true; break; } }
-                if (ch > numChannels - 1) {
+                if (ch > loaderChannels - 1) {
                     addError("I/O Index ausserhalb des gueltigen Bereichs (max. " + std::to_string(numChannels) + ")");
                     return;
                 }

@@ -56,7 +56,8 @@ public:
 
     int findRegister(const std::string& name) const;  // -1 if absent
 
-    int numChannels;
+    int numChannels;     // channels of the object as constructed: PCM layout, output latches, error texts
+    int loaderChannels;  // what setChannels() changes: only the loader's I/O-index bound (reference FX8010.h:73, FX8010.cpp:447)
     std::vector<Gpr> regs;
     std::vector<Instr> instrs;
     std::vector<LoadError> errors;  // [0] is always {"Kein Fehler", 1}

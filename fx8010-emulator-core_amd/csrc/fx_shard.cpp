@@ -1,0 +1,197 @@
+// fx_shard.cpp — fan-out / fan-in over the shards of a multi-GPU batch (see fx_shard.hpp).
+#include "fx_shard.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+
+#include "../../include/fx8010_amd.h"
+
+namespace fx {
+
+Sharded::Sharded(int64_t nInstances, int channels, const std::vector<int>& devices) : n_(nInstances) {
+    if (devices.empty()) throw std::runtime_error("no device given");
+    if (nInstances < (int64_t)devices.size()) throw std::runtime_error("fewer instances than shards");
+    const int64_t k = (int64_t)devices.size();
+    // contiguous ranges, whole wavefronts (64 instances) per shard where possible: shard i gets ceil-ish share
+    const int64_t waves = (nInstances + 63) / 64;
+    int64_t first = 0;
+    for (int64_t i = 0; i < k; ++i) {
+        const int64_t wavesHere = waves / k + (i < waves % k ? 1 : 0);
+        int64_t count = i + 1 == k ? nInstances - first : std::min<int64_t>(wavesHere * 64, nInstances - first);
+        if (count < 1) throw std::runtime_error("a shard would be empty: use fewer devices for this few instances");
+        auto w = std::make_unique<Worker>();
+        w->first = first;
+        w->count = count;
+        w->batch = std::make_unique<Batch>(count, channels, devices[(size_t)i]);
+        first += count;
+        shards_.push_back(std::move(w));
+    }
+    if (shards_.size() > 1)
+        for (auto& w : shards_) w->thread = std::thread(loop, w.get());
+}
+
+Sharded::~Sharded() {
+    for (auto& w : shards_) {
+        if (!w->thread.joinable()) continue;
+        {
+            std::lock_guard<std::mutex> lock(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        w->thread.join();
+    }
+}
+
+void Sharded::loop(Worker* w) {
+    std::unique_lock<std::mutex> lock(w->mu);
+    for (;;) {
+        w->cv.wait(lock, [&] { return w->pending || w->quit; });
+        if (w->quit) return;
+        std::function<int()> task = std::move(w->task);
+        w->pending = false;
+        lock.unlock();
+        int r;
+        try {
+            r = task();
+        } catch (const std::exception& e) {
+            w->batch->noteError(e.what());
+            r = FX_E_MEMORY;
+        }
+        lock.lock();
+        w->result = r;
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+
+int Sharded::fan(const std::function<int(int, Batch&)>& f) {
+    if (shards_.size() == 1) return f(0, *shards_[0]->batch);
+    for (size_t k = 0; k < shards_.size(); ++k) {
+        Worker* w = shards_[k].get();
+        std::lock_guard<std::mutex> lock(w->mu);
+        w->task = [&f, k, w] { return f((int)k, *w->batch); };
+        w->pending = true;
+        w->done = false;
+        w->cv.notify_all();
+    }
+    int first = 0;
+    for (auto& w : shards_) {
+        std::unique_lock<std::mutex> lock(w->mu);
+        w->cv.wait(lock, [&] { return w->done; });
+        if (first == 0 && w->result != 0) {
+            first = w->result;
+            lastError_ = w->batch->lastError();
+        }
+    }
+    return first;
+}
+
+int Sharded::shardOf(int64_t inst) const {
+    for (size_t k = 0; k < shards_.size(); ++k)
+        if (inst >= shards_[k]->first && inst < shards_[k]->first + shards_[k]->count) return (int)k;
+    return -1;
+}
+
+const std::string& Sharded::lastError() { return lastError_.empty() ? shards_.front()->batch->lastError() : lastError_; }
+
+bool Sharded::loadFile(const std::string& path) {
+    lastError_.clear();
+    return fan([&](int, Batch& b) { return b.loadFile(path) ? 0 : 1; }) == 0;
+}
+bool Sharded::loadText(const std::string& text) {
+    lastError_.clear();
+    return fan([&](int, Batch& b) { return b.loadText(text) ? 0 : 1; }) == 0;
+}
+int Sharded::setRegister(const std::string& key, float v) {
+    lastError_.clear();
+    return fan([&](int, Batch& b) { return b.setRegister(key, v); });
+}
+void Sharded::setChannels(int c) {
+    for (auto& w : shards_) w->batch->setChannels(c);
+}
+int Sharded::setRegisterAt(const std::string& key, int64_t inst, float v) {
+    const int k = shardOf(inst);
+    if (k < 0) { lastError_ = "instance out of range"; return front().program().findRegister(key) < 0 ? 1 : FX_E_ARG; }
+    return shards_[(size_t)k]->batch->setRegisterAt(key, inst - shards_[(size_t)k]->first, v);
+}
+float Sharded::getRegisterAt(const std::string& key, int64_t inst) {
+    const int k = shardOf(inst);
+    if (k < 0) return front().getRegisterAt(key, -1);
+    return shards_[(size_t)k]->batch->getRegisterAt(key, inst - shards_[(size_t)k]->first);
+}
+int Sharded::setRegisterArray(const std::string& key, const float* values) {
+    lastError_.clear();
+    if (!values) { lastError_ = "null buffer"; return FX_E_ARG; }
+    return fan([&](int k, Batch& b) { return b.setRegisterArray(key, values + shards_[(size_t)k]->first); });
+}
+int Sharded::getRegisterArray(const std::string& key, float* values) {
+    lastError_.clear();
+    if (!values) { lastError_ = "null buffer"; return FX_E_ARG; }
+    return fan([&](int k, Batch& b) { return b.getRegisterArray(key, values + shards_[(size_t)k]->first); });
+}
+int Sharded::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
+    const int k = shardOf(inst);
+    if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
+    return shards_[(size_t)k]->batch->seedNoiseAt(inst - shards_[(size_t)k]->first, x1, x2);
+}
+
+int Sharded::processHost(const float* in, float* out, int nSamples) {
+    lastError_.clear();
+    if (shards_.size() == 1) return front().processHost(in, out, nSamples);
+    if (nSamples > 0 && (!in || !out)) { lastError_ = "null buffer"; return FX_E_ARG; }
+    return fan([&](int k, Batch& b) {
+        const int64_t first = shards_[(size_t)k]->first;
+        return b.processHost(in ? in + first : in, out ? out + first : out, nSamples, n_);
+    });
+}
+int Sharded::processDeviceShards(const float* const* dIn, float* const* dOut, int nSamples) {
+    lastError_.clear();
+    if (nSamples > 0 && (!dIn || !dOut)) { lastError_ = "null buffer table"; return FX_E_ARG; }
+    return fan([&](int k, Batch& b) { return b.processDevice(dIn ? dIn[k] : nullptr, dOut ? dOut[k] : nullptr, nSamples, nullptr); });
+}
+int Sharded::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
+    lastError_.clear();
+    if (shards_.size() != 1) { lastError_ = "a batch of several shards takes one buffer pair per shard: fxb_process_block_dev_shards"; return FX_E_ARG; }
+    return front().processDevice(dIn, dOut, nSamples, stream);
+}
+int Sharded::sync() {
+    lastError_.clear();
+    return fan([](int, Batch& b) { return b.sync(); });
+}
+
+int64_t Sharded::instructionCounter() {
+    std::vector<int64_t> part(shards_.size(), 0);
+    fan([&](int k, Batch& b) { part[(size_t)k] = b.instructionCounter(); return 0; });
+    int64_t sum = 0;
+    for (int64_t p : part) {
+        if (p < 0) return -1;
+        sum += p;
+    }
+    return sum;
+}
+int64_t Sharded::instructionCounterAt(int64_t inst) {
+    const int k = shardOf(inst);
+    return k < 0 ? 0 : shards_[(size_t)k]->batch->instructionCounterAt(inst - shards_[(size_t)k]->first);
+}
+uint32_t Sharded::oodFlags() {
+    std::vector<uint32_t> part(shards_.size(), 0);
+    fan([&](int k, Batch& b) { part[(size_t)k] = b.oodFlags(); return 0; });
+    uint32_t all = 0;
+    for (uint32_t p : part) all |= p;
+    return all;
+}
+float Sharded::lastKernelMs() {
+    float worst = -1.0f;
+    for (auto& w : shards_) worst = std::max(worst, w->batch->lastKernelMs());
+    return worst;
+}
+int64_t Sharded::info(int what) {
+    if (what == FXB_INFO_GRID) {
+        int64_t sum = 0;
+        for (auto& w : shards_) sum += w->batch->info(what);
+        return sum;
+    }
+    return front().info(what);
+}
+
+}  // namespace fx

@@ -1,0 +1,88 @@
+// fx_shard.hpp — one batch of instances spread over several GPUs of a node (SURVEY.md section 8 b/e).
+//
+// Instances share nothing mutable, so the partition is contiguous instance ranges: shard k owns instances
+// [first_k, first_k + count_k) on device devices[k]; the program, its LUTs and the control values are replicated.
+// There is NO exchange step and no collective: every operation is a fan-out to the shards and a fan-in of their
+// results.  Each shard has its own host thread (so that the devices' copies, launches and waits overlap) and its
+// own HIP stream (inside fx::Batch); a shard's Batch is only ever touched from its thread.  A "sharded" batch with
+// a single shard runs inline on the caller's thread - that is what fxb_create() makes.
+#pragma once
+
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fx_batch.hpp"
+
+namespace fx {
+
+class Sharded {
+public:
+    // devices: HIP ordinals, one shard each (an ordinal may repeat: several shards on one GPU); -1 = the calling thread's
+    // current device.  Throws std::runtime_error when a device is unusable or there are more shards than instances.
+    Sharded(int64_t nInstances, int channels, const std::vector<int>& devices);
+    ~Sharded();
+    Sharded(const Sharded&) = delete;
+    Sharded& operator=(const Sharded&) = delete;
+
+    int shards() const { return (int)shards_.size(); }
+    int64_t instances() const { return n_; }
+    int64_t firstOf(int k) const { return shards_[(size_t)k]->first; }
+    int64_t countOf(int k) const { return shards_[(size_t)k]->count; }
+    int deviceOf(int k) const { return shards_[(size_t)k]->batch->device(); }
+    Batch& shard(int k) { return *shards_[(size_t)k]->batch; }
+    Batch& front() { return *shards_.front()->batch; }  // replicated state (program, errors, controls) reads from here
+
+    bool loadFile(const std::string& path);
+    bool loadText(const std::string& text);
+    int setRegister(const std::string& key, float v);
+    int setRegisterAt(const std::string& key, int64_t inst, float v);
+    float getRegisterAt(const std::string& key, int64_t inst);
+    int setRegisterArray(const std::string& key, const float* values);
+    int getRegisterArray(const std::string& key, float* values);
+    int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
+    void setChannels(int c);
+
+    // host buffers [sample][channel][all instances]: every shard copies its columns in, runs, copies them out
+    int processHost(const float* in, float* out, int nSamples);
+    // device-resident buffers, one pair per shard: dIn[k] / dOut[k] are [sample][channel][count_k] on shard k's device;
+    // asynchronous (pair with sync())
+    int processDeviceShards(const float* const* dIn, float* const* dOut, int nSamples);
+    // single shard only: the caller's stream
+    int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
+    int sync();
+
+    int64_t instructionCounter();
+    int64_t instructionCounterAt(int64_t inst);
+    uint32_t oodFlags();
+    float lastKernelMs();  // slowest shard
+    int64_t info(int what);
+    const std::string& lastError();
+
+private:
+    struct Worker {
+        std::unique_ptr<Batch> batch;
+        int64_t first = 0, count = 0;
+        // a one-slot mailbox: the owner posts a task, the thread runs it, the owner waits for `done`
+        std::thread thread;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> task;
+        bool pending = false, done = false, quit = false;
+        int result = 0;
+    };
+    int shardOf(int64_t inst) const;
+    // run f(k, batch) on every shard's thread, wait for all; returns the first non-zero result (shard order)
+    int fan(const std::function<int(int, Batch&)>& f);
+    static void loop(Worker* w);
+
+    int64_t n_ = 0;
+    std::vector<std::unique_ptr<Worker>> shards_;
+    std::string lastError_;
+};
+
+}  // namespace fx

@@ -14,9 +14,9 @@
 // #include "../include/FX8010.h" contributes nothing).
 //
 //   Klangraum::FX8010         one emulated DSP, one process() call per sample period
-//   Klangraum::FX8010Batch    N independent DSPs stepping one program on one GPU (the data-parallel path)
-//   Klangraum::FX8010Sharded  the same over several GPUs of one node (contiguous instance ranges, one host
-//                             thread + stream per device, no collective)
+//   Klangraum::FX8010Batch    N independent DSPs stepping one program on one GPU (the data-parallel path) or, built
+//                             with a device list / mask, over several GPUs of one node (contiguous instance
+//                             ranges, one host thread + stream per device, no collective)
 //
 // Header-only; link with -lfx8010_amd.  Differences that remain, by design:
 //   * construction prints no banner (the reference prints ~7 lines, source/FX8010.cpp:18-24);
@@ -86,7 +86,7 @@ public:
     // reference: FX8010(), include/FX8010.h:50 (declared only there)
     FX8010() : FX8010(1) {}
     // reference: FX8010(int numChannels), include/FX8010.h:51
-    FX8010(int numChannels) : h_(fx_create(numChannels)) {
+    FX8010(int numChannels) : channels_(numChannels), h_(fx_create(numChannels)) {
         if (!h_) throw std::runtime_error(std::string("FX8010: ") + fx_last_create_error());
     }
     ~FX8010() { fx_destroy(h_); }
@@ -98,13 +98,13 @@ public:
 
     // reference: std::vector<float> process(const std::vector<float>&), include/FX8010.h:57
     std::vector<float> process(const std::vector<float>& inputSamples) {
-        std::vector<float> out((size_t)fx_get_channels(h_), 0.0f);
+        std::vector<float> out((size_t)channels_, 0.0f);  // the reference's outputBuffer keeps its constructed size (FX8010.cpp:122)
         if (fx_process(h_, inputSamples.data(), out.data()) < 0) throw std::runtime_error(std::string("FX8010::process: ") + fx_last_error(h_));
         return out;
     }
     // extension: nSamples consecutive sample periods in one launch; in/out are [nSamples][channels]
     std::vector<float> processBlock(const std::vector<float>& in, int nSamples) {
-        std::vector<float> out((size_t)nSamples * (size_t)fx_get_channels(h_), 0.0f);
+        std::vector<float> out((size_t)nSamples * (size_t)channels_, 0.0f);
         if (fx_process_block(h_, in.data(), out.data(), nSamples) < 0) throw std::runtime_error(std::string("FX8010::processBlock: ") + fx_last_error(h_));
         return out;
     }
@@ -141,14 +141,34 @@ public:
     bool getReadyStatus() { return fx_ready(h_) != 0; }
 
 private:
+    int channels_;
     fx_handle* h_;
 };
 
-// N instances of one program on one GPU.  PCM layout: buf[(sample * channels + channel) * N + instance].
+// N instances of one program on one GPU - or, with a device list / mask, spread over several GPUs of the node
+// (contiguous instance ranges, one host thread + stream per device inside the library, no exchange between them).
+// PCM layout: buf[(sample * channels + channel) * N + instance].
 class FX8010Batch {
 public:
     FX8010Batch(int64_t nInstances, int numChannels, int device = -1) : n_(nInstances), ch_(numChannels), h_(fxb_create(nInstances, numChannels, device)) {
         if (!h_) throw std::runtime_error(std::string("FX8010Batch: ") + fx_last_create_error());
+    }
+    // one shard per entry of `devices` (HIP ordinals; an ordinal may repeat)
+    FX8010Batch(int64_t nInstances, int numChannels, const std::vector<int>& devices)
+        : n_(nInstances), ch_(numChannels), h_(fxb_create_on_devices(nInstances, numChannels, devices.data(), (int)devices.size())) {
+        if (!h_) throw std::runtime_error(std::string("FX8010Batch: ") + fx_last_create_error());
+    }
+    // one shard per set bit of deviceMask (bit d = HIP ordinal d): SURVEY.md section 8b's fxb_create(nInstances, ch, deviceMask)
+    static FX8010Batch* sharded(int64_t nInstances, int numChannels, uint64_t deviceMask) {
+        std::vector<int> devices;
+        for (int d = 0; d < 64; ++d)
+            if (deviceMask & (1ull << d)) devices.push_back(d);
+        return new FX8010Batch(nInstances, numChannels, devices);
+    }
+    int shardCount() { return fxb_shard_count(h_); }
+    // device-resident buffers of a sharded batch: dIn[k] / dOut[k] live on shard k's device, [nSamples][channels][instances of shard k]
+    void processDeviceShards(const float* const* dIn, float* const* dOut, int nSamples) {
+        if (fxb_process_block_dev_shards(h_, dIn, dOut, nSamples) < 0) throw std::runtime_error(std::string("FX8010Batch::processDeviceShards: ") + fxb_last_error(h_));
     }
     ~FX8010Batch() { fxb_destroy(h_); }
     FX8010Batch(const FX8010Batch&) = delete;

@@ -28,7 +28,7 @@ SYMBOLS = [
     "fx_create", "fx_destroy", "fx_load_file", "fx_process", "fx_process_block", "fx_set_register", "fx_get_register",
     "fx_instruction_counter", "fx_error_count", "fx_error_desc", "fx_error_row", "fx_control_count", "fx_control_at",
     "fx_meta_get", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
-    "fxb_create", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
+    "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
     "fxb_get_register_i", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
     "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error",
@@ -64,6 +64,9 @@ def load():
     sig("fx_set_channels", None, vp, i32); sig("fx_get_channels", i32, vp); sig("fx_ready", i32, vp)
     sig("fx_last_error", cp, vp); sig("fx_last_create_error", cp)
     sig("fxb_create", vp, i64, i32, i32); sig("fxb_destroy", None, vp)
+    sig("fxb_create_sharded", vp, i64, i32, C.c_uint64); sig("fxb_create_on_devices", vp, i64, i32, C.POINTER(C.c_int), i32)
+    sig("fxb_shard_count", i32, vp); sig("fxb_shard_info", i32, vp, i32, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64))
+    sig("fxb_process_block_dev_shards", i32, vp, C.POINTER(vp), C.POINTER(vp), i32)
     sig("fxb_load_file", i32, vp, cp); sig("fxb_load_text", i32, vp, cp)
     sig("fxb_set_register", i32, vp, cp, f32); sig("fxb_set_register_i", i32, vp, cp, i64, f32)
     sig("fxb_set_register_array", i32, vp, cp, vp); sig("fxb_get_register_array", i32, vp, cp, vp)
@@ -187,13 +190,37 @@ class Batch(_Reports):
     """N instances of one program on one GPU (fxb_*)."""
     _pfx = "fxb_"
 
-    def __init__(self, n_instances, channels=1, device=-1):
+    def __init__(self, n_instances, channels=1, device=-1, devices=None, device_mask=None):
+        """device: one HIP ordinal (-1: current).  devices=[...]: one shard per entry (fxb_create_on_devices; an ordinal may
+        repeat).  device_mask: one shard per set bit (fxb_create_sharded)."""
         self._lib = load()
         self.n = int(n_instances)
         self.channels = channels
-        self._h = self._lib.fxb_create(self.n, channels, device)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            self._h = self._lib.fxb_create_on_devices(self.n, channels, arr, len(devices))
+        elif device_mask is not None:
+            self._h = self._lib.fxb_create_sharded(self.n, channels, C.c_uint64(device_mask))
+        else:
+            self._h = self._lib.fxb_create(self.n, channels, device)
         if not self._h:
             raise RuntimeError("fxb_create failed: " + self._lib.fx_last_create_error().decode("latin-1"))
+
+    def shards(self):
+        """[(device, first_instance, n_instances)] of the batch's shards"""
+        out = []
+        for k in range(self._lib.fxb_shard_count(self._h)):
+            dev, first, cnt = C.c_int(), C.c_int64(), C.c_int64()
+            self._check(self._lib.fxb_shard_info(self._h, k, C.byref(dev), C.byref(first), C.byref(cnt)), "shard_info")
+            out.append((dev.value, first.value, cnt.value))
+        return out
+
+    def process_block_dev_shards(self, d_in, d_out, n_samples):
+        """d_in / d_out: one device pointer (int) per shard; asynchronous."""
+        k = len(d_in)
+        a = (C.c_void_p * k)(*[C.c_void_p(p) for p in d_in])
+        b = (C.c_void_p * k)(*[C.c_void_p(p) for p in d_out])
+        return self._check(self._lib.fxb_process_block_dev_shards(self._h, a, b, n_samples), "process_block_dev_shards")
 
     def close(self):
         if getattr(self, "_h", None):

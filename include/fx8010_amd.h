@@ -88,6 +88,19 @@ const char* fx_last_create_error(void);
 
 /* device: HIP ordinal, or -1 for the calling thread's current device. */
 fxb_handle* fxb_create(int64_t n_instances, int num_channels, int device);
+/* The same batch spread over several GPUs of one node (SURVEY.md section 8 b/e; the reference's README.md:13 "emulate
+ * much more DSP's" on many cores): contiguous instance ranges, whole wavefronts per shard, one host thread + one HIP
+ * stream per shard inside the library, program / tables / broadcast controls replicated, NO exchange between shards.
+ * Every fxb_* call works on such a handle unchanged (instances keep their global numbers; host PCM buffers keep the
+ * [sample][channel][all instances] layout and each shard copies its own columns); device-resident PCM is per device and
+ * goes through fxb_process_block_dev_shards.
+ *   fxb_create_sharded     one shard per set bit of device_mask (bit d = HIP ordinal d), in ordinal order
+ *   fxb_create_on_devices  one shard per list entry; an ordinal may repeat (several shards on one GPU) */
+fxb_handle* fxb_create_sharded(int64_t n_instances, int num_channels, uint64_t device_mask);
+fxb_handle* fxb_create_on_devices(int64_t n_instances, int num_channels, const int* devices, int n_devices);
+int fxb_shard_count(fxb_handle* h);
+/* device ordinal, first global instance and instance count of a shard; 0 or FX_E_ARG.  Any out pointer may be NULL. */
+int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instance, int64_t* n_instances);
 void fxb_destroy(fxb_handle* h);
 /* as fx_load_file; the program is parsed once on the host and lowered to the device
  * opcode stream.  fxb_load_text takes the program text itself. */
@@ -111,6 +124,9 @@ int fxb_process_block(fxb_handle* h, const float* in, float* out, int n_samples)
 /* Same with device-resident buffers (hipMalloc'ed, on h's device); asynchronous on `stream`
  * (a hipStream_t, NULL = the handle's own stream).  Pair with fxb_sync(). */
 int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n_samples, void* stream);
+/* Sharded batches: d_in[k] / d_out[k] are shard k's buffers on shard k's device, [n_samples][num_channels][n_instances of
+ * the shard]; launched concurrently from the shards' own threads on their own streams.  Pair with fxb_sync(). */
+int fxb_process_block_dev_shards(fxb_handle* h, const float* const* d_in, float* const* d_out, int n_samples);
 int fxb_sync(fxb_handle* h);
 /* executed instructions (reference counting: END and SKIP count, skipped ones do not):
  * summed over all instances / of one instance */

@@ -1,0 +1,189 @@
+"""GPU tests of the drop-in boundary itself: the multi-device batch handle, the reference's setChannels() meaning,
+loads that fail after a good one, and the reference's own console harness running on the device."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fx8010_programs as progs
+from pyoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name,n,s", [("config5", 1000, 96), ("config4", 333, 64), ("config3", 200, 1100)])
+def test_two_shards_on_one_gpu_reproduce_the_single_handle(gpu, name, n, s):
+    """fxb_create_on_devices with two shards (both on device 0: one host thread + stream each) against fxb_create:
+    outputs, registers, counters and flags bit for bit - through host buffers (each shard copies its columns of the
+    caller's [S][N] arrays) and through per-shard device buffers."""
+    import torch
+
+    text = progs.CONFIGS[name]()
+    x = progs.stimulus(n, s)
+    one = gpu.Batch(n, 1, 0)
+    two = gpu.Batch(n, 1, devices=[0, 0])
+    assert one.load_text(text) and two.load_text(text)
+    sh = two.shards()
+    assert len(sh) == 2 and sh[0][1] == 0 and sh[0][2] % 64 == 0 and sh[0][2] + sh[1][2] == n and sh[1][1] == sh[0][2]
+    # per-instance state on both sides of the cut
+    for inst, v in ((0, 0.25), (sh[0][2] - 1, -0.5), (sh[0][2], 0.125), (n - 1, 0.75)):
+        key = {"config5": "u", "config4": "o", "config3": "t"}[name]
+        one.set_register_i(key, inst, v)
+        two.set_register_i(key, inst, v)
+    y1 = one.process_block(x[: s // 2])
+    y2 = two.process_block(x[: s // 2])
+    assert np.array_equal(bits(y1), bits(y2))
+    # second half through device-resident buffers, one pair per shard
+    xs = [torch.from_numpy(np.ascontiguousarray(x[s // 2:, f:f + c])).cuda() for _, f, c in sh]
+    ys = [torch.empty_like(t) for t in xs]
+    torch.cuda.synchronize()
+    two.process_block_dev_shards([t.data_ptr() for t in xs], [t.data_ptr() for t in ys], s - s // 2)
+    two.sync()
+    y1b = one.process_block(x[s // 2:])
+    y2b = np.concatenate([t.cpu().numpy() for t in ys], axis=1)
+    assert np.array_equal(bits(y1b), bits(y2b))
+    assert one.instruction_counter() == two.instruction_counter()
+    assert one.ood_flags() == two.ood_flags() == 0
+    for inst in (0, sh[0][2] - 1, sh[0][2], n - 1):
+        assert one.instruction_counter_i(inst) == two.instruction_counter_i(inst)
+        for r in ("ccr", "out"):
+            assert one.get_register_bits_i(r, inst) == two.get_register_bits_i(r, inst)
+    # and against the oracle for the instances next to the cut
+    for inst in (sh[0][2] - 1, sh[0][2]):
+        o = Oracle(1)
+        assert o.load_text(text)
+        key = {"config5": "u", "config4": "o", "config3": "t"}[name]
+        o.set_register(key, {sh[0][2] - 1: -0.5, sh[0][2]: 0.125}[inst])
+        ref = o.process_block(x[:, inst].copy())
+        got = np.concatenate([y2[:, inst], y2b[:, inst]])
+        assert np.array_equal(bits(ref), bits(got)), inst
+
+
+def test_sharded_arrays_and_broadcasts(gpu):
+    n, s = 300, 40
+    text = progs.config2()
+    x = progs.stimulus(n, s)
+    one, three = gpu.Batch(n, 1, 0), gpu.Batch(n, 1, devices=[0, 0, 0])
+    assert one.load_text(text) and three.load_text(text)
+    assert len(three.shards()) == 3
+    vals = np.linspace(0.01, 0.9, n).astype(np.float32)
+    for b in (one, three):
+        b.set_register_array("cutoff", vals)
+    assert np.array_equal(bits(one.process_block(x)), bits(three.process_block(x)))
+    assert np.array_equal(bits(one.get_register_array("t")), bits(three.get_register_array("t")))
+    for b in (one, three):
+        b.set_register("cutoff", 0.4)
+    assert np.array_equal(bits(one.process_block(x)), bits(three.process_block(x)))
+    with pytest.raises(RuntimeError):
+        three.process_block_dev(0, 0, 4)  # one buffer pair cannot feed three shards
+
+
+def test_more_shards_than_wavefronts_is_refused(gpu):
+    with pytest.raises(RuntimeError):
+        gpu.Batch(3, 1, devices=[0, 0, 0, 0])
+
+
+def test_set_channels_only_moves_the_loaders_bound(gpu):
+    """reference: setChannels() changes numChannels, which only the loader's I/O-index check reads (FX8010.h:73,
+    FX8010.cpp:447); the one-sample buffers keep their constructed size.  Here: the device layout stays, a program that
+    then declares an index beyond it is refused at lowering (the reference would index out of bounds)."""
+    import ctypes as C
+
+    lib = gpu.load()
+    b = gpu.Batch(70, 1, 0)
+    assert not b.load_text("input in 1\noutput out 0\nmacs out, 0, in, 0.5\nend")  # index 1 > channels - 1
+    assert b.errors()[1][0].startswith("I/O Index")
+    h = lib.fx_create(1)
+    lib.fx_set_channels(h, 2)
+    assert lib.fx_get_channels(h) == 2
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "chan2.da")
+    with open(path, "wb") as fh:
+        fh.write(b"input in 1\noutput out 0\nmacs out, 0, in, 0.5\nend")
+    assert lib.fx_load_file(h, path.encode()) == 1  # the loader accepts index 1 now
+    x = (C.c_float * 1)(0.5)
+    y = (C.c_float * 1)(9.0)
+    assert lib.fx_process(h, x, y) == -4  # FX_E_PROGRAM: outside the parity domain, nothing was written out of bounds
+    assert b"I/O index 1" in lib.fx_last_error(h)
+    assert y[0] == 9.0
+    lib.fx_destroy(h)
+    # a batch that was constructed with two channels runs the same program
+    b2 = gpu.Batch(70, 2, 0)
+    assert b2.load_text("input in 1\noutput out 0\nmacs out, 0, in, 0.5\nend")
+    xx = np.zeros((8, 2, 70), dtype=np.float32)
+    xx[:, 0, :] = 0.25
+    xx[:, 1, :] = 0.5
+    # (the reference reads an X operand's input through A's channel - A is the literal 0 here, channel 0: FX8010.cpp:1058)
+    assert np.all(b2.process_block(xx)[:, 0, :] == 0.125)
+
+
+def test_failed_load_after_a_good_one_keeps_the_state_rows_apart(gpu):
+    """a load that fails still appends its literals and declarations (as the reference does); writing such a new register
+    must not land in the output-latch / cursor / LFSR / counter rows behind the old register block"""
+    n, s = 130, 50
+    text = progs.config3()
+    x = progs.stimulus(n, s)
+    b = gpu.Batch(n, 1, 0)
+    assert b.load_text(text)
+    y0 = b.process_block(x[:20])
+    nregs = b.info("num_registers")
+    assert not b.load_text("static fresh1\nstatic fresh2\nmacs fresh1, 0.123, 0.456, 0.789\nthis is not a line\nend")
+    assert b.info("num_registers") > nregs
+    b.set_register("fresh1", 0.5)
+    b.set_register_i("fresh2", 3, 0.25)
+    b.set_register_i("0.789", n - 1, 0.75)
+    assert b.get_register_i("fresh2", 3) == 0.25 and b.get_register_i("fresh2", 4) == 0.0
+    y1 = b.process_block(x[20:])
+    bad = "static fresh1\nstatic fresh2\nmacs fresh1, 0.123, 0.456, 0.789\nthis is not a line\nend"
+    for inst in (0, 3, 64, n - 1):
+        # the same call sequence on the oracle: like the reference, the failed load has appended its registers AND its
+        # two instructions (they run behind the first program's END from now on, FX8010.cpp:1033-1043)
+        o = Oracle(1)
+        assert o.load_text(text)
+        r0 = o.process_block(x[:20, inst].copy())
+        assert not o.load_text(bad)
+        o.set_register("fresh1", 0.5)
+        if inst == 3:
+            o.set_register("fresh2", 0.25)
+        if inst == n - 1:
+            o.set_register("0.789", 0.75)
+        r1 = o.process_block(x[20:, inst].copy())
+        assert np.array_equal(bits(np.concatenate([r0, r1])), bits(np.concatenate([y0[:, inst], y1[:, inst]]))), inst
+        assert b.instruction_counter_i(inst) == o.instruction_counter() == 256 * 20 + 258 * 30
+        for r in ("fresh1", "fresh2", "0.789", "rd", "ccr"):
+            assert b.get_register_bits_i(r, inst) == o.get_register_bits(r), (inst, r)
+    assert b.ood_flags() == 0
+
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "main_dropin")
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/main_dropin not built (needs /root/reference at build time)")
+def test_the_references_own_harness_runs_on_the_device(gpu, tmp_path):
+    """oracle/_ref/main_dropin = the reference's source/main.cpp + helpers.cpp compiled where they lie against
+    host/FX8010.h and linked with libfx8010_amd.so (oracle/Makefile `harness`).  It loads ./testcode.da, runs its
+    32-sample slider test and prints instruction count, a register, metadata and the control list - compared with what
+    oracle/_ref/main_ref (the same file linked with the reference's own FX8010.cpp) prints."""
+    with open(tmp_path / "testcode.da", "wb") as fh:
+        fh.write(progs.config1_shipped().encode())
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fx8010-emulator-core_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    got = subprocess.run([HARNESS], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+    assert got.returncode == 0, got.stderr
+    ref = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "main_ref")], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert ref.returncode == 0
+
+    def facts(out):
+        keep = []
+        for line in out.splitlines():
+            if "Instructions pro Audioblock" in line:
+                keep.append(line.split(" fuer ")[1])  # the count, not the microseconds
+            elif line.startswith(("Registerwert", "name:", "engine:", "comment:", "volume", "pan", "filter_cutoff", "Erlaubtes")):
+                keep.append(line)
+        return sorted(keep)
+
+    assert facts(got.stdout) == facts(ref.stdout) and len(facts(got.stdout)) >= 8
