@@ -38,6 +38,17 @@ namespace {
 inline float asFloat(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline uint32_t asBits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float sat1(float v) { return (v >= 1.0f) ? 1.0f : ((v <= -1.0f) ? -1.0f : v); }  // reference saturate()
+// Host-side folding of uniform operands must hand on the same NaN the reference's x86 build would: the FIRST operand's
+// (quieted, sign untouched), then the second's - whatever order this file's compiler picks for a plain + or *.
+// Operand order per opcode: tests/golden/nan_collisions.json (see fx_xlate.cpp product()).
+inline bool isNanF(float f) { return f != f; }
+inline float quietF(float f) { uint32_t u = asBits(f) | 0x00400000u; return asFloat(u); }
+inline double quietD(double d) { uint64_t u; std::memcpy(&u, &d, 8); u |= 0x0008000000000000ull; std::memcpy(&d, &u, 8); return d; }
+inline float addFirst(float a, float b) { return isNanF(a) ? quietF(a) : (isNanF(b) ? quietF(b) : a + b); }
+inline float subFirst(float a, float b) { return isNanF(a) ? quietF(a) : (isNanF(b) ? quietF(b) : a - b); }
+inline float mulFirst(float a, float b) { return isNanF(a) ? quietF(a) : (isNanF(b) ? quietF(b) : a * b); }
+inline double addFirstD(double a, double b) { return a != a ? quietD(a) : (b != b ? quietD(b) : a + b); }
+inline double mulFirstD(double a, double b) { return a != a ? quietD(a) : (b != b ? quietD(b) : a * b); }
 }  // namespace
 
 std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint64_t* handlers, bool foldUniform) {
@@ -78,11 +89,11 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
             case H_MACSN: {
                 slot = (h == H_MACS ? AS_MACS : AS_MACSN) + kind * 2 + ccr;
                 if (foldUniform && (kind & 6u) == 6u) {  // uniform X and Y: p = X*Y once, here
-                    const float prod = asFloat(m.w[3]) * asFloat(m.w[4]);
+                    const float prod = mulFirst(asFloat(m.w[3]), asFloat(m.w[4]));
                     r.w[3] = asBits(prod);
                     if (kind == 7u) {
                         const float a = asFloat(m.w[2]);
-                        r.w[2] = asBits(sat1(h == H_MACS ? a + prod : a - prod));
+                        r.w[2] = asBits(sat1(h == H_MACS ? addFirst(prod, a) : subFirst(a, prod)));
                     }
                 }
                 break;
@@ -90,20 +101,20 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
             case H_ACC3:
                 slot = AS_ACC3 + kind * 2 + ccr;
                 if (foldUniform && (kind & 3u) == 3u) {  // uniform A and X: t = A + X once, here
-                    const float t = asFloat(m.w[2]) + asFloat(m.w[3]);
-                    r.w[2] = asBits(kind == 7u ? sat1(t + asFloat(m.w[4])) : t);
+                    const float t = addFirst(asFloat(m.w[2]), asFloat(m.w[3]));
+                    r.w[2] = asBits(kind == 7u ? sat1(addFirst(t, asFloat(m.w[4]))) : t);
                 }
                 break;
             case H_INTERP: {
                 slot = AS_INTERP + kind * 2 + ccr;
                 const float x = asFloat(m.w[3]);
-                const double omx = 1.0 - (double)x;
+                const double omx = isNanF(x) ? quietD((double)x) : 1.0 - (double)x;
                 if (kind & 2u) std::memcpy(&r.w[6], &omx, 8);  // uniform X: (1.0 - (double)X) is the same for every instance
                 if (foldUniform && (kind & 6u) == 6u) {
-                    const float prod = x * asFloat(m.w[4]);
+                    const float prod = mulFirst(x, asFloat(m.w[4]));
                     r.w[3] = asBits(prod);
                     if (kind == 7u) {
-                        const double d = omx * (double)asFloat(m.w[2]) + (double)prod;
+                        const double d = addFirstD(mulFirstD(omx, (double)asFloat(m.w[2])), (double)prod);
                         r.w[2] = asBits(sat1((float)d));
                     }
                 }

@@ -60,6 +60,41 @@ __device__ __forceinline__ int cvtt_f64(double v) {
     return bad ? (int)0x80000000 : r;
 }
 
+// Arithmetic with a fixed SOURCE order (the compiler may commute a plain + or *): which NaN an instruction hands on when
+// several operands are NaN depends on it - gfx950: the first source; the x86 build of the reference: the first operand
+// of the SSE instruction g++ chose.  negated() is an exact sign change that leaves a NaN's sign alone (v_sub_f32 and neg
+// modifiers flip it; x86 subss does not).  See tools/micro/nanrules.hip and tests/golden/nan_collisions.json.
+__device__ __forceinline__ float addFirst(float first, float second) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(first), "v"(second));
+    return r;
+}
+__device__ __forceinline__ float mulFirst(float first, float second) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(first), "v"(second));
+    return r;
+}
+__device__ __forceinline__ float negated(float v) {
+    float r;
+    asm("v_mul_f32 %0, -1.0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ double addFirst64(double first, double second) {
+    double r;
+    asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(first), "v"(second));
+    return r;
+}
+__device__ __forceinline__ double mulFirst64(double first, double second) {
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(first), "v"(second));
+    return r;
+}
+__device__ __forceinline__ double oneMinus(double x) {  // 1.0 - x in one rounding, a NaN keeps its sign
+    double r;
+    asm("v_fma_f64 %0, %1, -1.0, 1.0" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // reference saturate(x, 1.0f), source/FX8010.cpp:275-279 (NaN passes through)
 __device__ __forceinline__ float saturate1(float v) { return (v >= 1.0f) ? 1.0f : ((v <= -1.0f) ? -1.0f : v); }
 
@@ -252,37 +287,40 @@ __device__ __forceinline__ void execOp(const Ctx<K>& c, uint32_t w0, uint32_t rO
     const Vec<K> y = (w0 & F_UY) ? splat<K>(asF(wY)) : ldsLoad<K>(c.lane, wY);
     Vec<K> r = a;
     switch (w0 & 0xffu) {
+        // NaN operands: the x86 build hands on the NaN of the first operand of each SSE instruction (quieted, sign untouched);
+        // gfx950 that of the first source, but flips the sign of a negated source.  first(a, b) keeps a as src0; sums with a
+        // subtrahend are A + (-1.0 * p); operand order per opcode as pinned by tests/golden/nan_collisions.json.
         case H_MACS:  // R = sat(A + X*Y)   FX8010.cpp:1077-1085 (MACINTS :1095-1103 is the same expression)
 #pragma unroll
-            for (int k = 0; k < K; ++k) { const float p = x.v[k] * y.v[k]; r.v[k] = saturate1(a.v[k] + p); }
+            for (int k = 0; k < K; ++k) { const float p = mulFirst(x.v[k], y.v[k]); r.v[k] = saturate1(addFirst(p, a.v[k])); }
             break;
         case H_MACSN:  // R = sat(A - X*Y)   :1086-1094
 #pragma unroll
-            for (int k = 0; k < K; ++k) { const float p = x.v[k] * y.v[k]; r.v[k] = saturate1(a.v[k] - p); }
+            for (int k = 0; k < K; ++k) { const float p = mulFirst(x.v[k], y.v[k]); r.v[k] = saturate1(addFirst(a.v[k], negated(p))); }
             break;
         case H_ACC3:  // R = sat((A + X) + Y)   :1104-1112
 #pragma unroll
-            for (int k = 0; k < K; ++k) { const float t = a.v[k] + x.v[k]; r.v[k] = saturate1(t + y.v[k]); }
+            for (int k = 0; k < K; ++k) { const float t = addFirst(a.v[k], x.v[k]); r.v[k] = saturate1(addFirst(t, y.v[k])); }
             break;
         case H_INTERP:  // R = sat((float)((1.0 - X)*A + (double)(X*Y)))   :1180-1187
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float p = x.v[k] * y.v[k];
-                const double d = (1.0 - (double)x.v[k]) * (double)a.v[k] + (double)p;
+                const float p = mulFirst(x.v[k], y.v[k]);
+                const double d = addFirst64(mulFirst64(oneMinus((double)x.v[k]), (double)a.v[k]), (double)p);
                 r.v[k] = saturate1((float)d);
             }
             break;
         case H_MACW:  // R = A + wrap(X*Y)   :1126-1131
 #pragma unroll
-            for (int k = 0; k < K; ++k) r.v[k] = a.v[k] + wrapAround(x.v[k] * y.v[k]);
+            for (int k = 0; k < K; ++k) r.v[k] = addFirst(a.v[k], wrapAround(mulFirst(x.v[k], y.v[k])));
             break;
         case H_MACWN:  // R = A - wrap(X*Y)   :1132-1137
 #pragma unroll
-            for (int k = 0; k < K; ++k) r.v[k] = a.v[k] - wrapAround(x.v[k] * y.v[k]);
+            for (int k = 0; k < K; ++k) r.v[k] = addFirst(a.v[k], negated(wrapAround(mulFirst(x.v[k], y.v[k]))));
             break;
         case H_MACINTW:  // R = wrap(A + X*Y)   :1138-1143
 #pragma unroll
-            for (int k = 0; k < K; ++k) { const float p = x.v[k] * y.v[k]; r.v[k] = wrapAround(a.v[k] + p); }
+            for (int k = 0; k < K; ++k) { const float p = mulFirst(x.v[k], y.v[k]); r.v[k] = wrapAround(addFirst(p, a.v[k])); }
             break;
         case H_MOV:  // MACMV (:1144-1149, accumulator unobservable), input refresh (:1053-1061), output latch (:1229-1233)
             break;

@@ -903,6 +903,21 @@ class Translator {
         e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", vR, vreg(5), 2, ", vcc");
     }
 
+    // NaN operands (exact streams only; a fast stream never sees one).  The x86 build hands on the NaN of the FIRST operand
+    // of each SSE instruction, quieted, sign untouched - and which operand is first is g++'s choice per expression, pinned by
+    // tests/golden/nan_collisions.json: MACS / MACINTS / MACINTW  X, Y, A;  MACSN / ACC3 / MACW / MACWN  A, X, Y;  INTERP  X, A, Y.
+    // gfx950 hands on the NaN of the first SOURCE (src0, src1, src2), quieted - but a negated source (v_sub_f32, neg
+    // modifiers) has its sign flipped first (tools/micro/nanrules.hip).  So the exact streams order their sources like
+    // the x86 build and never subtract: A - p is A + (-1.0 * p), 1 - X is fma(X, -1.0, 1.0).
+    static bool isNanBits(uint32_t bits) { return (bits & 0x7fffffffu) > 0x7f800000u; }
+    // a uniform NaN is put into a temporary VGPR so that it can take any source position
+    bool orderedOperand(uint32_t word, bool uniform, int temp, int* v) {
+        if (!uniform) return row(word, v);
+        e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(temp), value(word));
+        *v = temp;
+        return true;
+    }
+
     // p = X * Y into v3 unless both are uniform (then the record's X word holds the folded product)
     bool product(const MicroOp& r, uint32_t kind, bool* inV3) {
         const bool uX = kind & 2, uY = kind & 4;
@@ -915,6 +930,10 @@ class Translator {
         } else if (uX) {
             a = value(r.w[3]);
             if (!row(r.w[4], &b)) return false;
+        } else if (!fast_ && isNanBits(r.w[4])) {  // X must stay the first source
+            int vy;
+            if (!operand(r.w[3], false, &a) || !orderedOperand(r.w[4], true, 4, &vy)) return false;
+            b = vy;
         } else {
             a = value(r.w[4]);
             if (!row(r.w[3], &b)) return false;
@@ -935,7 +954,7 @@ class Translator {
         int pv = 3;
         bool inV3;
         const uint32_t unitWord = ((kind & 6u) == 2u) ? r.w[3] : ((kind & 6u) == 4u) ? r.w[4] : 0u;
-        if ((unitWord & 0x7fffffffu) == 0x3f800000u) {
+        if (fast_ && (unitWord & 0x7fffffffu) == 0x3f800000u) {  // (the exact streams multiply: the operand order decides which NaN is handed on)
             if (!row((kind & 6u) == 2u ? r.w[4] : r.w[3], &pv)) return false;
             if (unitWord >> 31) neg = !neg;
             inV3 = true;
@@ -945,6 +964,23 @@ class Translator {
         }
         const bool within = resultWithinUnit(neg ? 1 : 0, kind, r);  // then the sum goes straight to its row
         const int d = within ? vR : 2;
+        if (!fast_) {
+            // exact stream: sources in the x86 build's order, no subtraction (see product())
+            int vp = pv, vA;
+            if (!inV3) {
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(3), value(r.w[3]));  // the folded product
+                vp = 3;
+            }
+            if (neg) {
+                e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 3, imm32(0xbf800000u), vp);  // -p; a NaN keeps its sign
+                vp = 3;
+            }
+            if (!orderedOperand(r.w[2], kind & 1, 12, &vA)) return false;
+            if (neg) e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", d, vreg(vA), vp);  // A first
+            else e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", d, vreg(vp), vA);      // the product first
+            satStore(vR);
+            return true;
+        }
         if (inV3) {
             Src a;
             if (!operand(r.w[2], kind & 1, &a)) return false;
@@ -970,6 +1006,20 @@ class Translator {
         const bool uA = kind & 1, uX = kind & 2, uY = kind & 4;
         const bool within = resultWithinUnit(2, kind, r);
         const int d = within ? vR : 2;
+        if (!fast_) {
+            // exact stream: (A + X) + Y with A, X, Y in that source order (NaN priority of the x86 build, see product())
+            int vA, vX, vY;
+            if (uA && uX) {
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));  // A + X folded by the host
+            } else {
+                if (!orderedOperand(r.w[2], uA, 12, &vA) || !orderedOperand(r.w[3], uX, 4, &vX)) return false;
+                e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, vreg(vA), vX);
+            }
+            if (!orderedOperand(r.w[4], uY, 4, &vY)) return false;
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", d, vreg(2), vY);
+            satStore(vR);
+            return true;
+        }
         if (uA && uX) {  // t = A + X folded into the A word
             int vY;
             if (!row(r.w[4], &vY)) return false;
@@ -1047,7 +1097,9 @@ class Translator {
             Src x;
             if (!operand(r.w[3], false, &x)) return false;
             e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(6), x);
-            e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), named(242, "1.0"), vreg64(6), nullptr, 2);
+            // 1.0 - X as fma(X, -1.0, 1.0): one rounding as well, and a NaN in X keeps its sign (a negated source flips it)
+            Src plusOne = named(242, "1.0");
+            e_.vop3(VOP3_FMA_F64, "v_fma_f64", vreg64(6), vreg64(6), named(243, "-1.0"), &plusOne);
             e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
         }
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), p);
@@ -1270,7 +1322,7 @@ class Translator {
             ++stats_.inlined;
             return true;
         }
-        if (slot == AS_LUT && !(r.w[6] & 1u) && !(ccrLive && prog_.compactCcr)) {
+        if (slot == AS_LUT && !(r.w[6] & 1u)) {
             ++stats_.inlined;
             if (!lut(r)) return false;
             if (ccrLive) ccrFrom(vrow(r.w[5]));
@@ -1295,10 +1347,9 @@ class Translator {
                     default: return interp(r, kind);
                 }
             }
-            // a live CCR.  Last-sample streams materialise every CCR write and run once per block: they call the
-            // interpreter's handler (compact code).  Steady streams: the same code as above, then setCCR of the stored
-            // result - or the predicate of the SKIP that reads it.
-            if (prog_.compactCcr) return call(r, slot, family == 3 ? 0xfcu : 0x3cu);
+            // a live CCR: the same code as above, then setCCR of the stored result - or the predicate of the SKIP that
+            // reads it.  (Last-sample streams mark every CCR write live, but all except the final ones are overwritten
+            // before anything reads them - ccrDeadAfter - so this stays short there too.)
             if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
             ++stats_.inlined;
             bool ok;
@@ -1312,7 +1363,7 @@ class Translator {
             ccrOrSkip(vrow(r.w[5]));
             return true;
         }
-        if (slot == AS_MOV && !(ccrLive && prog_.compactCcr)) {
+        if (slot == AS_MOV) {
             int vR;
             Src a;
             if (!touch(r, !(r.w[6] & 1u), false, false, true)) return false;
@@ -1659,7 +1710,6 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     // streams' escape targets), then the fast ones.
     const std::vector<MicroOp>* recs[2] = {&steadyRecords, &lastRecords};
     XlateProgram prog[2] = {program, program};
-    prog[1].compactCcr = true;  // last-sample streams materialise every CCR write and run once: handler calls (compact code)
     uint32_t bytes[4] = {0, 0, 0, 0};  // steady fast, steady exact, last fast, last exact
     bool fastOk = true;
     for (int k = 0; k < 2; ++k) {

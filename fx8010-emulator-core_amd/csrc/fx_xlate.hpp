@@ -60,7 +60,6 @@ struct XlateProgram {
     // LOG/EXP tables in LDS: the fp32 thresholds, x1[] and the {slope, y1} arrays of the tables the program uses
     // (lutTables = their byte offsets in the LUT blob, in LDS order); empty = tables are read from global memory
     std::vector<uint32_t> lutTables;
-    bool compactCcr = false;      // set by planXlate for the last-sample streams: live-CCR instructions call the handler
     std::vector<uint8_t> wildRow; // per register-file row: 0 = BOUNDED class (always inside [-1, 1]), 1 = WILD
     // PCM I/O of the generated sample loop: row the input of channel c is copied to (-1: unused), row of its output latch
     std::vector<int> inRows, latchRows;

@@ -81,6 +81,15 @@ OPCODE_PROGRAMS = {
     "out_read_back": "macs out, out, in, 0.1", "idelay_nop_r": "idelay a, in, at, 0\nmacs out, 0, in, 1.0",
     "latch_on_skip": "macs out, 0, in, 1.0\nmacs out, out, 0.5, 0.5\nskip out, ccr, 2, 0",
     "skip_over_end": "macs a, in, 0, 0\nmacs out, out, 0.125, 0.5\nskip ccr, ccr, 6, 2\nmacs b, in, 0.5, 0.5",
+    # END in the middle: the for-loop of process() finishes its pass, so the instructions behind it still run (and count),
+    # FX8010.cpp:1033-1043
+    "end_in_the_middle": "macs a, in, 0.5, 0.5\nend\nmacs out, a, in, 0.25\nmacs b, out, 0.5, 0.5",
+    "end_twice_then_skip": "macs a, in, 0, 0\nend\nskip ccr, ccr, 6, 1\nmacs out, 0, in, 1.0\nend\nmacs b, out, in, 0.5",
+    # the logicOps branches (FX8010.cpp:330-360) not covered above: Y == ~X (OR), Y == 0xFFFFFF with another X (NAND);
+    # X == 0xFFFFFFF is not a float (it reads back as 0x10000000), so the NOT branch cannot be reached: generic result
+    "andxor_or": "macw a, 0, in, 100\nandxor out, a, 12, -13", "andxor_nand": "macw a, 0, in, 100\nandxor out, a, 12, 16777215",
+    "andxor_not_unreachable": "macw a, 0, in, 100\nandxor out, a, 268435455, 16777215",
+    "andxor_or_from_registers": "macw a, 0, in, 100\nmacw b, -1, a, -1\nandxor out, 5, a, b",
 }
 
 # loader corpus: each entry is a whole program text; only load status / error list / lists are pinned
@@ -163,6 +172,44 @@ def main():
             c["instance"] = inst
             cfg.append(c)
     out["configs.json"] = cfg
+
+    # 6b. non-finite values: what the x86 build of the reference does with NaN (either sign, payloads, signalling) and
+    # Inf coming in through the PCM input, with NaNs made by the arithmetic itself (Inf * 0, Inf - Inf: the x86 default
+    # NaN is NEGATIVE, 0xFFC00000), through saturating and non-saturating instructions, TRAM and the fp64 path
+    def f32(bits):
+        return np.array(bits, dtype=np.uint32).view(np.float32)
+    nf = f32([0x3f800000, 0x7fc00000, 0x3f000000, 0xffc00000, 0x3e800000, 0x7fc12345, 0xbf000000, 0x7f812345, 0x3f400000, 0xff9abcde,
+              0x7f800000, 0xbe800000, 0xff800000, 0x00000000, 0x80000000, 0x3f800000, 0x7f800000, 0x7f800000, 0xff800000, 0x3dcccccd,
+              0x7fffffff, 0x3f000000, 0xffffffff, 0x3f000000])
+    NONFINITE = {
+        "macs": "macs out, in, vol, 0.75", "macs_times_zero": "macs out, 0, in, 0", "macsn_self": "macsn out, in, in, 1.0",
+        "macs_product_of_input": "macs out, 0.5, in, in", "acc3": "acc3 out, in, in, 0.25", "acc3_cancel": "macsn a, 0, in, 1.0\nacc3 out, in, a, 0.25",
+        "interp_state": "interp out, out, 0.1, in", "interp_operands": "interp out, in, vol, in", "interp_per_lane_x": "interp out, 0.5, in, 0.25",
+        "macw": "macw out, in, 1.5, 1.0", "macwn": "macwn out, in, 1.5, in", "macintw": "macintw out, in, 1.5, 1.0", "macmv": "macmv out, in, 0.5, 0.5",
+        "limit": "limit out, in, 0.5, 0.25", "limitn": "limitn out, in, 0.5, 0.25", "limit_nan_y": "limit out, 0.5, 0.25, in", "tstneg": "tstneg out, in, 0.25, 0",
+        "tstneg_x": "tstneg out, 0.5, in, 0", "andxor": "andxor out, in, 15, 3", "skip_on_nan": "macs a, in, 0, 0\nskip ccr, ccr, 0, 1\nmacs out, 0, 0.5, 0.5",
+        "delay": "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, rd, 0.5, 0.5", "feedback": "macs a, a, in, 0.5\nmacs out, 0, a, 1.0",
+        "chain": "macs a, in, vol, 0.75\nmacsn b, a, in, 0.5\nacc3 out, a, b, in",
+    }
+    out["nonfinite.json"] = [run_case(k, "itramsize 3 \n" + HDR + v + "\nend", nf, regs=("a", "b", "out", "ccr", "in", "rd")) for k, v in sorted(NONFINITE.items())]
+
+    # 6c. two or three NaN operands at once: which payload the x86 build hands on (SSE returns its FIRST operand's NaN, and
+    # which operand is first is the compiler's choice per expression) - pins the operand priority of every arithmetic opcode
+    import struct
+
+    def nanf(bits):
+        return struct.unpack("<f", struct.pack("<I", bits))[0]
+    PAY = {"a": 0x7fc00aaa, "b": 0xffc00bbb, "c": 0x7fc00ccc}
+    coll = []
+    for op in ("macs", "macsn", "macints", "acc3", "interp", "macw", "macwn", "macintw", "macmv", "limit", "limitn", "tstneg"):
+        for mask in range(1, 8):
+            who = [r for k, r in enumerate("abc") if mask & (1 << k)]
+            sets = {0: [(r, nanf(PAY[r])) for r in who]}
+            text = "static a = 0.5\nstatic b = 0.25\nstatic c = 0.125\ninput in 0\noutput out 0\n%s out, a, b, c\nend" % op
+            c = run_case("%s_%s" % (op, "".join(who)), text, np.array([0.5, 0.25], np.float32), regs=("out", "ccr", "a", "b", "c"), sets=sets)
+            c["sets_bits"] = {"0": [(r, PAY[r]) for r in who]}
+            coll.append(c)
+    out["nan_collisions.json"] = coll
 
     # 7. loader corpus
     corpus = []

@@ -200,10 +200,15 @@ def test_interp_uniform_x_sweep(gpu, k):
     check_batch(gpu, text, x, regs=tuple(regs) + ("a", "out", "ccr"))
 
 
-def same_with_nan(ref, got):
-    """bit-equal, except that any NaN matches any NaN (x86 and gfx950 differ in the default NaN's sign bit)"""
+def same_with_nan(ref, got, k="default"):
+    """Bit-equal INCLUDING NaN words (sign, payload, quiet bit) for the translated program and the HIP C++ kernel: they
+    order their sources like the x86 build of the reference and never negate a NaN (tests/golden/nan_collisions.json,
+    tools/micro/nanrules.hip).  The VGPR builds of the hand-written interpreter reach their register-file operand only as
+    src0, so where two NaNs meet in one instruction they may hand on the other one's payload: any NaN matches any NaN there."""
     ref = np.asarray(ref, dtype=np.float32).reshape(-1)
     got = np.asarray(got, dtype=np.float32).reshape(-1)
+    if not (isinstance(k, str) and k.startswith("asm")):
+        return np.array_equal(bits(ref), bits(got))
     rn, gn = np.isnan(ref), np.isnan(got)
     return np.array_equal(rn, gn) and np.array_equal(bits(ref)[~rn], bits(got)[~gn])
 
@@ -276,12 +281,13 @@ def test_non_finite_values_without_wrap_or_skip(gpu, k, case):
         if case == "inf_uniform":
             o.set_register("vol", float("inf"))
         ref = o.process_block(x[:, n].copy())
-        assert same_with_nan(ref, y[:, n]), "instance %d" % n
+        assert same_with_nan(ref, y[:, n], k), "instance %d" % n
         saw_nan = saw_nan or bool(np.isnan(ref).any())
         for r in ("a", "b", "t", "u", "w", "out"):
             rb, gb = o.get_register_bits(r), b.get_register_bits_i(r, n)
             rf, gf = np.array([rb], dtype=np.uint32).view(np.float32)[0], np.array([gb], dtype=np.uint32).view(np.float32)[0]
-            assert (np.isnan(rf) and np.isnan(gf)) or rb == gb, "instance %d register %s: ref %08x got %08x" % (n, r, rb, gb)
+            loose = isinstance(k, str) and k.startswith("asm")
+            assert rb == gb or (loose and np.isnan(rf) and np.isnan(gf)), "instance %d register %s: ref %08x got %08x" % (n, r, rb, gb)
         assert b.instruction_counter_i(n) == o.instruction_counter()
     if case in ("nan_input", "nan_state", "inf_uniform"):
         assert saw_nan
@@ -327,12 +333,13 @@ def test_non_finite_values_follow_the_reference(gpu, k, case):
             o.set_register("vol", float("inf"))
             o.set_register("big", float("inf"))
         ref = o.process_block(x[:, n].copy())
-        assert same_with_nan(ref, y[:, n]), "instance %d" % n
+        assert same_with_nan(ref, y[:, n], k), "instance %d" % n
         saw_nan = saw_nan or bool(np.isnan(ref).any())
         for r in ("a", "b", "t", "u", "w", "out"):
             rb, gb = o.get_register_bits(r), b.get_register_bits_i(r, n)
             rf, gf = np.array([rb], dtype=np.uint32).view(np.float32)[0], np.array([gb], dtype=np.uint32).view(np.float32)[0]
-            assert (np.isnan(rf) and np.isnan(gf)) or rb == gb, "instance %d register %s: ref %08x got %08x" % (n, r, rb, gb)
+            loose = isinstance(k, str) and k.startswith("asm")
+            assert rb == gb or (loose and np.isnan(rf) and np.isnan(gf)), "instance %d register %s: ref %08x got %08x" % (n, r, rb, gb)
     if case in ("nan_input", "overflow_in_macw", "nan_state", "inf_uniform"):
         assert saw_nan  # the case does exercise NaN through saturating instructions
 

@@ -32,6 +32,8 @@ def run_oracle(case, text=None):
         return o
     x = f32(case["input"], case["shape"])
     sets = {int(k): v for k, v in case.get("sets", {}).items()}
+    if "sets_bits" in case:  # values that JSON cannot carry (NaN payloads): IEEE bits
+        sets = {int(k): [(reg, float(np.array([b], dtype=np.uint32).view(np.float32)[0])) for reg, b in v] for k, v in case["sets_bits"].items()}
     if sets:
         cuts = sorted(set([0] + list(sets) + [x.shape[0]]))
         outs = []
@@ -51,7 +53,7 @@ def run_oracle(case, text=None):
     return o
 
 
-@pytest.mark.parametrize("fixture", ["opcodes.json", "known_answers.json", "slider.json", "feedback_delay.json"])
+@pytest.mark.parametrize("fixture", ["opcodes.json", "known_answers.json", "slider.json", "feedback_delay.json", "nonfinite.json", "nan_collisions.json"])
 def test_oracle_matches_reference_vectors(fixture):
     for case in load(fixture):
         o = run_oracle(case)
