@@ -2,6 +2,7 @@
 """bench.py — aggregate emulated DSP MIPS of the MI355X batch FX8010 interpreter.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config config5] [--samples S] [--instances M]
+                    [--sharded] [--no-extras] [--parity-instances P]
 
 One "step" = one pass of the hot path over one batch of synthetic PCM: fxb_process_block_dev()
 for S sample periods on this rank's M instances (inputs already resident in HBM).  The default
@@ -13,8 +14,15 @@ other single-GPU configurations with their BASELINE.json instance counts.
 
 For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU); ranks
 only meet in the barriers around the timed region and in the MAX-reduction of the elapsed time.
+`--sharded` instead drives all N GPUs from ONE process through the library's own multi-device
+handle (fxb_create_sharded: one host thread + stream per device).
 
-Output: ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+Output: ONE JSON line (rank 0) with the contract fields plus
+  roofline      HBM roofline of the kernel (algorithmic bytes / HIP-event kernel time / 8 TB/s), and next to it
+                roofline.valu: the vector-ALU issue roofline that actually bounds this path
+  cpu_baseline  the unmodified reference (oracle/_ref) timed on this box's host cores (N = 1 only)
+  parity        instances of the timed run compared bit for bit with the CPU oracle after the timed region
+  extra         (N = 1, default workload only) the other single-GPU configurations and all of configs[4] on one GPU
 """
 import argparse
 import json
@@ -28,18 +36,22 @@ for p in (os.path.join(ROOT, "fx8010-emulator-core_amd", "python"), os.path.join
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+SIMDS = 1024           # 256 CUs x 4 SIMD-32
+MAX_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md: max clock; a wave64 VALU instruction takes 2 cycles of a SIMD
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5", "tram_bound"])
     ap.add_argument("--samples", type=int, default=4096, help="sample periods per step (block length S; SURVEY 8d: 4096)")
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (0 = BASELINE.json's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only); 0 disables")
-    ap.add_argument("--extra-configs", action="store_true", help="also report untimed single-launch MIPS of the other configs")
+    ap.add_argument("--parity-instances", type=int, default=1024, help="instances checked against the oracle after the timed region (0 disables)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configurations (they run by default for N=1, default workload)")
+    ap.add_argument("--sharded", action="store_true", help="one process, --gpus devices through fxb_create_sharded")
     return ap.parse_args()
 
 
@@ -49,8 +61,9 @@ def device_stimulus(torch, n_inst, n_samples, first_instance, device):
     M = 0xFFFFFFFF
     out = torch.empty((n_samples, n_inst), dtype=torch.float32, device=device)
     n = (torch.arange(n_inst, dtype=torch.int64, device=device) + first_instance)[None, :] * 0x9E3779B1 + 0xF8010
-    for s0 in range(0, n_samples, 256):
-        s1 = min(n_samples, s0 + 256)
+    slab = max(8, min(256, (1 << 26) // max(n_inst, 1)))
+    for s0 in range(0, n_samples, slab):
+        s1 = min(n_samples, s0 + slab)
         s = torch.arange(s0, s1, dtype=torch.int64, device=device)[:, None]
         x = (n + s * 0x85EBCA77) & M
         x = x ^ (x >> 16)
@@ -77,26 +90,25 @@ def usable_cores():
 
 
 def measured_traffic(config, n_inst, n_samples):
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/*hbm_traffic*.json: FETCH_SIZE and
-    WRITE_SIZE in their own passes, gfx950 read correction applied) when one exists for exactly this workload."""
+    """HBM bytes per launch from a COMMITTED rocprofv3 PMC pass (profiles/*hbm_traffic*.json: FETCH_SIZE and WRITE_SIZE in
+    their own passes, gfx950 read correction applied) of exactly this workload - a constant read from that file, not a
+    measurement of this run (counters cannot be collected from inside the timed process); its name goes into the line."""
     import glob
 
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
         try:
             d = json.load(open(f))
             w = d["workload"]
             if w["config"] == config and w["instances"] == n_inst and w["samples"] == n_samples:
-                return float(d["hbm_bytes_per_launch"])
+                return float(d["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, None
 
 
 def cpu_baseline(text, budget_s):
     """Time the reference (or, without oracle/_ref, the C port) on the host cores: bounded sample."""
     import tempfile
-
-    import numpy as np
 
     import fx8010_programs as progs
     from pyoracle import Oracle, Reference
@@ -126,6 +138,188 @@ def cpu_baseline(text, budget_s):
         os.unlink(path)
 
 
+def parity_check(text, y_last, n_inst, first_instance, n_samples, blocks, want):
+    """After the timed region: `want` instances spread over the shard (plus lanes 0 / 63 / the last one) are replayed on the
+    CPU oracle - all `blocks` launches of the run, state carried from block to block as on the device - and the device's
+    output of the LAST block is compared bit for bit.  y_last: callable instance -> numpy [S] of the device output."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    import fx8010_programs as progs
+    from pyoracle import Oracle
+
+    if want <= 0:
+        return None
+    picks = sorted(set([0, min(63, n_inst - 1), n_inst - 1] + [int(i) for i in np.linspace(0, n_inst - 1, num=min(want, n_inst))]))
+    t0 = time.perf_counter()
+
+    def one(n):
+        o = Oracle(1)
+        if not o.load_text(text):
+            return n, False
+        x = progs.stimulus(1, n_samples, first_instance=first_instance + n)[:, 0].copy()
+        ref = None
+        for _ in range(blocks):
+            ref = o.process_block(x)
+        got = y_last(n)
+        return n, bool(np.array_equal(ref.view(np.uint32), np.ascontiguousarray(got).view(np.uint32)))
+
+    with ThreadPoolExecutor(max_workers=usable_cores()) as pool:  # the oracle calls release the GIL
+        results = list(pool.map(one, picks))
+    bad = [n for n, ok in results if not ok]
+    return {"parity_checked": len(picks), "parity_ok": not bad, "mismatching_instances": bad[:8],
+            "what": "device output of the last timed block vs oracle/ (C restatement of the reference), bit for bit, after replaying all %d blocks" % blocks,
+            "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def kernel_name(batch):
+    kid = batch.info("kernel")
+    vg = (0, 0, 64, 72, 80, 96, 128, 168, 256)
+    if kid == 0:
+        return "fx_step_block (HIP C++)"
+    if kid == 1:
+        return "fx_interp_lds (gfx950 asm interpreter, LDS register file)"
+    if kid <= 8:
+        return "fx_interp_v%d (gfx950 asm interpreter, VGPR register file)" % vg[kid]
+    return ("fx_xlate_v%d (program translated to gfx950 code: %d records inline, %d handler calls, %d saturations elided, %d code bytes)"
+            % (vg[kid - 7], batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_unsaturated"), batch.info("xlate_code_bytes")))
+
+
+def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warmup, devices, rank, dist, reduce_dev, parity_n):
+    """One configuration on this process's device(s).  Returns (fields for the JSON line, batch text)."""
+    text = progs.CONFIGS[config]()
+    P = progs.count_instructions(text)
+    sharded = len(devices) > 1
+    batch = fx8010_amd.Batch(n_inst * len(devices), 1, devices=devices) if sharded else fx8010_amd.Batch(n_inst, 1, devices[0])
+    if not batch.load_text(text):
+        raise RuntimeError("program failed to load: %s" % batch.errors())
+    first_instance, _ = shard.weak_shard(n_inst, rank)  # weak scaling: every GPU owns n_inst instances
+    xs, ys, streams = [], [], []
+    for k, (dev_ord, first, count) in enumerate(batch.shards()):
+        dev = torch.device("cuda", dev_ord)
+        with torch.cuda.device(dev):
+            xs.append(device_stimulus(torch, count, S, first_instance + first, dev))  # [S, N_k] resident in HBM
+            ys.append(torch.empty_like(xs[-1]))
+    for d in devices:
+        torch.cuda.synchronize(d)
+    # a non-default torch stream: the kernel is launched on it through the C ABI, so the
+    # torch.cuda.Events below (HIP events on that same stream) bracket exactly the launches
+    dev0 = torch.device("cuda", devices[0])
+    tstream = torch.cuda.Stream(device=dev0)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
+
+    def step():
+        if sharded:
+            batch.process_block_dev_shards([t.data_ptr() for t in xs], [t.data_ptr() for t in ys], S)
+        else:
+            batch.process_block_dev(xs[0].data_ptr(), ys[0].data_ptr(), S, stream)
+
+    def barrier():
+        if sharded:
+            batch.sync()
+        if dist is not None:
+            dist.barrier()
+        for d in devices:
+            torch.cuda.synchronize(d)
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    c0 = batch.instruction_counter()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    # HIP events on the launch stream (single device); a sharded batch launches from its own threads on its own
+    # streams: the slowest shard's last launch, measured by the library's events on that stream
+    kernel_ms = batch.last_kernel_ms() if sharded else ev0.elapsed_time(ev1) / max(steps, 1)
+    last_ms = batch.last_kernel_ms()
+    executed = batch.instruction_counter() - c0  # reference counting: END/SKIP count, skipped don't
+    ood = batch.ood_flags()
+    elapsed = shard.reduce_scalar(dist, elapsed, "max", reduce_dev)        # slowest rank
+    executed_all = shard.reduce_scalar(dist, executed, "sum", reduce_dev)  # whole job
+
+    parity = None
+    if rank == 0 and parity_n > 0:
+        cuts = [(f, c) for _, f, c in batch.shards()]
+
+        def y_last(n):
+            for k, (f, c) in enumerate(cuts):
+                if f <= n < f + c:
+                    return ys[k][:, n - f].cpu().numpy()
+            raise IndexError(n)
+
+        parity = parity_check(text, y_last, n_inst * len(devices), first_instance, S, warmup + steps, parity_n)
+
+    res = None
+    if rank == 0:
+        n_dev = len(devices)
+        mips = executed_all / elapsed / 1e6
+        tram_ops = batch.info("tram_ops")
+        rows = batch.info("num_rows")
+        # algorithmic HBM bytes of ONE launch on ONE GPU (SURVEY.md section 8d): PCM in+out, every executed
+        # TRAM read/write, and the once-per-block register-file spill/fill
+        bytes_per_inst_sample = 4 * (1 + 1) + 4 * tram_ops
+        algo_bytes = float(n_inst) * (S * bytes_per_inst_sample + 2 * 4 * (rows + 9))
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(config, n_inst, S)
+        valu_per_wave_sample = batch.info("xlate_valu")
+        waves = (n_inst + 63) // 64
+        valu = None
+        if valu_per_wave_sample > 0:
+            per_s = valu_per_wave_sample * waves * S / (kernel_ms * 1e-3)
+            peak = SIMDS * MAX_CLOCK_HZ / 2.0
+            valu = {"bound": "valu issue", "achieved": round(per_s / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
+                    "frac": round(per_s / peak, 4), "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves / float(SIMDS), 3),
+                    "valu_per_emulated_instr": round(valu_per_wave_sample / max(executed / float(steps * S * n_inst * n_dev), 1e-9), 3),
+                    "note": "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction; the chip holds a lower clock under this load (DVFS), "
+                            "and below 2 wavefronts per SIMD one wavefront issues only every 4th cycle (DESIGN.md section 5)"}
+        res = {
+            "value": round(mips, 1),
+            "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 4),
+            "config": {
+                "workload": "%s: %d instances/GPU x %d-instr program, block of %d samples, mono 48 kHz" % (config, n_inst, P, S),
+                "instances_total": n_inst * max(n_dev, 1) * (dist.get_world_size() if dist is not None else 1),
+                "instr_per_sample_static": P,
+                "instr_per_sample_executed": round(executed / float(steps * S * n_inst * n_dev), 3),
+                "tram_ops_per_sample": tram_ops,
+                "lane_register_rows": rows,
+                "parity_domain_flags": ood,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
+                "kernel": kernel_name(batch),
+                "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_last_launch": round(last_ms, 4),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "note": "the interpreter is instruction-issue bound (>= 12 emulated instr per algorithmic HBM byte): see roofline.valu and DESIGN.md section 5",
+                "emulated_instr_per_s_per_gpu": round(executed / n_dev / (kernel_ms * 1e-3 * steps), 1),
+                "valu": valu,
+            },
+        }
+        if parity is not None:
+            res["parity"] = parity
+    torch.cuda.set_stream(torch.cuda.default_stream(dev0))
+    del batch, xs, ys
+    torch.cuda.empty_cache()
+    return res, text
+
+
 def main():
     args = parse()
     import torch  # first: its HIP runtime is the one the library binds to in this process
@@ -141,122 +335,70 @@ def main():
     # rehearsal on a box with fewer GPUs than ranks (FX_BENCH_REHEARSAL=1): ranks share the devices round-robin and
     # meet over gloo instead of RCCL, which refuses two ranks on one device - same code path otherwise
     rehearsal = os.environ.get("FX_BENCH_REHEARSAL") == "1"
+    n_visible = max(torch.cuda.device_count(), 1)
     if rehearsal:
-        local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = shard.init_process_group("gloo" if rehearsal else "nccl", dev)  # RCCL; None for a single process
-    reduce_dev = "cpu" if rehearsal else dev
+        local = local % n_visible
+    if args.sharded:
+        if world != 1:
+            raise SystemExit("--sharded drives all devices from one process: do not launch it under torch.distributed.run")
+        devices = [d % n_visible for d in range(args.gpus)] if rehearsal else list(range(args.gpus))
+        dist, reduce_dev = None, "cpu"
+        torch.cuda.set_device(devices[0])
+    else:
+        torch.cuda.set_device(local)
+        devices = [local]
+        dev = torch.device("cuda", local)
+        dist = shard.init_process_group("gloo" if rehearsal else "nccl", dev)  # RCCL; None for a single process
+        reduce_dev = "cpu" if rehearsal else dev
 
-    text = progs.CONFIGS[args.config]()
     n_inst = args.instances or progs.CONFIG_INSTANCES[args.config]
     S = args.samples
-    P = progs.count_instructions(text)
-
-    batch = fx8010_amd.Batch(n_inst, 1, local)
-    if not batch.load_text(text):
-        raise RuntimeError("program failed to load: %s" % batch.errors())
-    first_instance, _ = shard.weak_shard(n_inst, rank)  # weak scaling: every GPU owns n_inst instances
-    x = device_stimulus(torch, n_inst, S, first_instance, dev)  # [S, N] resident in HBM
-    y = torch.empty_like(x)
-    torch.cuda.synchronize()
-    # a non-default torch stream: the kernel is launched on it through the C ABI, so the
-    # torch.cuda.Events below (HIP events on that same stream) bracket exactly the launches
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    assert stream != 0
-
-    def step():
-        batch.process_block_dev(x.data_ptr(), y.data_ptr(), S, stream)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    c0 = batch.instruction_counter()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # HIP events on the launch stream
-    last_ms = batch.last_kernel_ms()
-    executed = batch.instruction_counter() - c0  # reference counting: END/SKIP count, skipped don't
-    ood = batch.ood_flags()
-
-    elapsed = shard.reduce_scalar(dist, elapsed, "max", reduce_dev)            # slowest rank
-    executed_all = shard.reduce_scalar(dist, executed, "sum", reduce_dev)      # whole job
+    res, text = run_workload(torch, fx8010_amd, progs, shard, args.config, n_inst, S, args.steps, args.warmup, devices, rank, dist, reduce_dev,
+                             args.parity_instances)
+    n_gpus = args.gpus if args.sharded else world
 
     if rank == 0:
-        mips = executed_all / elapsed / 1e6
-        tram_ops = batch.info("tram_ops")
-        rows = batch.info("num_rows")
-        kid = batch.info("kernel")
-        vg = (0, 0, 64, 72, 80, 96, 128, 168, 256)
-        if kid == 0:
-            kernel_kind = "fx_step_block (HIP C++)"
-        elif kid == 1:
-            kernel_kind = "fx_interp_lds (gfx950 asm interpreter, LDS register file)"
-        elif kid <= 8:
-            kernel_kind = "fx_interp_v%d (gfx950 asm interpreter, VGPR register file)" % vg[kid]
-        else:
-            kernel_kind = ("fx_xlate_v%d (program translated to gfx950 code: %d records inline, %d handler calls, %d saturations elided, %d code bytes)"
-                           % (vg[kid - 7],
-                              batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_unsaturated"), batch.info("xlate_code_bytes")))
-        # algorithmic HBM bytes of ONE launch on ONE GPU: PCM in+out, every executed
-        # TRAM read/write, and the once-per-block register-file spill/fill
-        bytes_per_inst_sample = 4 * (1 + 1) + 4 * tram_ops
-        algo_bytes = float(n_inst) * (S * bytes_per_inst_sample + 2 * 4 * (rows + 9))
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "aggregate emulated DSP MIPS (instr x samples x instances / s)",
-            "value": round(mips, 1),
+            "value": res["value"],
             "unit": "MIPS",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32+f64",  # the path computes in IEEE fp32 with fp64 for INTERP / LOG / EXP, as the reference does
             "data": "synthetic",
-            "config": {
-                "workload": "%s: %d instances/GPU x %d-instr program, block of %d samples, mono 48 kHz" % (args.config, n_inst, P, S),
-                "instances_total": n_inst * world,
-                "instr_per_sample_static": P,
-                "instr_per_sample_executed": round(executed / float(args.steps * S * n_inst), 3),
-                "tram_ops_per_sample": tram_ops,
-                "lane_register_rows": rows,
-                "parity_domain_flags": ood,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": measured_traffic(args.config, n_inst, S),
-                "kernel": kernel_kind,
-                "kernel_ms": round(kernel_ms, 4),
-                "kernel_ms_last_launch": round(last_ms, 4),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "the interpreter is instruction-issue bound (>= 12 emulated instr per algorithmic HBM byte); see DESIGN.md section 5",
-                "emulated_instr_per_s_per_gpu": round(executed / (kernel_ms * 1e-3 * args.steps), 1),
-            },
+            "config": res["config"],
+            "roofline": res["roofline"],
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if args.sharded:
+            out["config"]["host"] = "one process, fxb_create_sharded over %d devices (one host thread + stream each)" % len(devices)
+        if "parity" in res:
+            out["parity"] = res["parity"]
+        single = n_gpus == 1
+        if single and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(text, args.cpu_seconds)
+        if single and not args.no_extras and args.config == "config5" and not args.instances and S == 4096:
+            # the other single-GPU configurations of BASELINE.json at their instance counts, and ALL of configs[4]
+            # (2 097 152 instances, 64 GiB of xTRAM) on this one GPU; fewer launches each, same block length
+            extra = {}
+            plan = [("config2", 4096, 10, 256), ("config3", 65536, 10, 256), ("config4", 262144, 6, 256), ("config5_full_1gpu", 2097152, 4, 64)]
+            for name, n, k, pn in plan:
+                cfg = "config5" if name.startswith("config5") else name
+                try:
+                    r, _ = run_workload(torch, fx8010_amd, progs, shard, cfg, n, S, k, 1, devices, 0, None, "cpu", pn)
+                    extra[name] = {"value": r["value"], "unit": "MIPS", "steps": k, "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                                   "instr_per_sample_executed": r["config"]["instr_per_sample_executed"],
+                                   "kernel_ms": r["roofline"]["kernel_ms"], "hbm_frac": r["roofline"]["frac"],
+                                   "valu_frac": (r["roofline"]["valu"] or {}).get("frac"), "waves_per_simd": (r["roofline"]["valu"] or {}).get("waves_per_simd"),
+                                   "valu_per_emulated_instr": (r["roofline"]["valu"] or {}).get("valu_per_emulated_instr"),
+                                   "parity_checked": (r.get("parity") or {}).get("parity_checked"), "parity_ok": (r.get("parity") or {}).get("parity_ok")}
+                except Exception as e:  # an extra must never take the headline line down
+                    extra[name] = {"error": str(e)[:200]}
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -311,6 +311,7 @@ int Batch::ensureLowered() {
             xlateUnsaturated_ = image.steady.unsaturated;
             xlateInlined_ = image.steady.inlined;
             xlateCalled_ = image.steady.called;
+            xlateValu_ = image.steady.valu;
             useXlate_ = true;
         }
     }
@@ -628,6 +629,7 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_INLINED: return useXlate_ ? xlateInlined_ : 0;
         case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;
         case FXB_INFO_XLATE_UNSATURATED: return useXlate_ ? xlateUnsaturated_ : 0;
+        case FXB_INFO_XLATE_VALU: return useXlate_ ? xlateValu_ : 0;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
         case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? 0 : (int64_t)low_.nRows * 256 * instPerLane_;

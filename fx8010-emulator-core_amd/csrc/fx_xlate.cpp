@@ -173,6 +173,10 @@ class Emitter {
 
     size_t bytes() const { return w_.size() * 4; }
     int count() const { return count_; }
+    // vector-ALU instructions on the path a finite, in-domain wave takes every sample (cold(true) brackets code that
+    // such a wave does not execute: entry stubs, out-of-range paths, the second LUT trip)
+    int valu() const { return valu_; }
+    void cold(bool on) { cold_ = on; }
     // the listing is kept as lines until the stream is complete (forward branches are patched in place)
     void finish() {
         if (!text_) return;
@@ -215,19 +219,23 @@ class Emitter {
     }
 
     void vop2(uint32_t op, const char* name, int vdst, const Src& src0, int vsrc1, const char* tail = "") {
+        tally();
         put((op << 25) | ((uint32_t)vdst << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
         if (text_) line(std::string(name) + " v" + std::to_string(vdst) + ", " + src0.text + ", v" + std::to_string(vsrc1) + tail);
     }
     void vop1(uint32_t op, const char* name, const Src& vdst, const Src& src0) {
+        tally();
         put(0x7e000000u | ((vdst.code & 0xffu) << 17) | (op << 9) | src0.code, src0);
         if (text_) line(std::string(name) + " " + vdst.text + ", " + src0.text);
     }
     void vopc(uint32_t op, const char* name, const Src& src0, int vsrc1) {
+        tally();
         put(0x7c000000u | (op << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
         if (text_) line(std::string(name) + " vcc, " + src0.text + ", v" + std::to_string(vsrc1));
     }
     // VOP3A: no literals on gfx9; neg = per-source negate bits
     void vop3(uint32_t op, const char* name, const Src& vdst, const Src& s0, const Src& s1, const Src* s2, uint32_t neg = 0) {
+        tally();
         w_.push_back(0xd0000000u | (op << 16) | (vdst.code & 0xffu));
         w_.push_back(s0.code | (s1.code << 9) | ((s2 ? s2->code : 0u) << 18) | (neg << 29));
         ++count_;
@@ -238,6 +246,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form, result to VCC, |src0| when abs0
     void vop3cmp(uint32_t op, const char* name, const Src& s0, bool abs0, const Src& s1) {
+        tally();
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | 106u);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -307,12 +316,14 @@ class Emitter {
     }
     // v = v + carry (VCC in and out)
     void addCarry(int v) {
+        tally();
         w_.push_back((VOP2_ADDC_OP << 25) | ((uint32_t)v << 17) | ((uint32_t)v << 9) | 128u);
         ++count_;
         if (text_) line("v_addc_co_u32_e32 v" + std::to_string(v) + ", vcc, 0, v" + std::to_string(v) + ", vcc");
     }
     // v = v - borrow, borrow in from the SGPR pair `sin`, borrow out to the pair `sout`
     void subBorrow(int v, int sin, int sout) {
+        tally();
         w_.push_back(0xd0000000u | (0x11eu << 16) | ((uint32_t)sout << 8) | (uint32_t)v);
         w_.push_back(128u | ((256u + (uint32_t)v) << 9) | ((uint32_t)sin << 18));
         ++count_;
@@ -326,6 +337,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
     void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
+        tally();
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | (sdst.code & 0xffu));
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -333,6 +345,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form with an SGPR-pair destination
     void vop3cmpTo(uint32_t op, const char* name, int sdst, const Src& s0, const Src& s1) {
+        tally();
         w_.push_back(0xd0000000u | (op << 16) | (uint32_t)sdst);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -364,7 +377,9 @@ class Emitter {
     std::vector<uint32_t>& w_;
     std::string* text_;
     std::vector<std::string> lines_;
-    int count_ = 0;
+    int count_ = 0, valu_ = 0;
+    bool cold_ = false;
+    void tally() { if (!cold_) ++valu_; }
 };
 
 // gfx950 opcodes used (checked against llvm-mc by tests/test_xlate.py, which re-assembles the listing)
@@ -451,9 +466,11 @@ class Translator {
             // a launch whose cursor distance rules the early issue out)
             e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSPrefetched), imm32(1));
             Emitter::Fixup toHot = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
+            e_.cold(true);
             for (int k = 0; k < H.leadCount; ++k)
                 if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false)) { if (err) *err = err_; return false; }
             e_.waitVmcnt(0);
+            e_.cold(false);
             Emitter::Fixup toJoin = e_.branchForward(SOPP_BRANCH, "s_branch");
             e_.bind(toHot);
             e_.waitVmcnt(H.vmemAfterHoist + storesPerSample);  // younger than the reads: the rest of that sample's TRAM traffic and its PCM stores
@@ -530,6 +547,7 @@ class Translator {
         }
 
         // ---- cold entry (from the template): scalar copies of what the loop keeps in SGPRs
+        e_.cold(true);
         if (coldEntry) *coldEntry = base_ + (uint32_t)e_.bytes();
         if (prog_.uniformCursors) {
             // every TRAM instruction runs on all lanes: the four cursors are the same in every lane, keep them in SGPRs
@@ -545,7 +563,7 @@ class Translator {
         if (!e_.branchBack(SOPP_BRANCH, "s_branch", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
         e_.finish();
         if (returns) *returns = returns_;
-        if (stats) { *stats = stats_; stats->instructions = e_.count(); stats->nonFiniteImmediate = nonFinite_; }
+        if (stats) { *stats = stats_; stats->instructions = e_.count(); stats->valu = e_.valu(); stats->nonFiniteImmediate = nonFinite_; }
         return true;
     }
 
@@ -700,11 +718,13 @@ class Translator {
         e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTemp + 2), imm32(0));
         Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
         // (two instructions lie between the VALU writes of VCC / the SGPR pair and the VALU reads below)
+        e_.cold(true);
         e_.addCarry(6);
         e_.subBorrow(6, kSTemp, kSTemp + 2);
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
         fetchSegment(false);
         if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
+        e_.cold(false);
         e_.bind(hit);
         if (guarded) {
             // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it.  The two
@@ -788,7 +808,9 @@ class Translator {
         Emitter::Fixup done = e_.branchForward(SOPP_BRANCH, "s_branch");
         e_.bind(outside);
         e_.waitVmcnt(0);
+        e_.cold(true);
         e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+        e_.cold(false);
         e_.bind(done);
         if (deferred) pending_.push_back(vR);
         advanceCursor(cursor, t);

@@ -75,6 +75,7 @@ struct XlateStats {
     int inlined = 0;     // records translated to straight-line code
     int called = 0;      // records executed by a call to the interpreter's handler
     int instructions = 0;
+    int valu = 0;        // vector-ALU instructions a finite, in-domain wave executes per sample period
     int fusedSkips = 0;  // SKIPs translated as a predicate on the value that would have set their CCR
     int regions = 0;     // SKIP shadows run under one EXEC mask (no per-instruction PRED)
     int unitMultipliers = 0;  // multiplications by +-1.0 that were not emitted

@@ -173,7 +173,8 @@ enum {
     FXB_INFO_XLATE_CODE_BYTES = 18,/* translated program: bytes of machine code (both streams), else 0 */
     FXB_INFO_XLATE_INLINED = 19,   /* records of the steady stream turned into straight-line code */
     FXB_INFO_XLATE_CALLED = 20,    /* records of the steady stream that call an interpreter handler */
-    FXB_INFO_XLATE_UNSATURATED = 21 /* saturating instructions translated without a saturation (result provably in [-1, 1]) */
+    FXB_INFO_XLATE_UNSATURATED = 21,/* saturating instructions translated without a saturation (result provably in [-1, 1]) */
+    FXB_INFO_XLATE_VALU = 22        /* translated program: vector-ALU instructions per wavefront and sample period (steady fast stream) */
 };
 int64_t fxb_info(fxb_handle* h, int what);
 
