@@ -35,6 +35,7 @@ struct AsmArgs {
     int oodRow, countLo, countHi, staticCount;
     int lutX1Off;
     int initOff;  // translated programs: byte offset (from the kernel entry) of code to run once before the first sample, 0 = none
+    const uint32_t* tracks;  // translated programs with control tracks: TrackHeader[kMaxTracks] + values (fx_xlate.hpp), else nullptr
 };
 static_assert(offsetof(AsmArgs, lut) == 0x40, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, nLoad) == 0x58, "AsmArgs layout");
@@ -45,7 +46,8 @@ static_assert(offsetof(AsmArgs, iSlots) == 0x88, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, cursorRow) == 0x98, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, oodRow) == 0xa0, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, lutX1Off) == 0xb0, "AsmArgs layout");
-static_assert(sizeof(AsmArgs) == 0xb8, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, tracks) == 0xb8, "AsmArgs layout");
+static_assert(sizeof(AsmArgs) == 0xc0, "AsmArgs layout");
 
 // handler slots of fx_interp_gfx950.S (fx_interp_table.inc)
 enum AsmSlot : uint32_t {

@@ -65,6 +65,7 @@ Batch::~Batch() {
     (void)hipFree(dLut_);
     (void)hipFree(dStream_);
     (void)hipFree(dScratch_);
+    (void)hipFree(dTracks_);
     (void)hipFree(dIn_);
     (void)hipFree(dOut_);
     if (xlateModule_) (void)hipModuleUnload(xlateModule_);
@@ -199,7 +200,7 @@ int Batch::chooseInstPerLane() const {
         const int k = std::atoi(env);
         if (k == 1 || k == 2 || k == 4) return k;
     }
-    const Lowered probe = lowerProgram(prog_, hostValue_, forcedLane_, 1);
+    const Lowered probe = lowerProgram(prog_, hostValue_, laneForced(), 1);
     if (!probe.error.empty()) return 1;
     for (int k : {4, 2}) {
         const long long waves = (n_ + 64LL * k - 1) / (64LL * k);
@@ -212,7 +213,7 @@ int Batch::chooseInstPerLane() const {
 bool Batch::intrinsicLane(int reg) const { return reg >= 0 && (size_t)reg < intrinsicLane_.size() && intrinsicLane_[reg] != 0; }
 
 bool Batch::laneResident(int reg) const {
-    if (reg < (int)forcedLane_.size() && forcedLane_[reg]) return true;
+    if ((reg < (int)forcedLane_.size() && forcedLane_[reg]) || tracked(reg)) return true;
     return !lowDirty_ ? low_.rowOfReg[reg] >= 0 : (reg < (int)low_.rowOfReg.size() && low_.rowOfReg[reg] >= 0);
 }
 
@@ -231,7 +232,7 @@ int Batch::ensureLowered() {
         // first choice: register file in VGPRs (row pitch 1 = plain indices), else in LDS
         const bool tryVgpr = !(forceHip && std::strcmp(forceHip, "asm_lds") == 0);
         if (tryVgpr) {
-            fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false, 1);
+            fresh = lowerProgram(prog_, hostValue_, laneForced(), 1, false, 1);
             asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
             if (asmOk) {
                 // smallest VGPR build that holds the register file = most wavefronts per SIMD
@@ -248,14 +249,14 @@ int Batch::ensureLowered() {
             }
         }
         if (!asmOk) {
-            fresh = lowerProgram(prog_, hostValue_, forcedLane_, 1, false);
+            fresh = lowerProgram(prog_, hostValue_, laneForced(), 1, false);
             asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
             asmVariant_ = ASM_LDS;
         }
     } else {
         asmWhyNot_ = "disabled by FX_KERNEL / FX_INST_PER_LANE";
     }
-    if (!asmOk) fresh = lowerProgram(prog_, hostValue_, forcedLane_, chooseInstPerLane());
+    if (!asmOk) fresh = lowerProgram(prog_, hostValue_, laneForced(), chooseInstPerLane());
     if (!fresh.error.empty()) return fail(FX_E_PROGRAM, fresh.error);
     instPerLane_ = fresh.instPerLane;
     useAsm_ = asmOk;
@@ -265,13 +266,13 @@ int Batch::ensureLowered() {
     std::vector<uint32_t> rows, values;
     for (size_t r = 0; r < fresh.rowOfReg.size(); ++r) {
         const bool was = r < before.size() && before[r] >= 0;
-        const bool forced = forcedLane_[r] != 0;  // already seeded when it was forced
+        const bool forced = forcedLane_[r] != 0 || tracked((int)r);  // already seeded (every register's state row is kept valid)
         if (fresh.rowOfReg[r] >= 0 && !was && !forced) { rows.push_back((uint32_t)r); values.push_back(bitsOf(hostValue_[r])); }
     }
     low_ = std::move(fresh);
     // registers the program itself keeps per-instance (it writes them): a static property, valid until the next load
     intrinsicLane_.assign(low_.rowOfReg.size(), 0);
-    for (size_t r = 0; r < low_.rowOfReg.size(); ++r) intrinsicLane_[r] = low_.rowOfReg[r] >= 0 && !forcedLane_[r];
+    for (size_t r = 0; r < low_.rowOfReg.size(); ++r) intrinsicLane_[r] = low_.rowOfReg[r] >= 0 && !forcedLane_[r] && !tracked((int)r);
     if (!rows.empty() && (rc = fillRows(rows, values)) != 0) return rc;
     if ((rc = ensureTram()) != 0) return rc;
 
@@ -288,7 +289,9 @@ int Batch::ensureLowered() {
     } else if (useAsm_ && asmVariant_ != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
         // first choice for a VGPR build: translate the program into gfx950 code (FX_KERNEL=asm* pins the interpreter)
         const std::vector<MicroOp> steadyRecords = encodeAsmStream(low_.steady, nullptr, true), lastRecords = encodeAsmStream(low_.last, nullptr, true);
-        XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow, low_.latchRow);
+        std::vector<int> trackRows;
+        for (int reg : trackRegs_) trackRows.push_back(low_.rowOfReg[(size_t)reg]);
+        XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow, low_.latchRow, trackRows);
         XlateImage image;
         const XlateTemplate* tmpl = nullptr;
         bool built = false;
@@ -357,8 +360,10 @@ int Batch::setRegister(const std::string& key, float v) {
     if (r < 0) return 1;
     hostValue_[r] = v;
     forcedLane_[r] = 0;  // every instance holds the same value again
-    lowDirty_ = true;    // immediates (and possibly the classification) change
-    if (loaded_ && everLowered_) controlHeat_ = kHeatPerChange;
+    if (!tracked(r)) {   // (a trackable register lives in its row whatever happens: nothing to re-lower)
+        lowDirty_ = true;    // immediates (and possibly the classification) change
+        if (loaded_ && everLowered_) controlHeat_ = kHeatPerChange;
+    }
     if (dState_) {
         // Invariant: the state row of EVERY register holds its current value for every instance, also while the
         // register is uniform (folded into the code) - so that a later per-instance write only has to force the
@@ -437,6 +442,116 @@ int Batch::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
     return e == hipSuccess ? 0 : hipFail(e, "seedNoiseAt");
 }
 
+bool Batch::tracked(int reg) const { return std::find(trackRegs_.begin(), trackRegs_.end(), reg) != trackRegs_.end(); }
+
+std::vector<uint8_t> Batch::laneForced() const {
+    std::vector<uint8_t> f = forcedLane_;
+    for (int reg : trackRegs_)
+        if ((size_t)reg < f.size()) f[(size_t)reg] = 1;
+    return f;
+}
+
+int Batch::setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance, int64_t pitch) {
+    (void)hipSetDevice(device_);
+    const int r = prog_.findRegister(key);
+    if (r < 0) return 1;
+    if (!values || nSteps < 1 || period < 1) return fail(FX_E_ARG, "track: values, n_steps >= 1 and period >= 1 are required");
+    if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
+    if (pitch <= 0) pitch = n_;
+    if (perInstance && pitch < n_) return fail(FX_E_ARG, "track: pitch below the instance count");
+    size_t slot = 0;
+    while (slot < trackRegs_.size() && trackRegs_[slot] != r) ++slot;
+    if (slot == trackRegs_.size()) {
+        if (trackRegs_.size() >= (size_t)kMaxTracks) return fail(FX_E_ARG, "track: at most " + std::to_string(kMaxTracks) + " registers can have schedules");
+        trackRegs_.push_back(r);
+        pendingTracks_.resize(trackRegs_.size());
+        lowDirty_ = true;  // the register gets a row of its own and the generated loop the code to re-load it
+    }
+    PendingTrack& t = pendingTracks_[slot];
+    t.period = period;
+    t.steps = nSteps;
+    t.perInstance = perInstance;
+    if (perInstance) {
+        t.values.resize((size_t)nSteps * (size_t)n_);
+        for (int k = 0; k < nSteps; ++k) std::memcpy(&t.values[(size_t)k * (size_t)n_], values + (size_t)k * (size_t)pitch, (size_t)n_ * 4);
+    } else {
+        t.values.assign(values, values + nSteps);
+    }
+    return 0;
+}
+
+// header + values of the armed schedules -> dTracks_ (on the launch stream, ahead of the kernel); the schedules are one-shot
+int Batch::uploadTracks(int nSamples, hipStream_t s) {
+    if (!tracksArmed() && tracksClear_ && dTracks_) return 0;  // nothing armed and the device header already says so
+    const size_t headerWords = (size_t)kMaxTracks * 4;
+    size_t words = headerWords;
+    for (const PendingTrack& t : pendingTracks_)
+        if (t.steps > 0) words += t.perInstance ? (size_t)t.steps * (size_t)nPad_ : (size_t)t.steps;
+    if (words * 4 > tracksCap_) {
+        waitLastLaunch();
+        (void)hipFree(dTracks_);
+        dTracks_ = nullptr;
+        tracksCap_ = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dTracks_), words * 4 + 256);
+        if (e != hipSuccess) return hipFail(e, "hipMalloc tracks");
+        tracksCap_ = words * 4 + 256;
+    }
+    waitLastLaunch();  // trackStage_ / dTracks_ of the previous block are free again
+    trackStage_.assign(words, 0);
+    size_t at = headerWords;
+    for (size_t k = 0; k < pendingTracks_.size(); ++k) {
+        PendingTrack& t = pendingTracks_[k];
+        if (t.steps <= 0) continue;
+        const int used = std::min(t.steps, (nSamples + t.period - 1) / t.period);  // changes that fall inside this block
+        TrackHeader h{(uint32_t)t.period, (uint32_t)used, (uint32_t)(at * 4), t.perInstance ? (uint32_t)(nPad_ * 4) : 4u};
+        std::memcpy(&trackStage_[k * 4], &h, sizeof(h));
+        const int reg = trackRegs_[k];
+        if (t.perInstance) {
+            for (int q = 0; q < used; ++q) std::memcpy(&trackStage_[at + (size_t)q * (size_t)nPad_], &t.values[(size_t)q * (size_t)n_], (size_t)n_ * 4);
+            at += (size_t)t.steps * (size_t)nPad_;
+            forcedLane_[(size_t)reg] = 1;
+        } else {
+            std::memcpy(&trackStage_[at], t.values.data(), (size_t)t.steps * 4);
+            at += (size_t)t.steps;
+            hostValue_[(size_t)reg] = t.values[(size_t)used - 1];  // what every instance holds after the block
+            forcedLane_[(size_t)reg] = 0;
+        }
+        t.steps = 0;
+        t.values.clear();
+    }
+    tracksClear_ = words == headerWords;
+    hipError_t e = hipMemcpyAsync(dTracks_, trackStage_.data(), words * 4, hipMemcpyHostToDevice, s);
+    return e == hipSuccess ? 0 : hipFail(e, "tracks upload");
+}
+
+// Tiers without in-kernel tracks (interpreter, HIP C++ kernel): the same schedule by cutting the block at its change
+// points and writing the registers in between - what the caller would have had to do.
+int Batch::processWithTrackFallback(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
+    std::vector<PendingTrack> tracks;
+    tracks.swap(pendingTracks_);
+    pendingTracks_.resize(trackRegs_.size());
+    std::vector<int> cuts{0, nSamples};
+    for (const PendingTrack& t : tracks)
+        for (int k = 0; k < t.steps && (int64_t)k * t.period < nSamples; ++k) cuts.push_back(k * t.period);
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    const size_t rowFloats = (size_t)prog_.numChannels * (size_t)n_;
+    for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+        const int lo = cuts[c], hi = cuts[c + 1];
+        for (size_t k = 0; k < tracks.size(); ++k) {
+            const PendingTrack& t = tracks[k];
+            if (t.steps <= 0 || lo % t.period != 0 || lo / t.period >= t.steps) continue;
+            const std::string& name = prog_.regs[(size_t)trackRegs_[k]].name;
+            const int rc = t.perInstance ? setRegisterArray(name, &t.values[(size_t)(lo / t.period) * (size_t)n_]) : setRegister(name, t.values[(size_t)(lo / t.period)]);
+            if (rc != 0) return rc < 0 ? rc : fail(FX_E_ARG, "track: register vanished");
+        }
+        controlHeat_ = 0;  // these writes are the schedule, not a moving slider
+        const int rc = processDevice(dIn + (size_t)lo * rowFloats, dOut + (size_t)lo * rowFloats, hi - lo, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
     (void)hipSetDevice(device_);
     if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
@@ -447,7 +562,9 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     everLowered_ = true;
     if (nSamples == 0) return 0;
     if (!dIn || !dOut) return fail(FX_E_ARG, "null buffer");
+    if (tracksArmed() && !useXlate_) return processWithTrackFallback(dIn, dOut, nSamples, stream);
     hipStream_t s = pick(stream);
+    if (useXlate_ && !trackRegs_.empty() && (rc = uploadTracks(nSamples, s)) != 0) return rc;
     KernelArgs a{};
     const size_t nOps = low_.steady.size();
     a.steady = dStream_;
@@ -509,6 +626,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                 g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteady_);
                 g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLast_);
                 g.initOff = (int)xlateInitOff_;
+                g.tracks = trackRegs_.empty() ? nullptr : dTracks_;
                 e = launchAsmFunction(xlateFn_, g, (unsigned)((n_ + 63) / 64), xlateLdsBytes_, s);
             } else {
                 e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);

@@ -33,6 +33,11 @@ public:
     int setRegisterArray(const std::string& key, const float* values);   // values[n]
     int getRegisterArray(const std::string& key, float* values);
     int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
+    // A schedule of values for register `key`, applied by the NEXT process call: at sample s of that block, when s is a
+    // multiple of `period`, the register takes values[s / period] (perInstance: values[(s / period) * pitch + instance];
+    // pitch 0 = n) - what a caller of the reference does with setRegisterValue() between process() calls
+    // (source/main.cpp:107-114), without cutting the block.  At most kMaxTracks registers; one-shot.
+    int setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance, int64_t pitch = 0);
 
     int processHost(const float* in, float* out, int nSamples, int64_t pitch = 0);  // synchronous; pitch: instances per host PCM row (0 = n)
     int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
@@ -61,6 +66,10 @@ private:
     int ensureLowered();          // (re)lower + upload the stream when dirty
     int ensureState();            // allocate / grow the state block for the current register count
     int ensureTram();
+    int uploadTracks(int nSamples, hipStream_t s);   // translated tier: header + values -> dTracks_
+    int processWithTrackFallback(const float* dIn, float* dOut, int nSamples, hipStream_t stream);  // other tiers: cut the block
+    bool tracked(int reg) const;
+    std::vector<uint8_t> laneForced() const;      // forcedLane_ plus the trackable registers
     int fillRows(const std::vector<uint32_t>& rows, const std::vector<uint32_t>& values);
     bool laneResident(int reg) const;
     bool intrinsicLane(int reg) const;
@@ -110,6 +119,15 @@ private:
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;
     size_t streamCap_ = 0;
+    // control tracks (fx_xlate.hpp TrackHeader): registers the generated loop can re-load by itself, and what is armed
+    struct PendingTrack { int period = 0, steps = 0; bool perInstance = false; std::vector<float> values; };
+    std::vector<int> trackRegs_;           // register of slot t
+    std::vector<PendingTrack> pendingTracks_;  // per slot; steps == 0: not armed
+    uint32_t* dTracks_ = nullptr;
+    size_t tracksCap_ = 0;                 // bytes
+    bool tracksClear_ = false;             // the device header holds no armed schedule
+    std::vector<uint32_t> trackStage_;     // host image of dTracks_ for the block being launched
+    bool tracksArmed() const { for (const PendingTrack& t : pendingTracks_) if (t.steps > 0) return true; return false; }
     uint32_t* dScratch_ = nullptr;  // small device scratch: fill lists, reductions
     float* dIn_ = nullptr;
     float* dOut_ = nullptr;

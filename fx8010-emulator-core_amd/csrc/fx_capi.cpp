@@ -160,6 +160,9 @@ int fxb_set_register_i(fxb_handle* h, const char* key, int64_t inst, float v) { 
 float fxb_get_register_i(fxb_handle* h, const char* key, int64_t inst) { return (h && key) ? guard(&h->batch.front(), 1.0f, [&] { return h->batch.getRegisterAt(key, inst); }) : 1.0f; }
 int fxb_set_register_array(fxb_handle* h, const char* key, const float* values) { return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.setRegisterArray(key, values); }) : 1; }
 int fxb_get_register_array(fxb_handle* h, const char* key, float* values) { return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.getRegisterArray(key, values); }) : 1; }
+int fxb_set_register_track(fxb_handle* h, const char* key, const float* values, int n_steps, int period, int per_instance) {
+    return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.setRegisterTrack(key, values, n_steps, period, per_instance != 0); }) : 1;
+}
 int fxb_seed_noise_i(fxb_handle* h, int64_t inst, int32_t x1, int32_t x2) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.seedNoiseAt(inst, x1, x2); }) : FX_E_ARG; }
 int fxb_process_block(fxb_handle* h, const float* in, float* out, int n) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.processHost(in, out, n); }) : FX_E_ARG; }
 int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n, void* stream) {

@@ -83,7 +83,8 @@
 	.set KA_STATICCNT,0xac
 	.set KA_LUTX1OFF, 0xb0      // byte offset of x1[] inside the LUT blob
 	.set KA_INIT,     0xb4      // translated programs: offset of run-once code (LDS tables), 0 = none
-	.set KA_SIZE,     0xb8
+	.set KA_TRACKS,   0xb8      // translated programs: control tracks of this block (fx_batch.hpp TrackHeader[3] + values), 0 = none
+	.set KA_SIZE,     0xc0
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
 	.set OOD_TRAM_READ_NEG, 1
@@ -773,11 +774,11 @@ PNAME:
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 184
+        .size: 192
         .value_kind: by_value
     .group_segment_fixed_size: 0
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 184
+    .kernarg_segment_size: 192
     .max_flat_workgroup_size: 64
     .name: KNAME
     .private_segment_fixed_size: 0
@@ -788,11 +789,11 @@ amdhsa.kernels:
 #ifndef XLATE
   - .args:
       - .offset: 0
-        .size: 184
+        .size: 192
         .value_kind: by_value
     .group_segment_fixed_size: 0
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 184
+    .kernarg_segment_size: 192
     .max_flat_workgroup_size: 64
     .name: PNAME
     .private_segment_fixed_size: 0

@@ -135,6 +135,13 @@ int Sharded::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
     return shards_[(size_t)k]->batch->seedNoiseAt(inst - shards_[(size_t)k]->first, x1, x2);
 }
 
+int Sharded::setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance) {
+    lastError_.clear();
+    if (!values) { lastError_ = "null buffer"; return FX_E_ARG; }
+    // per-instance schedules are [step][all instances]: a shard takes its columns
+    return fan([&](int k, Batch& b) { return b.setRegisterTrack(key, perInstance ? values + shards_[(size_t)k]->first : values, nSteps, period, perInstance, n_); });
+}
+
 int Sharded::processHost(const float* in, float* out, int nSamples) {
     lastError_.clear();
     if (shards_.size() == 1) return front().processHost(in, out, nSamples);

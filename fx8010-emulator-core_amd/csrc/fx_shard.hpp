@@ -45,6 +45,7 @@ public:
     int setRegisterArray(const std::string& key, const float* values);
     int getRegisterArray(const std::string& key, float* values);
     int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
+    int setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance);
     void setChannels(int c);
 
     // host buffers [sample][channel][all instances]: every shard copies its columns in, runs, copies them out

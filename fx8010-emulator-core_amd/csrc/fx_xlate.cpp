@@ -209,6 +209,13 @@ class Emitter {
         return true;
     }
     size_t words() const { return w_.size(); }
+    // a two-dword instruction given as its words and its listing line (SMEM loads)
+    void raw2(uint32_t w0, uint32_t w1, const std::string& text) {
+        w_.push_back(w0);
+        w_.push_back(w1);
+        ++count_;
+        if (text_) line(text);
+    }
     // s_waitcnt vmcnt(n), the other counters left alone (n <= 63: bits 3:0 and 15:14)
     void waitVmcnt(int n) {
         if (n > 63) n = 63;
@@ -389,7 +396,7 @@ enum : uint32_t {
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
-    SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_LT_U32 = 0x0a, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
+    SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
     SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
@@ -431,6 +438,9 @@ constexpr int kSValidLanes = 58;                    // s[58:59]: lanes that hold
 constexpr int kVInput = 23;                         // v23..v26: PCM input of the current sample, channel 0..3 (requested one sample ahead)
 constexpr int kVInstance4 = 27;                     // v27 = instance * 4: byte offset into a PCM / state row
 constexpr int kSPrefetched = 94;                    // s94 = 1: the leading TRAM reads of this sample are already in flight
+constexpr int kSTrackNext[kMaxTracks] = {28, 29, 69};   // sample index at which track slot t takes its next value (0xFFFFFFFF: never)
+constexpr int kSTrackPtr[kMaxTracks] = {26, 30, 70};    // s[26:27] / s[30:31] / s[70:71]: address of that value
+constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
 
 class Translator {
@@ -479,6 +489,8 @@ class Translator {
         } else {
             e_.waitVmcnt(prog_.tramOpsInline + storesPerSample);  // the PCM input requested one sample ago
         }
+        for (size_t t = 0; t < prog_.trackRows.size(); ++t)
+            if (!trackStep((int)t)) { if (err) *err = err_; return false; }
         if (fast_) {
             for (int c = 0; c < channels; ++c)
                 if (prog_.inRows[(size_t)c] >= 0) taintIfNonFinite(kVInput + c);
@@ -554,6 +566,7 @@ class Translator {
             for (int c = 0; c < 4; ++c) e_.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSCursor + c), vreg(kVCursor + c));
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
         }
+        for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
         if (anyLut && prog_.lutTables.empty()) {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutXthr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutXthr + 1), sreg(kSLut + 1), imm32(0));
@@ -614,6 +627,67 @@ class Translator {
             }
         }
         e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+    }
+
+    // ---- control tracks (fx_xlate.hpp TrackHeader): scalar bookkeeping, one vector move / load per change
+    void smemLoad(int dwords, int sdst, int sbase, uint32_t offset) {  // s_load_dword / x2 / x4 with a 20-bit immediate offset
+        const uint32_t op = dwords == 1 ? 0u : (dwords == 2 ? 1u : 2u);
+        e_.raw2(0xc0020000u | (op << 18) | ((uint32_t)sdst << 6) | ((uint32_t)sbase >> 1), offset,
+                std::string(dwords == 1 ? "s_load_dword s" + std::to_string(sdst) : "s_load_dwordx" + std::to_string(dwords) + " s[" + std::to_string(sdst) + ":" +
+                            std::to_string(sdst + dwords - 1) + "]") + ", s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "], " +
+                    (offset ? "0x" + hexOf(offset) : std::string("0x0")));
+    }
+    static std::string hexOf(uint32_t v) {
+        char buf[16];
+        std::snprintf(buf, sizeof(buf), "%x", v);
+        return buf;
+    }
+    // cold entry: slot t's first change is at sample 0 when the track is armed (steps > 0)
+    void trackInit(int t) {
+        const int next = kSTrackNext[t], ptr = kSTrackPtr[t];
+        smemLoad(2, kSTemp, 0, kKernargTracks);                       // s[62:63] = tracks buffer
+        e_.waitLgkm0();
+        smemLoad(4, kSTemp + 2, kSTemp, (uint32_t)t * 16);             // s[64:67] = period, steps, valuesOffset, strideBytes
+        e_.waitLgkm0();
+        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(ptr), sreg(kSTemp), sreg(kSTemp + 4));
+        e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(ptr + 1), sreg(kSTemp + 1), imm32(0));
+        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp + 3), imm32(0));
+        e_.sop2(SOP2_CSELECT_B32, "s_cselect_b32", sreg(next), imm32(0xffffffffu), imm32(0));
+    }
+    // head of a sample: if this is the sample at which slot t changes, fetch the value(s) and schedule the next change
+    bool trackStep(int t) {
+        const int next = kSTrackNext[t], ptr = kSTrackPtr[t];
+        int vRow;
+        if (!row((uint32_t)prog_.trackRows[(size_t)t], &vRow)) return false;
+        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSSample), sreg(next));
+        Emitter::Fixup notNow = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        e_.cold(true);
+        smemLoad(2, kSTemp, 0, kKernargTracks);
+        e_.waitLgkm0();
+        smemLoad(4, kSTemp + 2, kSTemp, (uint32_t)t * 16);
+        e_.waitLgkm0();
+        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp + 5), imm32(4));
+        Emitter::Fixup perInstance = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        smemLoad(1, kSTemp, ptr, 0);                                   // one value for every instance
+        e_.waitLgkm0();
+        e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vRow), sreg(kSTemp));
+        Emitter::Fixup loaded = e_.branchForward(SOPP_BRANCH, "s_branch");
+        e_.bind(perInstance);
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), sreg64(kSValidLanes));
+        e_.global(GLOBAL_LOAD_DWORD, true, vRow, kVInstance4, ptr);
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+        e_.waitVmcnt(0);
+        e_.bind(loaded);
+        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(ptr), sreg(ptr), sreg(kSTemp + 5));
+        e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(ptr + 1), sreg(ptr + 1), imm32(0));
+        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(next), sreg(next), sreg(kSTemp + 2));
+        e_.sop2(SOP2_MUL_I32, "s_mul_i32", sreg(kSTemp), sreg(kSTemp + 2), sreg(kSTemp + 3));  // period * steps: past the schedule
+        e_.sopc(SOPC_CMP_GE_U32, "s_cmp_ge_u32", sreg(next), sreg(kSTemp));
+        e_.sop2(SOP2_CSELECT_B32, "s_cselect_b32", sreg(next), imm32(0xffffffffu), sreg(next));
+        if (fast_) taintIfNonFinite(vRow);
+        e_.cold(false);
+        e_.bind(notNow);
+        return true;
     }
 
     // TRAM reads in the middle of a program are issued without waiting; the wait (and, in the fast stream, the taint
@@ -1643,8 +1717,9 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
 }  // namespace
 
 XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
-                            int nRows, const std::vector<int>& inputRows, const std::vector<int>& latchRows) {
+                            int nRows, const std::vector<int>& inputRows, const std::vector<int>& latchRows, const std::vector<int>& trackRows) {
     XlateProgram p;
+    p.trackRows = trackRows;
     p.iSize = iSize;
     p.xSize = xSize;
     p.inRows = inputRows;
@@ -1692,6 +1767,8 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
     auto operandWild = [&](uint32_t word, bool uniform) { return uniform ? big(word) : wild(word); };
     p.wildRow[0] = 1;  // CCR holds 0, 2, 6, 8, 16, 20
     for (int r : inputRows)
+        if (r >= 0 && (size_t)r < p.wildRow.size()) p.wildRow[(size_t)r] = 1;
+    for (int r : trackRows)  // a schedule may hold any finite value
         if (r >= 0 && (size_t)r < p.wildRow.size()) p.wildRow[(size_t)r] = 1;
     for (bool changed = true; changed;) {
         changed = false;

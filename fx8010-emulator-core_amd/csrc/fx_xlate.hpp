@@ -53,6 +53,21 @@ struct HoistPlan {
     std::vector<uint32_t> forbidden[2];  // [iTRAM, xTRAM]: cursor distances for which a hoisted read and a later write share a slot
 };
 
+// Control tracks (the reference's caller changes a slider every 8 samples, source/main.cpp:107-114):
+// up to kMaxTracks registers can be given a schedule of values that the generated sample loop applies itself - at
+// sample s of a block, when s is a multiple of the track's period, the register takes the next value - instead of the
+// caller cutting the block.  The generated code only knows WHICH rows are trackable; period, number of steps and the
+// values come from a device buffer (AsmArgs.tracks) at run time, so arming, changing or clearing a schedule needs no
+// re-translation.  Buffer: TrackHeader[kMaxTracks], then the values: one float per step (broadcast) or nPad floats per
+// step (one per instance).
+constexpr int kMaxTracks = 3;
+struct TrackHeader {
+    uint32_t period;       // samples between two values (>= 1)
+    uint32_t steps;        // values in the schedule; 0 = track not armed for this block
+    uint32_t valuesOffset; // byte offset of the first value from the start of the buffer
+    uint32_t strideBytes;  // 4: one value for all instances (scalar load); else bytes between steps of a per-instance schedule
+};
+
 // What the translator needs to know about the program beyond its records.
 struct XlateProgram {
     int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
@@ -64,12 +79,14 @@ struct XlateProgram {
     // PCM I/O of the generated sample loop: row the input of channel c is copied to (-1: unused), row of its output latch
     std::vector<int> inRows, latchRows;
     int tramOpsInline = 0;        // inline TRAM instructions per sample of the steady stream (each issues one VMEM operation)
+    std::vector<int> trackRows;   // register-file row of track slot t (at most kMaxTracks); such rows are of the WILD class
     HoistPlan hoist;
 };
 // nRows = rows of the register file, inputRows = the rows the PCM input goes to (-1: unused channel), latchRows = the
 // rows the PCM output comes from; one entry per channel
 XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
-                            int nRows, const std::vector<int>& inputRows, const std::vector<int>& latchRows);
+                            int nRows, const std::vector<int>& inputRows, const std::vector<int>& latchRows,
+                            const std::vector<int>& trackRows = std::vector<int>());
 
 struct XlateStats {
     int inlined = 0;     // records translated to straight-line code

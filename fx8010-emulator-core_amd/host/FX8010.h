@@ -181,6 +181,12 @@ public:
     float getRegisterValue(const std::string& key, int64_t instance) { return fxb_get_register_i(h_, key.c_str(), instance); }
     // one value per instance (values.size() == instances): per-instance control automation between blocks
     int setRegisterValues(const std::string& key, const std::vector<float>& values) { return fxb_set_register_array(h_, key.c_str(), values.data()); }
+    // a schedule for the next process call: at its sample s, s % period == 0, the register takes values[s / period]
+    // (perInstance: values[(s / period) * instances + instance]); the slider of source/main.cpp:107-114 without cutting the block
+    int setRegisterTrack(const std::string& key, const std::vector<float>& values, int period, bool perInstance = false) {
+        const int steps = (int)(perInstance ? values.size() / (size_t)n_ : values.size());
+        return fxb_set_register_track(h_, key.c_str(), values.data(), steps, period, perInstance ? 1 : 0);
+    }
     // nSamples sample periods for every instance (host buffers, synchronous)
     void process(const float* in, float* out, int nSamples) {
         if (fxb_process_block(h_, in, out, nSamples) < 0) throw std::runtime_error(std::string("FX8010Batch::process: ") + fxb_last_error(h_));

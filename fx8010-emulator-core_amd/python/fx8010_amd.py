@@ -29,7 +29,7 @@ SYMBOLS = [
     "fx_instruction_counter", "fx_error_count", "fx_error_desc", "fx_error_row", "fx_control_count", "fx_control_at",
     "fx_meta_get", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
     "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
-    "fxb_get_register_i", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
+    "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
     "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error",
     "fxb_last_kernel_ms", "fxb_info", "fxb_device_count", "fxb_version",
@@ -69,6 +69,7 @@ def load():
     sig("fxb_process_block_dev_shards", i32, vp, C.POINTER(vp), C.POINTER(vp), i32)
     sig("fxb_load_file", i32, vp, cp); sig("fxb_load_text", i32, vp, cp)
     sig("fxb_set_register", i32, vp, cp, f32); sig("fxb_set_register_i", i32, vp, cp, i64, f32)
+    sig("fxb_set_register_track", i32, vp, cp, vp, i32, i32, i32)
     sig("fxb_set_register_array", i32, vp, cp, vp); sig("fxb_get_register_array", i32, vp, cp, vp)
     sig("fxb_get_register_i", f32, vp, cp, i64); sig("fxb_seed_noise_i", i32, vp, i64, C.c_int32, C.c_int32)
     sig("fxb_process_block", i32, vp, _f32p, _f32p, i32)
@@ -250,6 +251,15 @@ class Batch(_Reports):
         v = np.ascontiguousarray(values, dtype=np.float32)
         assert v.shape == (self.n,)
         return self._check(self._lib.fxb_set_register_array(self._h, key.encode(), v.ctypes.data_as(C.c_void_p)), "set_register_array")
+
+    def set_register_track(self, key, values, period):
+        """values: [steps] (one value for all instances) or [steps, N] (per instance); applied by the next process call at
+        samples 0, period, 2*period, ..."""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        per = v.ndim == 2
+        assert v.ndim == 1 or v.shape[1] == self.n
+        return self._check(self._lib.fxb_set_register_track(self._h, key.encode(), v.ctypes.data_as(C.c_void_p), int(v.shape[0]), int(period), 1 if per else 0),
+                           "set_register_track")
 
     def get_register_array(self, key):
         v = np.empty(self.n, dtype=np.float32)

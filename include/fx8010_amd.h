@@ -116,6 +116,14 @@ float fxb_get_register_i(fxb_handle* h, const char* key, int64_t instance);
  * 0 found, 1 not found, <0 FX_E_*.  One host-to-device copy; the register becomes per-instance. */
 int fxb_set_register_array(fxb_handle* h, const char* key, const float* values);
 int fxb_get_register_array(fxb_handle* h, const char* key, float* values);
+/* Control track: a schedule of values for register `key` that the NEXT fxb_process_block* call applies by itself - at
+ * sample s of that block, whenever s is a multiple of `period`, the register takes values[s / period] (per_instance:
+ * values[(s / period) * n_instances + instance]) - exactly what a caller of the reference does with setRegisterValue()
+ * between process() calls (the slider every 8 samples of source/main.cpp:107-114), in ONE launch instead of one per
+ * change.  At most 3 registers can have tracks; steps beyond the block are dropped; the register keeps its last value.
+ * The translated program reads the schedule from device memory (no re-translation per schedule); the interpreter and
+ * HIP C++ tiers cut the block at the change points.  0 found, 1 not found, <0 FX_E_*. */
+int fxb_set_register_track(fxb_handle* h, const char* key, const float* values, int n_steps, int period, int per_instance);
 /* white-noise generator seeds of one instance (reference: g_x1/g_x2, include/FX8010.h:290-291;
  * every instance starts with the reference's seeds) */
 int fxb_seed_noise_i(fxb_handle* h, int64_t instance, int32_t x1, int32_t x2);

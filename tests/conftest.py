@@ -25,6 +25,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def amd():
+    # torch first: a process that initialises HIP through libfx8010_amd.so before torch has loaded its own HIP runtime
+    # leaves torch without devices ("No HIP GPUs are available"); the other order works (bench.py does the same)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import fx8010_amd
 
     fx8010_amd.load()

@@ -187,3 +187,107 @@ def test_the_references_own_harness_runs_on_the_device(gpu, tmp_path):
         return sorted(keep)
 
     assert facts(got.stdout) == facts(ref.stdout) and len(facts(got.stdout)) >= 8
+
+
+# ---- control tracks (fxb_set_register_track)
+@pytest.fixture(params=["default", "asm", "hip"], ids=["xlate", "asm", "hip"])
+def track_tier(request, monkeypatch):
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    if request.param != "default":
+        monkeypatch.setenv("FX_KERNEL", request.param)
+    return request.param
+
+
+def test_slider_schedule_of_the_reference_harness_in_one_launch(gpu, track_tier):
+    """source/main.cpp:103-122 sets `volume` to 0.1 / 0.25 / 0.5 / 1.0 every 8 samples around process(); tests/golden/slider.json
+    is what the reference then outputs.  Here: ONE 32-sample block with the schedule as a control track."""
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "slider.json")) as fh:
+        case = json.load(fh)[0]
+    x1 = np.frombuffer(bytes.fromhex(case["input"]), dtype=np.uint32).view(np.float32)
+    want = np.frombuffer(bytes.fromhex(case["output"]), dtype=np.uint32)
+    N = 130
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(case["program"])
+    b.set_register_track("volume", [0.1, 0.25, 0.5, 1.0], 8)
+    y = b.process_block(np.repeat(x1.reshape(-1, 1), N, axis=1).copy())
+    if track_tier == "default":
+        assert b.info("kernel") >= 9  # the translated program applied the schedule itself
+    for n in (0, 63, 64, N - 1):
+        assert np.array_equal(np.ascontiguousarray(y[:, n]).view(np.uint32), want), n
+        assert b.instruction_counter_i(n) == case["counter"]
+        for reg, bits_ in case["registers"].items():
+            assert b.get_register_bits_i(reg, n) == bits_, (reg, n)
+    # the schedule was one-shot: the next block runs with the last value, like the reference object would
+    y2 = b.process_block(np.repeat(x1.reshape(-1, 1), N, axis=1).copy())
+    o = Oracle(1)
+    assert o.load_text(case["program"])
+    for lo, v in ((0, 0.1), (8, 0.25), (16, 0.5), (24, 1.0)):
+        o.set_register("volume", v)
+        o.process_block(x1[lo:lo + 8].copy())
+    ref2 = o.process_block(x1.copy())
+    assert np.array_equal(bits(ref2), bits(y2[:, 7]))
+
+
+def test_tracks_per_instance_and_broadcast_together(gpu, track_tier):
+    """two schedules with different periods - one value per instance and step, one value for all - inside a 100-sample block of
+    config3 (TRAM reads issued a sample ahead, fp64 path), then a plain block; against the oracle doing the same with
+    set_register between sub-blocks"""
+    n, s = 200, 100
+    text = progs.config3()
+    x = progs.stimulus(n, s + 30)
+    rng = np.random.default_rng(5)
+    cut = rng.uniform(0.01, 0.9, size=(4, n)).astype(np.float32)       # period 32: samples 0, 32, 64, 96
+    fbv = np.array([0.5, 0.25, -0.4, 0.6, 0.1, 0.45], dtype=np.float32)  # period 24: samples 0, 24, 48, 72, 96 (6th value unused)
+    b = gpu.Batch(n, 1, 0)
+    assert b.load_text(text)
+    b.process_block(x[:10])  # state before the tracked block
+    b.set_register_track("cutoff", cut, 32)
+    b.set_register_track("fb", fbv, 24)
+    y = b.process_block(x[10:10 + s])
+    y2 = b.process_block(x[10 + s:])
+    assert b.ood_flags() == 0
+    for inst in (0, 63, 64, 130, n - 1):
+        o = Oracle(1)
+        assert o.load_text(text)
+        o.process_block(x[:10, inst].copy())
+        outs = []
+        for lo in range(s):
+            if lo % 32 == 0:
+                o.set_register("cutoff", float(cut[lo // 32, inst]))
+            if lo % 24 == 0:
+                o.set_register("fb", float(fbv[lo // 24]))
+            outs.append(o.process_block(x[10 + lo:11 + lo, inst].copy()))
+        ref = np.concatenate(outs)
+        assert np.array_equal(bits(ref), bits(y[:, inst])), inst
+        ref2 = o.process_block(x[10 + s:, inst].copy())
+        assert np.array_equal(bits(ref2), bits(y2[:, inst])), inst
+        assert b.instruction_counter_i(inst) == o.instruction_counter()
+        assert b.get_register_bits_i("cutoff", inst) == o.get_register_bits("cutoff")
+        assert b.get_register_bits_i("fb", inst) == o.get_register_bits("fb")
+
+
+def test_track_limits_and_sharded_tracks(gpu):
+    n = 300
+    b = gpu.Batch(n, 1, devices=[0, 0])
+    assert b.load_text(progs.config5())
+    for key in ("damp", "decay", "diff"):
+        b.set_register_track(key, [0.3, 0.2], 16)
+    with pytest.raises(RuntimeError):
+        b.set_register_track("in", [0.0], 4)  # a fourth register
+    import ctypes as C
+    one_value = (C.c_float * 1)(0.5)
+    assert b._lib.fxb_set_register_track(b._h, b"nosuch", one_value, 1, 1, 0) == 1  # the reference's "not found"
+    assert b._lib.fxb_set_register_track(b._h, b"damp", None, 1, 1, 0) == -3       # FX_E_ARG
+    one = gpu.Batch(n, 1, 0)
+    b = gpu.Batch(n, 1, devices=[0, 0])  # (a fresh one: the schedules armed above would still apply)
+    assert one.load_text(progs.config5()) and b.load_text(progs.config5())
+    x = progs.stimulus(n, 40)
+    vals = np.linspace(0.1, 0.6, 3 * n).reshape(3, n).astype(np.float32)
+    for bb in (b, one):
+        bb.set_register_track("damp", vals, 16)
+        bb.set_register_track("decay", [0.45, 0.2], 20)
+    assert np.array_equal(bits(b.process_block(x)), bits(one.process_block(x)))
+    assert np.array_equal(bits(b.get_register_array("damp")), bits(vals[2]))
