@@ -403,7 +403,7 @@ enum : uint32_t {
     VOP2_ADDC_CO_U32 = 0x1c, VOP3B_SUBBREV_CO_U32 = 0x11e,
     VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49, VOPC_CMP_NGT_F32 = 0x4b, VOPC_CMP_NLE_F32 = 0x4c,
     VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
-    VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
+    VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F32 = 0x1cb, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
     SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
@@ -468,6 +468,7 @@ class Translator {
             usesSkipCounter = usesSkipCounter || r.w[0] == AS_PRED || r.w[0] == AS_SKIP;
             anyLut = anyLut || r.w[0] == AS_LUT;
         }
+        buildConstantPool(records, anyLut);
         // ---- head: this sample's operands that come from memory
         const size_t headWord = e_.words();
         const int storesPerSample = channels;
@@ -567,6 +568,7 @@ class Translator {
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
         }
         for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
+        for (const auto& c : pool_) e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(c.second), imm32(c.first, true));
         if (anyLut && prog_.lutTables.empty()) {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutXthr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutXthr + 1), sreg(kSLut + 1), imm32(0));
@@ -760,8 +762,13 @@ class Translator {
         // exact stream, which a wave enters precisely when that invariant broke) the index is clamped and the flag derived.
         const bool guarded = operandWild || !fast_;
         Src zero = imm32(0), top = imm32(63), vcc = named(106, "vcc");
-        e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x3f800000u), vA);
-        e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 6, imm32(0x41fc0000u), 6);                  // * 31.5
+        if (pooled(0x41fc0000u) >= 0) {  // (x + 1) * 31.5 as fma(x, 31.5, 31.5): it is only a guess, checked below
+            Src k = sreg(pooled(0x41fc0000u));
+            e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(6), vreg(vA), k, &k);
+        } else {
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x3f800000u), vA);
+            e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 6, imm32(0x41fc0000u), 6);              // * 31.5
+        }
         e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
         const uint32_t slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes, y1Off = slopeOff + 512;
@@ -790,7 +797,7 @@ class Translator {
         e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));      // x <  xthr[g]  : one down
         e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTemp + 2), vcc, sreg64(kSTemp));
         e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTemp + 2), imm32(0));
-        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");  // (s_cbranch_vccz would save the compare, but VCC must survive for the miss path)
         // (two instructions lie between the VALU writes of VCC / the SGPR pair and the VALU reads below)
         e_.cold(true);
         e_.addCarry(6);
@@ -1038,10 +1045,70 @@ class Translator {
         return true;
     }
 
+    // ---- constants held in SGPRs for the whole loop (VOP3 takes no literal on gfx9): the multipliers of "R = 0 + X * c"
+    // with |c| > 0.5, and 31.5 for the LOG/EXP index guess.  s88..s93 are free unless the LOG/EXP tables are read from
+    // global memory (more than four tables).
+    void buildConstantPool(const std::vector<MicroOp>& records, bool anyLut) {
+        pool_.clear();
+        if (!fast_ || (anyLut && prog_.lutTables.empty())) return;
+        std::vector<std::pair<uint32_t, int>> freq;
+        auto bump = [&](uint32_t bits, int by) {
+            for (auto& f : freq)
+                if (f.first == bits) { f.second += by; return; }
+            freq.emplace_back(bits, by);
+        };
+        for (const MicroOp& r : records) {
+            uint32_t c;
+            if (r.w[0] == AS_LUT && !(r.w[6] & 1u)) bump(0x41fc0000u, 1);
+            else if (zeroPlusScaled(r, &c, nullptr)) bump(c, 1);
+        }
+        std::stable_sort(freq.begin(), freq.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.second > b.second; });
+        for (size_t k = 0; k < freq.size() && k < 6; ++k) pool_.emplace_back(freq[k].first, 88 + (int)k);
+    }
+    int pooled(uint32_t bits) const {
+        for (const auto& c : pool_)
+            if (c.first == bits) return c.second;
+        return -1;
+    }
+    // MACS / MACINTS "R = sat(0 + X * c)" with a uniform finite |c| > 0.5 and a per-lane X: the reference's mul-then-add
+    // equals ONE fma(X, c, +0).  The add of +0 only matters when the product is -0 (it becomes +0); with |c| > 0.5 a
+    // non-zero X never underflows to zero (|X * c| > 2^-150 rounds to at least the smallest denormal), so the product is
+    // a zero exactly when X is, and then fma gives (+-0) + (+0) = +0 as well.  Everywhere else fma rounds X * c once,
+    // like the multiplication, and adding +0 changes nothing.
+    static bool zeroPlusScaled(const MicroOp& r, uint32_t* c, uint32_t* xRow) {
+        const uint32_t slot = r.w[0];
+        if (slot < AS_MACS || slot >= AS_MACSN) return false;  // MACS family only (not MACSN: 0 - p)
+        const uint32_t kind = ((slot - AS_MACS) % 16) / 2;
+        if (!(kind & 1u) || r.w[2] != 0u) return false;        // A must be the uniform +0.0
+        uint32_t cb, xr;
+        if ((kind & 6u) == 2u) { cb = r.w[3]; xr = r.w[4]; }
+        else if ((kind & 6u) == 4u) { cb = r.w[4]; xr = r.w[3]; }
+        else return false;
+        const uint32_t mag = cb & 0x7fffffffu;
+        if (mag <= 0x3f000000u || mag >= 0x7f800000u || mag == 0x3f800000u) return false;  // |c| > 0.5, finite; +-1.0 needs no multiply at all
+        if (c) *c = cb;
+        if (xRow) *xRow = xr;
+        return true;
+    }
+
     bool macs(const MicroOp& r, uint32_t kind, bool neg) {
         int vR;
         if (!row(r.w[5], &vR)) return false;
         plainMode();
+        {
+            uint32_t c, xRow;
+            int vX;
+            if (fast_ && !neg && zeroPlusScaled(r, &c, &xRow) && pooled(c) >= 0) {
+                if (!row(xRow, &vX)) return false;
+                const bool within = resultWithinUnit(0, kind, r);
+                Src zero = imm32(0);
+                e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(within ? vR : 2), vreg(vX), sreg(pooled(c)), &zero);
+                ++stats_.fusedZeroAdds;
+                if (within) ++stats_.unsaturated;
+                else satStore(vR);
+                return true;
+            }
+        }
         if (kind == 7) {  // folded on the host: the A word is the saturated result
             e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), value(r.w[2]));
             return true;
@@ -1490,6 +1557,7 @@ class Translator {
     const std::vector<uint32_t>* exactReturns_;
     std::vector<uint32_t> returns_;  // sync points of this stream (see run())
     std::vector<int> pending_;       // VGPRs with a TRAM read in flight
+    std::vector<std::pair<uint32_t, int>> pool_;  // uniform constants kept in SGPRs for the whole loop: (bits, SGPR)
     const std::vector<MicroOp>* records_ = nullptr;
     size_t consumed_ = (size_t)-1;   // record already translated together with its predecessor
     bool predOpen_ = false;          // EXEC is restricted by a PRED / a simple shadow

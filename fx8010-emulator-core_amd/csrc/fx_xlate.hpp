@@ -96,6 +96,7 @@ struct XlateStats {
     int fusedSkips = 0;  // SKIPs translated as a predicate on the value that would have set their CCR
     int regions = 0;     // SKIP shadows run under one EXEC mask (no per-instruction PRED)
     int unitMultipliers = 0;  // multiplications by +-1.0 that were not emitted
+    int fusedZeroAdds = 0;    // "R = 0 + X * c", |c| > 0.5, emitted as one fma (bit-identical, see fx_xlate.cpp zeroPlusScaled)
     int unsaturated = 0; // saturating instructions whose result provably lies in [-1, 1]: no v_med3 in the fast stream
     bool nonFiniteImmediate = false;  // a NaN / Inf among the uniform operands: no fast stream for this program
 };

@@ -80,7 +80,7 @@ def branch_targets(listing):
     sizes = []
     for l in lines:
         op = l.split()[0]
-        eight = (op.endswith("_e64") or op in ("v_med3_f32", "v_med3_i32", "v_fma_f64", "v_add_f64", "v_mul_f64") or op.startswith(("global_", "ds_"))
+        eight = (op.endswith("_e64") or op in ("v_med3_f32", "v_med3_i32", "v_fma_f32", "v_fma_f64", "v_add_f64", "v_mul_f64") or op.startswith(("global_", "ds_"))
                  or re.search(r"0x[0-9a-f]+", l) is not None)
         sizes.append(8 if eight else 4)
     assert sum(sizes) == len(code), "instruction size model"

@@ -14,12 +14,14 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in $CONFIGS; do
   echo "== $c: bench" 
-  python3 $ROOT/bench.py --config $c --cpu-seconds 0 > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err || exit 1
+  python3 $ROOT/bench.py --config $c --cpu-seconds 0 --no-extras > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err || exit 1
   cat $OUT/${c}_bench.json
   echo "== $c: kernel trace"
-  rocprofv3 --kernel-trace --stats -d $OUT/${c}_trace -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 > $OUT/${c}_bench_under_rocprof.json 2> $OUT/${c}_trace.err || exit 1
+  rocprofv3 --kernel-trace --stats -d $OUT/${c}_trace -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --no-extras --parity-instances 0 > $OUT/${c}_bench_under_rocprof.json 2> $OUT/${c}_trace.err || exit 1
+  echo "== $c: HBM traffic counters"
+  rocprofv3 -i $ROOT/tools/pmc_hbm.txt --kernel-trace -d $OUT/${c}_hbm -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 3 --warmup 1 --no-extras --parity-instances 0 > $OUT/${c}_hbm.json 2> $OUT/${c}_hbm.err || exit 1
   echo "== $c: SQ counters"
-  rocprofv3 -i $ROOT/tools/pmc_sq.txt -d $OUT/${c}_pmc -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 2 --warmup 1 > $OUT/${c}_pmc.json 2> $OUT/${c}_pmc.err || exit 1
+  rocprofv3 -i $ROOT/tools/pmc_sq.txt -d $OUT/${c}_pmc -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 2 --warmup 1 --no-extras --parity-instances 0 > $OUT/${c}_pmc.json 2> $OUT/${c}_pmc.err || exit 1
 done
 find $OUT -name "*kernel_stats.csv" | head
 echo done
