@@ -25,6 +25,7 @@ bool asmEligible(const Lowered& low, std::string* why) {
     auto no = [&](const char* w) { if (why) *why = w; return false; };
     if (low.instPerLane != 1) return no("more than one instance per lane");
     if (low.multipass) return no("END can be skipped (multi-pass program)");
+    if (low.tramDane && (low.usesITram || low.usesXTram)) return no("opt-in DANE delay-line model (HIP C++ kernel only)");
     if (low.rowPitch != 1 && (size_t)low.nRows * 256 > 64 * 1024) return no("register file above 64 KiB of LDS");
     if (low.rowPitch == 1 && low.nRows > kAsmVgprRows[ASM_V256]) return no("register file above 224 VGPR rows");
     for (const MicroOp& m : low.steady) {

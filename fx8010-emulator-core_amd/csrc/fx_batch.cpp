@@ -600,6 +600,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     a.aliveOff = low_.aliveRow >= 0 ? (uint32_t)low_.aliveRow * rowBytes : 0;
     a.hasShadow = low_.skipRow >= 0 ? 1 : 0;
     a.instPerLane = instPerLane_;
+    a.tramDane = (low_.tramDane && low_.cursorRow >= 0) ? 1 : 0;
     a.oodRow = stateLayout_.oodRow;
     a.countLo = stateLayout_.countLo;
     a.countHi = stateLayout_.countHi;

@@ -58,6 +58,13 @@ public:
     // reference setChannels(): only the loader's I/O-index bound changes (include/FX8010.h:73, source/FX8010.cpp:447)
     void setChannels(int c) { prog_.loaderChannels = c; }
     void noteError(const std::string& what) { lastError_ = what; }
+    // behaviour beyond the reference (fx_model.hpp kOpt*): takes effect for programs loaded afterwards
+    int setOption(unsigned option, bool on) {
+        if (option & ~(kOptTramDane | kOptTramAddrShift)) return -3;
+        prog_.options = on ? (prog_.options | option) : (prog_.options & ~option);
+        lowDirty_ = true;
+        return 0;
+    }
 
 private:
     int fail(int code, const std::string& what);

@@ -127,6 +127,7 @@ int fx_control_count(fx_handle* h) { return h ? controlCount(h->batch) : 0; }
 const char* fx_control_at(fx_handle* h, int i) { return h ? controlAt(h->batch, i) : ""; }
 int fx_meta_get(fx_handle* h, const char* key, char* buf, int buflen) { return h ? guard(&h->batch, 0, [&] { return metaGet(h->batch, key, buf, buflen); }) : 0; }
 void fx_set_channels(fx_handle* h, int c) { if (h) h->batch.setChannels(c); }
+int fx_set_option(fx_handle* h, unsigned option, int on) { return h ? h->batch.setOption(option, on != 0) : FX_E_ARG; }
 int fx_get_channels(fx_handle* h) { return h ? h->batch.loaderChannels() : 0; }
 int fx_ready(fx_handle* h) { return (h && h->batch.program().ready) ? 1 : 0; }
 const char* fx_last_error(fx_handle* h) { return h ? h->batch.lastError().c_str() : "null handle"; }
@@ -153,6 +154,7 @@ int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instanc
     return 0;
 }
 void fxb_destroy(fxb_handle* h) { delete h; }
+int fxb_set_option(fxb_handle* h, unsigned option, int on) { return h ? h->batch.setOption(option, on != 0) : FX_E_ARG; }
 int fxb_load_file(fxb_handle* h, const char* path) { return (h && path) ? guard(&h->batch.front(), 0, [&] { return h->batch.loadFile(path) ? 1 : 0; }) : 0; }
 int fxb_load_text(fxb_handle* h, const char* text) { return (h && text) ? guard(&h->batch.front(), 0, [&] { return h->batch.loadText(text) ? 1 : 0; }) : 0; }
 int fxb_set_register(fxb_handle* h, const char* key, float v) { return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.setRegister(key, v); }) : 1; }
@@ -190,6 +192,11 @@ int64_t fxb_info(fxb_handle* h, int what) { return h ? guard(&h->batch.front(), 
 /* ---- front-end only ---- */
 fxp_handle* fxp_create(int ch) { return create<fxp_handle>(ch); }
 void fxp_destroy(fxp_handle* h) { delete h; }
+int fxp_set_option(fxp_handle* h, unsigned option, int on) {
+    if (!h || (option & ~(fx::kOptTramDane | fx::kOptTramAddrShift))) return FX_E_ARG;
+    h->prog.options = on ? (h->prog.options | option) : (h->prog.options & ~option);
+    return 0;
+}
 int fxp_load_file(fxp_handle* h, const char* path) { if (!h || !path) return 0; h->lowered = false; return guard(h, 0, [&] { return h->prog.loadFile(path) ? 1 : 0; }); }
 int fxp_load_text(fxp_handle* h, const char* text) { if (!h || !text) return 0; h->lowered = false; return guard(h, 0, [&] { return h->prog.loadText(text) ? 1 : 0; }); }
 int fxp_num_registers(fxp_handle* h) { return h ? (int)h->prog.regs.size() : 0; }

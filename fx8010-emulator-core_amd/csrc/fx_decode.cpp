@@ -201,8 +201,10 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
     }
 
     // ---- 6. TRAM sizing ---------------------------------------------------------------------------
+    out.tramDane = (prog.options & kOptTramDane) != 0;
     auto tramSlots = [&](int op, int size, int cap) {
         if (size <= 0) return 0;
+        if (out.tramDane) return std::min(size, cap);  // ring addressing: every slot index is below size
         int maxOff = 0;
         bool dynamic = false;
         for (const Instr& I : prog.instrs) {
@@ -287,6 +289,7 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
             }
             uint32_t flags = sh | F_COUNT;
             if (setsCcr(I.op) && (pass == 1 || ccrLive[k])) flags |= F_CCR;
+            if (h >= H_TRAM_IR && h <= H_TRAM_XW && out.tramDane) flags |= F_TRAM_DANE | ((prog.options & kOptTramAddrShift) ? F_TRAM_SHIFT : 0u);
 
             // operand slots: LDS byte offset of a per-instance row, or the immediate of a uniform register;
             // slots an opcode does not read are immediates too, so the kernel issues no LDS read for them

@@ -52,7 +52,9 @@ enum : uint32_t {
     F_POSTFIX = 1u << 14,  // helper op behind its instruction (runs where the instruction ran)
     F_COUNT = 1u << 15,    // a reference instruction (counts towards getInstructionCounter)
     F_STATIC_OOD = 1u << 16,  // decoder already knows this op leaves the parity domain
-    F_WRITE_R = 1u << 17      // the handler's result is stored to row R (and CCR derived from it if F_CCR)
+    F_WRITE_R = 1u << 17,     // the handler's result is stored to row R (and CCR derived from it if F_CCR)
+    F_TRAM_DANE = 1u << 18,   // opt-in delay-line model (fx_model.hpp kOptTramDane): slot = (per-sample counter + position) mod size
+    F_TRAM_SHIFT = 1u << 19   // ... positions are DANE addresses: >> 11
 };
 
 // state rows (32-bit words per instance) in the device state block, after the register rows
@@ -94,6 +96,7 @@ struct Lowered {
     int nShadowed = 0, nCcrLive = 0;
     int tramOpsPerSample = 0;
     bool multipass = false;
+    bool tramDane = false;        // the opt-in DANE delay-line model is in force (only the HIP C++ kernel implements it)
     bool usesNoise = false, usesITram = false, usesXTram = false, usesLut = false;
     int iSlots = 0, xSlots = 0;  // TRAM slots to allocate per instance
     std::string error;            // non-empty: cannot be lowered

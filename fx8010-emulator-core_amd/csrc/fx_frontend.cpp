@@ -204,7 +204,9 @@ void Program::checkLine(const std::string& line) {
         bool shape = true;
         for (;;) {
             sc.blanks();
-            std::string tok = sc.run(isOperandChar);
+            std::string tok;
+            if ((options & kOptTramDane) && !sc.done() && sc.peek() == '&') { tok = "&"; ++sc.i; }  // opt-in: &name = position register of a delay tap
+            tok += sc.run(isOperandChar);
             if (tok.empty()) { shape = false; break; }
             ops.push_back(tok);
             sc.blanks();
@@ -216,6 +218,18 @@ void Program::checkLine(const std::string& line) {
         Instr in;
         in.op = kw.code;
         int idx[4];
+        // opt-in DANE taps (docs/TRAM Registermapping.pdf p.1): the position of "idelay read, rd, at, 17" lives in a register
+        // of its own, "&rd" (created here with the literal as its value), which other instructions may write
+        if ((options & kOptTramDane) && (kw.code == IDELAY || kw.code == XDELAY) && looksNumeric(ops[3]) && ops[1][0] != '&') {
+            const std::string tap = "&" + ops[1];
+            if (findRegister(tap) < 0) {
+                float v = std::strtof(ops[3].c_str(), nullptr);
+                if (std::isinf(v)) sawUnparsable = true;
+                if (options & kOptTramAddrShift) v = v * 9.5367431640625e-07f;  // samples -> DANE address fraction: 0x800 / 2^31 per sample
+                regs.push_back({R_STATIC, tap, v, 0});
+            }
+            ops[3] = tap;
+        }
         for (int k = 0; k < 4; ++k) {  // R, A, X, Y in that order; stop at the first unknown name
             idx[k] = resolveOperand(ops[k]);
             if (idx[k] < 0) { addError(kUndeclared); return; }

@@ -227,6 +227,42 @@ __device__ __forceinline__ void orOod(const Ctx<K>& c, const uint32_t (&bits)[K]
 }
 
 // reference read/write{Small,Large}Delay, source/FX8010.cpp:909-967; the cursors live in LDS rows
+// Opt-in DANE delay-line model (NOT reference behaviour: docs/TRAM Registermapping.pdf, kX/DANE convention; the oracle has
+// the same switch): one address counter per TRAM - the write-cursor row - that steps DOWN once per sample period
+// (daneStep); a tap, read or write, addresses (counter + position) mod size, position in samples or, with F_TRAM_SHIFT,
+// in DANE addresses of 0x800 per sample.  A value written at position pw is read pr - pw samples later at position pr.
+template <int K>
+__device__ __forceinline__ void daneTap(const Ctx<K>& c, float* __restrict__ base, int slots, int size, uint32_t counterOff, uint32_t flags,
+                                        bool isRead, Vec<K>& av, const Vec<K>& yv, const bool (&run)[K]) {
+    uint32_t ood[K];
+    const Vec<K> cur = ldsLoad<K>(c.lane, counterOff);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ood[k] = 0;
+        if (!run[k]) continue;
+        if (size <= 0) { ood[k] = OOD_TRAM_SIZE0; if (isRead) av.v[k] = 0.0f; continue; }
+        // whole samples, or (F_TRAM_SHIFT) a DANE address held as the register's fixed-point fraction: value * 2^31, 0x800 per sample
+        const int position = (flags & F_TRAM_SHIFT) ? (cvtt_f32(yv.v[k] * 2147483648.0f) >> 11) : cvtt_f32(yv.v[k]);
+        long long idx = ((long long)(int)asU(cur.v[k]) + position) % size;
+        if (idx < 0) idx += size;
+        float* cell = base + (size_t)idx * (64 * K) + k;
+        if (idx < slots) { if (isRead) av.v[k] = *cell; else *cell = av.v[k]; }
+        else if (isRead) av.v[k] = 0.0f;
+    }
+    orOod<K>(c, ood);
+}
+template <int K>
+__device__ __forceinline__ void daneStep(const Ctx<K>& c, int size, uint32_t counterOff) {
+    if (size <= 0) return;
+    Vec<K> cur = ldsLoad<K>(c.lane, counterOff);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int v = (int)asU(cur.v[k]);
+        cur.v[k] = asF((uint32_t)(v <= 0 ? size - 1 : v - 1));
+    }
+    ldsStore<K>(c.lane, counterOff, cur);
+}
+
 template <int K>
 __device__ __forceinline__ Vec<K> tramRead(const Ctx<K>& c, float* __restrict__ base, int slots, int size, uint32_t cursorOff,
                                            const Vec<K>& yv, const bool (&run)[K]) {
@@ -375,15 +411,19 @@ __device__ __forceinline__ void execOp(const Ctx<K>& c, uint32_t w0, uint32_t rO
             break;
         }
         case H_TRAM_IR:  // A = readSmallDelay((int)Y)   :1188-1193
+            if (w0 & F_TRAM_DANE) { r = splat<K>(0.0f); daneTap<K>(c, c.itramLane, c.a->iSlots, c.a->iSize, c.a->cursorOff, w0, true, r, y, run); break; }
             r = tramRead<K>(c, c.itramLane, c.a->iSlots, c.a->iSize, c.a->cursorOff + 1u * ROWB, y, run);
             break;
         case H_TRAM_IW:  // writeSmallDelay(A, (int)Y)   :1194-1198
+            if (w0 & F_TRAM_DANE) { Vec<K> av = a; daneTap<K>(c, c.itramLane, c.a->iSlots, c.a->iSize, c.a->cursorOff, w0, false, av, y, run); break; }
             tramWrite<K>(c, c.itramLane, c.a->iSlots, c.a->iSize, kMaxITram, c.a->cursorOff, a, y, run);
             break;
         case H_TRAM_XR:  // :1200-1205
+            if (w0 & F_TRAM_DANE) { r = splat<K>(0.0f); daneTap<K>(c, c.xtramLane, c.a->xSlots, c.a->xSize, c.a->cursorOff + 2u * ROWB, w0, true, r, y, run); break; }
             r = tramRead<K>(c, c.xtramLane, c.a->xSlots, c.a->xSize, c.a->cursorOff + 3u * ROWB, y, run);
             break;
         case H_TRAM_XW:  // :1206-1210
+            if (w0 & F_TRAM_DANE) { Vec<K> av = a; daneTap<K>(c, c.xtramLane, c.a->xSlots, c.a->xSize, c.a->cursorOff + 2u * ROWB, w0, false, av, y, run); break; }
             tramWrite<K>(c, c.xtramLane, c.a->xSlots, c.a->xSize, kMaxXTram, c.a->cursorOff + 2u * ROWB, a, y, run);
             break;
         case H_NOISE: {  // whitenoise()   :993-1000
@@ -566,6 +606,10 @@ __global__ __launch_bounds__(64) void fx_step_block(const KernelArgs a) {
 #pragma unroll
         for (int ch = 0; ch < kMaxChannels; ++ch)
             if (ch < CH) gStore<K>(a.out + ((size_t)s * CH + ch) * n + inst0, ldsLoad<K>(c.lane, (uint32_t)a.latchRow[ch] * ROWB), vecIo, nValid);
+        if (a.tramDane) {  // opt-in delay-line model: the address counters step once per sample period
+            daneStep<K>(c, a.iSize, a.cursorOff);
+            daneStep<K>(c, a.xSize, a.cursorOff + 2u * ROWB);
+        }
     }
 
     // ---- epilogue: LDS rows -> state rows

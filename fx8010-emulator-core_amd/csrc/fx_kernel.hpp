@@ -49,6 +49,7 @@ struct KernelArgs {
     int nRows;
     int hasShadow;
     int instPerLane;     // K: 1, 2 or 4
+    int tramDane;        // opt-in DANE delay-line model: the two write-cursor rows are per-sample address counters
 };
 
 // grid = ceil(n / (64*K)) workgroups of one wavefront; dynamic LDS = nRows*256*K bytes.

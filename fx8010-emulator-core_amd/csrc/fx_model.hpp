@@ -25,6 +25,10 @@ enum RegType : int {
     R_READ, R_WRITE, R_AT, R_CCR
 };
 
+// options (same values as FX_OPT_* in include/fx8010_amd.h and FXO_OPT_* in the oracle)
+constexpr unsigned kOptTramDane = 1u << 0;       // DANE delay-line model: per-sample address counter, ring taps, &name tap registers
+constexpr unsigned kOptTramAddrShift = 1u << 1;  // tap positions are DANE addresses (0x800 per sample)
+
 constexpr int kMaxITram = 8192;     // reference MAX_IDELAY_SIZE, include/FX8010.h:41
 constexpr int kMaxXTram = 1048576;  // reference MAX_XDELAY_SIZE, include/FX8010.h:42
 
@@ -64,6 +68,8 @@ public:
     std::vector<std::string> controls;
     std::vector<std::pair<std::string, std::string>> meta;
     int iTramSize = 0, xTramSize = 0;
+    // behaviour beyond the reference, off by default (FX_OPT_* of include/fx8010_amd.h): set before loading
+    unsigned options = 0;
     bool ready = false;
     bool sawUnparsable = false;  // input on which the reference itself throws (stoi/stof)
 

@@ -47,6 +47,7 @@ public:
     int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
     int setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance);
     void setChannels(int c);
+    int setOption(unsigned option, bool on) { int rc = 0; for (auto& w : shards_) rc = w->batch->setOption(option, on) ? -3 : rc; return rc; }
 
     // host buffers [sample][channel][all instances]: every shard copies its columns in, runs, copies them out
     int processHost(const float* in, float* out, int nSamples);

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "..", "libfx8010_amd.so")
 _f32p = C.POINTER(C.c_float)
 _lib = None
 
+OPT_TRAM_DANE, OPT_TRAM_ADDR_SHIFT = 1, 2  # FX_OPT_* of include/fx8010_amd.h
+
 # selectors of fxb_info / fxp_lower_info
 INFO = {
     "num_instructions": 0, "num_registers": 1, "num_lane_regs": 2, "num_uniform_regs": 3, "lds_bytes_per_wg": 4,
@@ -27,7 +29,7 @@ INFO = {
 SYMBOLS = [
     "fx_create", "fx_destroy", "fx_load_file", "fx_process", "fx_process_block", "fx_set_register", "fx_get_register",
     "fx_instruction_counter", "fx_error_count", "fx_error_desc", "fx_error_row", "fx_control_count", "fx_control_at",
-    "fx_meta_get", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
+    "fx_meta_get", "fx_set_option", "fxb_set_option", "fxp_set_option", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
     "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
     "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
@@ -61,6 +63,8 @@ def load():
     sig("fx_process", i32, vp, _f32p, _f32p); sig("fx_process_block", i32, vp, _f32p, _f32p, i32)
     sig("fx_set_register", i32, vp, cp, f32); sig("fx_get_register", f32, vp, cp)
     sig("fx_instruction_counter", i64, vp)
+    for pfx in ("fx_", "fxb_", "fxp_"):
+        sig(pfx + "set_option", i32, vp, C.c_uint, i32)
     sig("fx_set_channels", None, vp, i32); sig("fx_get_channels", i32, vp); sig("fx_ready", i32, vp)
     sig("fx_last_error", cp, vp); sig("fx_last_create_error", cp)
     sig("fxb_create", vp, i64, i32, i32); sig("fxb_destroy", None, vp)
@@ -104,6 +108,12 @@ class _Reports:
 
     def _call(self, name, *a):
         return getattr(self._lib, self._pfx + name)(self._h, *a)
+
+    def set_option(self, option, on=True):
+        """FX_OPT_* (OPT_TRAM_DANE, OPT_TRAM_ADDR_SHIFT): behaviour beyond the reference; before loading"""
+        rc = self._call("set_option", option, 1 if on else 0)
+        if rc != 0:
+            raise RuntimeError("set_option(%d) failed: %d" % (option, rc))
 
     def errors(self):
         return [(self._call("error_desc", i).decode("latin-1"), self._call("error_row", i)) for i in range(self._call("error_count"))]

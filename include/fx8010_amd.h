@@ -38,6 +38,27 @@ extern "C" {
 #define FX_E_PROGRAM (-4)  /* program cannot be lowered for the device (see fxb_last_error) */
 #define FX_E_MEMORY (-5)   /* device allocation failed                        */
 
+/* Options: behaviour BEYOND the reference, off by default - with every option off the library is the reference, bit for bit.
+ * Set before loading a program (fx_set_option / fxb_set_option / fxp_set_option; 0 or FX_E_ARG).
+ *
+ * FX_OPT_TRAM_DANE  the delay-line model the reference's own design note asks for but does not implement
+ *   (docs/TRAM Registermapping.pdf p.1-3; the reference advances a cursor per executed instruction and reads
+ *   buf[(rpos - p) % size] with C's remainder, source/FX8010.cpp:909-967, so only offset 0 is defined):
+ *     - one address counter per TRAM that steps DOWN once per sample period; a tap, read or write, addresses
+ *       (counter + position) mod size (true ring): a value written at position pw is read pr - pw samples later at pr -
+ *       any number of taps per delay line, the kX / DANE convention ("idelay write wrt at 0; idelay read rd at 1439");
+ *     - the position of "idelay read, rd, at, 17" lives in a register of its own, "&rd" (the PDF's GPR "&rd", created with
+ *       the literal as its value), which instructions may name as an operand and write: modulated delay lines;
+ *     - no FXO_OOD flag for offsets (there is nothing out of the domain in a ring).
+ * FX_OPT_TRAM_ADDR_SHIFT  position registers hold DANE addresses, the "Address-Shifting (0x800)" of the PDF: the FX8010
+ *   keeps an address in a register as a 32-bit fixed-point fraction with 0x800 units per sample, so
+ *   position = floatToInt(value) >> 11 = floor(value * 2^20) (floatToInt as source/FX8010.cpp:1016-1020), and a tap declared
+ *   "at 1439" starts with &rd = 1439 * 2^-20.  That keeps addresses inside [-1, 1): MACS / MACSN / INTERP can compute
+ *   them (kX's "macs t, &wrt1, rd_max_shifted, sin_abs"); the low 11 bits (the interpolation fraction) are dropped.
+ * Implemented by the HIP C++ kernel tier (FXB_INFO_KERNEL 0) and by oracle/ (FXO_OPT_*). */
+#define FX_OPT_TRAM_DANE (1u << 0)
+#define FX_OPT_TRAM_ADDR_SHIFT (1u << 1)
+
 typedef struct fx_handle fx_handle;   /* one emulated DSP  */
 typedef struct fxb_handle fxb_handle; /* a batch of N DSPs */
 
@@ -75,6 +96,7 @@ const char* fx_control_at(fx_handle* h, int i);
 int fx_meta_get(fx_handle* h, const char* key, char* buf, int buflen);
 /* setChannels / getChannels / getReadyStatus  include/FX8010.h:73-75 */
 void fx_set_channels(fx_handle* h, int num_channels);
+int fx_set_option(fx_handle* h, unsigned option, int on);
 int fx_get_channels(fx_handle* h);
 int fx_ready(fx_handle* h);
 const char* fx_last_error(fx_handle* h);
@@ -102,6 +124,7 @@ int fxb_shard_count(fxb_handle* h);
 /* device ordinal, first global instance and instance count of a shard; 0 or FX_E_ARG.  Any out pointer may be NULL. */
 int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instance, int64_t* n_instances);
 void fxb_destroy(fxb_handle* h);
+int fxb_set_option(fxb_handle* h, unsigned option, int on);   /* FX_OPT_*: before loading */
 /* as fx_load_file; the program is parsed once on the host and lowered to the device
  * opcode stream.  fxb_load_text takes the program text itself. */
 int fxb_load_file(fxb_handle* h, const char* path);
@@ -193,6 +216,7 @@ int64_t fxb_info(fxb_handle* h, int what);
 typedef struct fxp_handle fxp_handle;
 fxp_handle* fxp_create(int num_channels);
 void fxp_destroy(fxp_handle* h);
+int fxp_set_option(fxp_handle* h, unsigned option, int on);
 int fxp_load_file(fxp_handle* h, const char* path);
 int fxp_load_text(fxp_handle* h, const char* text);
 int fxp_num_registers(fxp_handle* h);

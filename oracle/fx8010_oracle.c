@@ -61,6 +61,7 @@ struct fxo {
     double lut_exp[32][65];
     int ready;
     unsigned ood;
+    unsigned opts;                /* FXO_OPT_*: behaviour beyond the reference, off by default (see fx8010_oracle.h) */
 };
 
 /* ------------------------------------------------------------------ helpers */
@@ -297,6 +298,7 @@ static void syntax_check(fxo_t* f, const char* s, size_t n) {
         size_t t0[4], t1[4]; int nf = 0, ok = 1; size_t q = j;
         while (ok) {
             size_t a = skip_s(s, n, q), b = a;
+            if ((f->opts & FXO_OPT_TRAM_DANE) && b < n && s[b] == '&') ++b;       /* opt-in: &name = position register of a delay tap */
             while (b < n && (is_w(s[b]) || s[b] == '.' || s[b] == '-')) ++b;
             if (b == a || nf == 4) { ok = 0; break; }
             t0[nf] = a; t1[nf] = b; ++nf;
@@ -310,8 +312,22 @@ static void syntax_check(fxo_t* f, const char* s, size_t n) {
         ins_t in; memset(&in, 0, sizeof in);
         in.op = KW_OPS_C[k];
         int idx[4];
+        char tapname[256]; const char* tok[4]; size_t tlen[4];
+        for (int o = 0; o < 4; ++o) { tok[o] = s + t0[o]; tlen[o] = t1[o] - t0[o]; }
+        /* opt-in DANE taps (docs/TRAM Registermapping.pdf p.1): the position of "idelay read, rd, at, 17" lives in a register
+         * of its own, "&rd" (created here with the literal as its value), which other instructions may write */
+        if ((f->opts & FXO_OPT_TRAM_DANE) && (in.op == OP_IDELAY || in.op == OP_XDELAY) && is_number(tok[3], tlen[3]) && tlen[1] + 2 < sizeof tapname
+            && tok[1][0] != '&') {
+            tapname[0] = '&'; memcpy(tapname + 1, tok[1], tlen[1]); tapname[tlen[1] + 1] = 0;
+            if (find_reg(f, tapname, tlen[1] + 1) < 0) {
+                float pos = parse_float(f, tok[3], tlen[3]);                 /* samples; as a DANE address: 0x800 per sample of 2^31 */
+                if (f->opts & FXO_OPT_TRAM_ADDR_SHIFT) pos = pos * 9.5367431640625e-07f;
+                push_reg(f, RT_STATIC, tapname, tlen[1] + 1, pos, 0);
+            }
+            tok[3] = tapname; tlen[3] = tlen[1] + 1;
+        }
         for (int o = 0; o < 4; ++o) {            /* R (:574), A (:608), X (:637), Y (:666), early return on the first failure */
-            idx[o] = map_register(f, s + t0[o], t1[o] - t0[o]);
+            idx[o] = map_register(f, tok[o], tlen[o]);
             if (idx[o] == -1) { push_error(f, ERR_UNDECL, row); return; }
             gpr_t* g = &f->regs[idx[o]];
             if (o == 0) {
@@ -452,6 +468,17 @@ static inline const double* lut_row(fxo_t* f, int kind, float xsel) {
 
 /* TRAM engine: source/FX8010.cpp:909-967 */
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* opt-in DANE delay-line model (NOT reference behaviour; docs/TRAM Registermapping.pdf, kX/DANE convention): one address
+ * counter per TRAM that steps DOWN once per sample period; every tap addresses (counter + position) mod size, so a value
+ * written at position pw is read pr - pw samples later at position pr.  Positions are whole samples, or - with
+ * FXO_OPT_TRAM_ADDR_SHIFT - DANE addresses of 0x800 per sample. */
+static int dane_slot(fxo_t* f, int size, int base, float value) {
+    /* a position register holds whole samples, or (ADDR_SHIFT) a DANE address as the fixed-point fraction the FX8010 keeps in
+     * its registers: address = value * 2^31 (the reference's floatToInt, FX8010.cpp:1016-1020), 0x800 of them per sample */
+    int position = (f->opts & FXO_OPT_TRAM_ADDR_SHIFT) ? (cvtt_f32(value * 2147483648.0f) >> 11) : cvtt_f32(value);
+    long idx = ((long)base + position) % size;
+    return (int)(idx < 0 ? idx + size : idx);
+}
 static void tram_write(fxo_t* f, float* buf, int cap, int size, int* wpos, float sample, int position) {
     if (size <= 0) { f->ood |= FXO_OOD_TRAM_SIZE0; return; }
     position = position > size - 1 ? size - 1 : position; position = position < 0 ? 0 : position; /* max(0,min(p,size-1)) */
@@ -545,12 +572,24 @@ void fxo_process(fxo_t* f, const float* in, float* out) {
                     double d = (1.0 - (double)X->value) * (double)A->value + (double)p;
                     float r = (float)d; f->acc = r; R->value = saturate(r, 1.0f); set_ccr(f, R->value); break; }
                 case OP_IDELAY:                                              /* :1188-1199 */
+                    if ((f->opts & FXO_OPT_TRAM_DANE) && (R->type == RT_READ || R->type == RT_WRITE)) {
+                        if (f->itram_size <= 0) { f->ood |= FXO_OOD_TRAM_SIZE0; if (R->type == RT_READ) A->value = 0.0f; break; }
+                        const int slot = dane_slot(f, f->itram_size, f->iw, Y->value);
+                        if (R->type == RT_READ) A->value = f->itram[slot]; else f->itram[slot] = A->value;
+                        break;
+                    }
                     if (R->type == RT_READ) A->value = tram_read(f, f->itram, MAX_IDELAY_SIZE, f->itram_size, &f->ir, cvtt_f32(Y->value));
                     else if (R->type == RT_WRITE) tram_write(f, f->itram, MAX_IDELAY_SIZE, f->itram_size, &f->iw, A->value, cvtt_f32(Y->value));
                     break;
                 case OP_XDELAY:                                              /* :1200-1211 */
                     if (R->type == RT_READ || R->type == RT_WRITE) {
                         if (!f->xtram) f->xtram = (float*)calloc(MAX_XDELAY_SIZE, sizeof(float));
+                        if (f->opts & FXO_OPT_TRAM_DANE) {
+                            if (f->xtram_size <= 0) { f->ood |= FXO_OOD_TRAM_SIZE0; if (R->type == RT_READ) A->value = 0.0f; break; }
+                            const int slot = dane_slot(f, f->xtram_size, f->xw, Y->value);
+                            if (R->type == RT_READ) A->value = f->xtram[slot]; else f->xtram[slot] = A->value;
+                            break;
+                        }
                         if (R->type == RT_READ) A->value = tram_read(f, f->xtram, MAX_XDELAY_SIZE, f->xtram_size, &f->xr, cvtt_f32(Y->value));
                         else tram_write(f, f->xtram, MAX_XDELAY_SIZE, f->xtram_size, &f->xw, A->value, cvtt_f32(Y->value));
                     }
@@ -566,6 +605,10 @@ void fxo_process(fxo_t* f, const float* in, float* out) {
         }
         if (!is_end && ++passes >= PASS_CAP) { f->ood |= FXO_OOD_PASS_CAP; break; }
     } while (!is_end);                                                       /* :1243 */
+    if (f->opts & FXO_OPT_TRAM_DANE) {           /* opt-in: the address counters step once per sample period */
+        if (f->itram_size > 0) f->iw = (f->iw + f->itram_size - 1) % f->itram_size;
+        if (f->xtram_size > 0) f->xw = (f->xw + f->xtram_size - 1) % f->xtram_size;
+    }
     for (int c = 0; c < f->channels; ++c) out[c] = f->outbuf[c];             /* :1248 */
 }
 
@@ -587,6 +630,7 @@ int64_t fxo_instruction_counter(fxo_t* f) { return f->icount; } /* :986-989 */
 int fxo_ready(fxo_t* f) { return f->ready; }
 int fxo_channels(fxo_t* f) { return f->channels; }
 unsigned fxo_ood_flags(fxo_t* f) { return f->ood; }
+void fxo_set_option(fxo_t* f, unsigned option, int on) { if (on) f->opts |= option; else f->opts &= ~option; }
 void fxo_seed_noise(fxo_t* f, int32_t x1, int32_t x2) { f->g_x1 = x1; f->g_x2 = x2; }
 int fxo_error_count(fxo_t* f) { return f->nerrs; }
 const char* fxo_error_desc(fxo_t* f, int i) { return (i < 0 || i >= f->nerrs) ? "" : f->errs[i].desc; }

@@ -28,6 +28,12 @@ enum {
     FXO_OOD_PARSE = 1 << 6           /* loader input on which the reference throws (stoi/stof) */
 };
 
+/* behaviour beyond the reference, off by default: the same switches as the product's FX_OPT_* (include/fx8010_amd.h) */
+enum {
+    FXO_OPT_TRAM_DANE = 1 << 0,       /* DANE delay-line model: per-sample address counter, ring taps, &name tap registers */
+    FXO_OPT_TRAM_ADDR_SHIFT = 1 << 1  /* tap positions are DANE addresses (0x800 per sample) */
+};
+
 fxo_t* fxo_create(int channels);
 void fxo_destroy(fxo_t*);
 int fxo_load_file(fxo_t*, const char* path); /* 1 = ok, 0 = failed (see error list) */
@@ -41,6 +47,7 @@ int fxo_ready(fxo_t*);
 int fxo_channels(fxo_t*);
 unsigned fxo_ood_flags(fxo_t*);
 void fxo_seed_noise(fxo_t*, int32_t x1, int32_t x2);
+void fxo_set_option(fxo_t*, unsigned option, int on);   /* before loading: FXO_OPT_* */
 
 int fxo_error_count(fxo_t*);
 const char* fxo_error_desc(fxo_t*, int i);

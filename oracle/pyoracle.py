@@ -175,6 +175,8 @@ class Oracle(_Base):
             lib.fxo_ood_flags.argtypes = [C.c_void_p]
             lib.fxo_ood_flags.restype = C.c_uint
             lib.fxo_seed_noise.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+            lib.fxo_set_option.argtypes = [C.c_void_p, C.c_uint, C.c_int]
+            lib.fxo_set_option.restype = None
             lib.fxo_num_registers.argtypes = [C.c_void_p]
             lib.fxo_register_name.argtypes = [C.c_void_p, C.c_int]
             lib.fxo_register_name.restype = C.c_char_p
@@ -202,6 +204,10 @@ class Oracle(_Base):
 
     def ood_flags(self):
         return int(self._lib.fxo_ood_flags(self._h))
+
+    def set_option(self, option, on=True):
+        """FXO_OPT_* (1 = DANE delay-line model, 2 = DANE address shift): behaviour beyond the reference; before loading"""
+        self._lib.fxo_set_option(self._h, C.c_uint(option), 1 if on else 0)
 
     def seed_noise(self, x1, x2):
         self._lib.fxo_seed_noise(self._h, C.c_int32(x1), C.c_int32(x2))

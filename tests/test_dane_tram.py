@@ -1,0 +1,158 @@
+"""Opt-in DANE delay-line model (FX_OPT_TRAM_DANE / FX_OPT_TRAM_ADDR_SHIFT, include/fx8010_amd.h): NOT reference behaviour
+(the reference's own design note docs/TRAM Registermapping.pdf describes it; its code defines offset 0 only), so there
+is no golden vector from the reference - the checker is oracle/ with the same switch, pinned here by the delay-line
+properties themselves (CPU tests), and the GPU path is compared with it bit for bit (gpu tests).  With the options off
+nothing changes: every other test in this directory runs with them off."""
+import numpy as np
+import pytest
+
+import fx8010_programs as progs
+from pyoracle import Oracle
+
+OPT_DANE, OPT_SHIFT = 1, 2
+
+TWO_TAPS = """itramsize 64 
+xtramsize 500 
+input in 0
+output out 0
+static w
+static r1
+static r2
+static xr
+idelay write, w, at, 0
+idelay read, r1, at, 7
+idelay read, r2, at, 19
+xdelay write, in, at, 3
+xdelay read, xr, at, 403
+macs w, in, 0, 0
+macs out, r1, r2, 0.5
+end"""
+
+CHORUS = """itramsize 2880 
+input in 0
+output out 0
+static wrt
+static rd1
+static rd2
+static lfo = 0.25
+static cosv = 0.9
+static t
+control speed = 0.3
+control depth = 0.0008
+idelay write, in, at, 0
+idelay read, rd1, at, 1439
+idelay read, rd2, at, 700
+macs lfo, lfo, speed, cosv
+macsn cosv, cosv, speed, lfo
+macs &rd1, 0.0013, lfo, depth
+macs t, rd1, rd2, 0.5
+macs out, 0, t, 0.5
+end"""
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_taps_are_delays_of_their_position_difference():
+    """a value written at position pw comes back pr - pw samples later at position pr; any number of taps per line"""
+    o = Oracle(1)
+    o.set_option(OPT_DANE)
+    assert o.load_text(TWO_TAPS), o.errors()
+    x = np.zeros(600, np.float32)
+    x[0], x[5] = 1.0, -0.5
+    y = o.process_block(x)
+    # w = in one instruction after the write tap: the impulse enters the line at sample 1; taps at 7 and 19
+    want = np.zeros(600, np.float32)
+    for t0, v in ((0, 1.0), (5, -0.5)):
+        want[t0 + 1 + 7] += v
+        want[t0 + 1 + 19] += 0.5 * v
+    assert np.array_equal(bits(y), bits(want))
+    assert o.get_register_bits("&r1") == bits(np.float32(7.0))[()] and o.get_register_bits("&r2") == bits(np.float32(19.0))[()]
+    assert o.ood_flags() == 0
+    # the xTRAM line: written at 3, read at 403: 400 samples
+    o2 = Oracle(1)
+    o2.set_option(OPT_DANE)
+    assert o2.load_text(TWO_TAPS.replace("macs out, r1, r2, 0.5", "macs out, 0, xr, 1.0"))
+    y2 = o2.process_block(x)
+    assert y2[400] == 1.0 and y2[405] == -0.5 and np.count_nonzero(y2) == 2
+
+
+def test_reference_mode_rejects_the_tap_register_syntax_and_keeps_its_cursor_model():
+    o = Oracle(1)
+    assert not o.load_text(CHORUS)  # '&' is not an operand character of the reference dialect
+    o = Oracle(1)
+    assert o.load_text(TWO_TAPS)    # the same text IS a reference program: cursor per executed instruction, offsets flagged
+    o.process_block(np.ones(30, np.float32))
+    assert o.ood_flags() != 0       # read offsets > cursor: outside the parity domain there
+
+
+def test_address_shift_positions_are_fixed_point_fractions():
+    """with FX_OPT_TRAM_ADDR_SHIFT a tap 'at 1439' starts as 1439 * 2^-20 and addresses floor(value * 2^20) samples"""
+    o = Oracle(1)
+    o.set_option(OPT_DANE)
+    o.set_option(OPT_SHIFT)
+    assert o.load_text(CHORUS.replace("macs &rd1, 0.0013, lfo, depth\n", "")), o.errors()
+    assert o.get_register_bits("&rd1") == bits(np.float32(1439.0 * 2.0 ** -20))[()]
+    x = np.zeros(1600, np.float32)
+    x[0] = 1.0
+    y = o.process_block(x)
+    assert y[700] == 0.25 and y[1439] == 0.5 and np.count_nonzero(y) == 2  # out = 0.5 * (rd1 + 0.5 * rd2)
+    # a position written by the program: 100.7 samples -> tap at 100
+    o.set_register("&rd2", float(np.float32(100.7 * 2.0 ** -20)))
+    y = o.process_block(x)
+    assert y[100] == 0.25
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [False, True], ids=["sample_positions", "dane_addresses"])
+@pytest.mark.parametrize("text", [TWO_TAPS, CHORUS], ids=["two_taps", "modulated_chorus"])
+def test_gpu_matches_the_oracle_in_the_dane_model(gpu, text, shift, monkeypatch):
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    if shift and text is TWO_TAPS:
+        pytest.skip("literal positions only: the shifted form is covered by the chorus")
+    n, s = 150, 3100
+    x = progs.stimulus(n, s)
+    b = gpu.Batch(n, 1, 0)
+    b.set_option(gpu.OPT_TRAM_DANE)
+    if shift:
+        b.set_option(gpu.OPT_TRAM_ADDR_SHIFT)
+    assert b.load_text(text), b.errors()
+    if text is CHORUS:  # per-instance modulation depth and speed: every lane addresses its own slots
+        b.set_register_array("depth", np.linspace(0.0, 0.0012 if shift else 0.9, n).astype(np.float32))
+        b.set_register_array("speed", np.linspace(0.05, 0.6, n).astype(np.float32))
+    ys = [b.process_block(x[:1000]), b.process_block(x[1000:])]
+    y = np.concatenate(ys, axis=0)
+    assert b.info("kernel") == 0  # the HIP C++ kernel implements the opt-in model
+    assert b.ood_flags() == 0
+    for inst in (0, 63, 64, 99, n - 1):
+        o = Oracle(1)
+        o.set_option(OPT_DANE)
+        if shift:
+            o.set_option(OPT_SHIFT)
+        assert o.load_text(text)
+        if text is CHORUS:
+            o.set_register("depth", float(np.linspace(0.0, 0.0012 if shift else 0.9, n).astype(np.float32)[inst]))
+            o.set_register("speed", float(np.linspace(0.05, 0.6, n).astype(np.float32)[inst]))
+        ref = o.process_block(x[:, inst].copy())
+        assert np.array_equal(bits(ref), bits(y[:, inst])), inst
+        assert b.instruction_counter_i(inst) == o.instruction_counter()
+        for r in ("out", "ccr") + (("&rd1", "lfo") if text is CHORUS else ("&r1", "w")):
+            assert b.get_register_bits_i(r, inst) == o.get_register_bits(r), (inst, r)
+
+
+@pytest.mark.gpu
+def test_options_off_is_the_reference(gpu):
+    """the same two-tap text without the option: reference cursor model, domain flags - and identical to the oracle without it"""
+    n, s = 70, 40
+    x = progs.stimulus(n, s)
+    b = gpu.Batch(n, 1, 0)
+    assert b.load_text(TWO_TAPS)
+    y = b.process_block(x)
+    o = Oracle(1)
+    assert o.load_text(TWO_TAPS)
+    ref = o.process_block(x[:, 9].copy())
+    assert np.array_equal(bits(ref), bits(y[:, 9])) and b.ood_flags() == o.ood_flags() != 0
+    b2 = gpu.Batch(n, 1, 0)
+    assert not b2.load_text(CHORUS)
