@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5", "tram_bound"])
+    ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5", "tram_bound", "config5_dane"])
     ap.add_argument("--samples", type=int, default=4096, help="sample periods per step (block length S; SURVEY 8d: 4096)")
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (0 = BASELINE.json's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only); 0 disables")
@@ -138,7 +138,7 @@ def cpu_baseline(text, budget_s):
         os.unlink(path)
 
 
-def parity_check(text, y_last, n_inst, first_instance, n_samples, blocks, want):
+def parity_check(text, y_last, n_inst, first_instance, n_samples, blocks, want, option=0):
     """After the timed region: `want` instances spread over the shard (plus lanes 0 / 63 / the last one) are replayed on the
     CPU oracle - all `blocks` launches of the run, state carried from block to block as on the device - and the device's
     output of the LAST block is compared bit for bit.  y_last: callable instance -> numpy [S] of the device output."""
@@ -156,6 +156,8 @@ def parity_check(text, y_last, n_inst, first_instance, n_samples, blocks, want):
 
     def one(n):
         o = Oracle(1)
+        if option:
+            o.set_option(option)
         if not o.load_text(text):
             return n, False
         x = progs.stimulus(1, n_samples, first_instance=first_instance + n)[:, 0].copy()
@@ -192,6 +194,9 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
     P = progs.count_instructions(text)
     sharded = len(devices) > 1
     batch = fx8010_amd.Batch(n_inst * len(devices), 1, devices=devices) if sharded else fx8010_amd.Batch(n_inst, 1, devices[0])
+    option = getattr(progs, "CONFIG_OPTIONS", {}).get(config, 0)  # opt-in behaviour beyond the reference (config5_dane)
+    if option:
+        batch.set_option(option)
     if not batch.load_text(text):
         raise RuntimeError("program failed to load: %s" % batch.errors())
     first_instance, _ = shard.weak_shard(n_inst, rank)  # weak scaling: every GPU owns n_inst instances
@@ -258,7 +263,7 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
                     return ys[k][:, n - f].cpu().numpy()
             raise IndexError(n)
 
-        parity = parity_check(text, y_last, n_inst * len(devices), first_instance, S, warmup + steps, parity_n)
+        parity = parity_check(text, y_last, n_inst * len(devices), first_instance, S, warmup + steps, parity_n, option)
 
     res = None
     if rank == 0:

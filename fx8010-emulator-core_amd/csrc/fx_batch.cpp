@@ -99,6 +99,7 @@ int Batch::afterLoad(bool ok) {
     forcedLane_.resize(prog_.regs.size(), 0);
     for (size_t r = old; r < prog_.regs.size(); ++r) hostValue_[r] = prog_.regs[r].value;
     lowDirty_ = true;
+    daneHipOnly_ = false;
     // a load that failed after an earlier good one has still appended registers (literals and declarations are created
     // before the error, as in the reference): the state block must follow, or set_register of a new one would land in
     // the rows behind the registers (output latches, cursors, LFSR, counter)
@@ -227,7 +228,7 @@ int Batch::ensureLowered() {
     bool asmOk = false;
     const bool tramPinned = iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0;
     const char* forceHip = std::getenv("FX_KERNEL");
-    const bool wantAsm = !(forceHip && std::strcmp(forceHip, "hip") == 0) && !std::getenv("FX_INST_PER_LANE");
+    const bool wantAsm = !(forceHip && std::strcmp(forceHip, "hip") == 0) && !std::getenv("FX_INST_PER_LANE") && !daneHipOnly_;
     if (wantAsm && (!tramPinned || instPerLane_ == 1)) {
         // first choice: register file in VGPRs (row pitch 1 = plain indices), else in LDS
         const bool tryVgpr = !(forceHip && std::strcmp(forceHip, "asm_lds") == 0);
@@ -252,6 +253,11 @@ int Batch::ensureLowered() {
             fresh = lowerProgram(prog_, hostValue_, laneForced(), 1, false);
             asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
             asmVariant_ = ASM_LDS;
+        }
+        // the opt-in DANE delay-line model exists as generated code (translated tier) and in the HIP C++ kernel only
+        if (asmOk && fresh.tramDane && (asmVariant_ == ASM_LDS || (forceHip && std::strncmp(forceHip, "asm", 3) == 0))) {
+            asmOk = false;
+            asmWhyNot_ = "opt-in DANE delay-line model: no interpreter handlers";
         }
     } else {
         asmWhyNot_ = "disabled by FX_KERNEL / FX_INST_PER_LANE";
@@ -281,7 +287,7 @@ int Batch::ensureLowered() {
     xlateDeferred_ = false;
     // (a block of more than ~half a millisecond of translated code pays for its translation at once)
     const double blockMs = (double)n_ * (double)pendingSamples_ * (double)std::max(low_.staticCount, 1) / 1e10;
-    if (useAsm_ && asmVariant_ != ASM_LDS && controlHeat_ > 0 && blockMs < 0.5 && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0)) {
+    if (useAsm_ && asmVariant_ != ASM_LDS && controlHeat_ > 0 && blockMs < 0.5 && !low_.tramDane && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0)) {
         // controls are moving (a set_register within the last few blocks): a translation costs a module load
         // (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until the controls have been quiet
         xlateDeferred_ = true;
@@ -317,6 +323,10 @@ int Batch::ensureLowered() {
             xlateValu_ = image.steady.valu;
             useXlate_ = true;
         }
+    }
+    if (useAsm_ && !useXlate_ && low_.tramDane) {  // (translation failed: e.g. code larger than the hole) -> HIP C++ kernel
+        daneHipOnly_ = true;
+        return ensureLowered();
     }
     if (useAsm_ && !useXlate_) {
         hipError_t pe = hipSuccess;

@@ -123,6 +123,7 @@ private:
     int controlHeat_ = 0;
     int pendingSamples_ = 0;  // block length of the call that triggered the lowering
     bool xlateDeferred_ = false, everLowered_ = false;
+    bool daneHipOnly_ = false;  // a DANE-model program that the translator could not take: HIP C++ kernel from now on
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;
     size_t streamCap_ = 0;

@@ -443,6 +443,8 @@ constexpr int kSTrackPtr[kMaxTracks] = {26, 30, 70};    // s[26:27] / s[30:31] /
 constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
 
+int32_t danePosition(uint32_t bits, bool shifted, int32_t size);  // (defined with the hoist planning below)
+
 class Translator {
   public:
     // exactReturns == nullptr: the exact stream (NaN passes every saturation).  Otherwise the fast stream, which
@@ -525,7 +527,7 @@ class Translator {
                 e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSHoistOk), imm32(0));
                 Emitter::Fixup skip = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
                 for (int k = 0; k < H.leadCount; ++k)
-                    if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false)) { if (err) *err = err_; return false; }
+                    if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false, true)) { if (err) *err = err_; return false; }
                 e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSPrefetched), imm32(1));
                 e_.bind(skip);
             }
@@ -543,6 +545,7 @@ class Translator {
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(q + 1), sreg(q + 1), imm32(0));
         }
         e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSample), sreg(kSSample), imm32(1));
+        if (prog_.tramDane && prog_.uniformCursors) daneStep();
         if (!isLast_) {
             // loop while the sample after this one is not the block's last, then on to the last-sample stream
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSSample), imm32(1));
@@ -857,7 +860,33 @@ class Translator {
     }
     // deferred: a read in the middle of the program (its row is waited for at its first use); otherwise a leading read,
     // whose wait is the head of the sample loop
-    bool tramRead(const MicroOp& r, uint32_t slot, bool deferred) {
+    // opt-in DANE model: slot = (counter + position) mod size, counter in s80 (iTRAM) / s82 (xTRAM); `ahead`: the read belongs
+    // to the NEXT sample, whose counter is one lower
+    void daneSlot(const MicroOp& r, int t, int32_t size, bool ahead) {
+        int32_t q = danePosition(r.w[4], (r.w[6] & 32u) != 0, size);
+        if (ahead) q = (q - 1 + size) % size;
+        const int counter = kSCursor + 2 * t;
+        e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(counter), imm32((uint32_t)q));
+        e_.sopc(SOPC_CMP_GE_I32, "s_cmp_ge_i32", sreg(kSPos), sreg(kSTramSize[t]));
+        Emitter::Fixup inRing = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSPos), sreg(kSPos), sreg(kSTramSize[t]));
+        e_.bind(inRing);
+    }
+    // end of a sample period in the DANE model: both address counters step down
+    void daneStep() {
+        for (int t = 0; t < 2; ++t) {
+            const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
+            if (size < 1) continue;
+            const int counter = kSCursor + 2 * t;
+            e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(counter), sreg(counter), imm32(1));
+            e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", sreg(counter), imm32(0));
+            Emitter::Fixup fine = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+            e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(counter), sreg(counter), sreg(kSTramSize[t]));
+            e_.bind(fine);
+        }
+    }
+
+    bool tramRead(const MicroOp& r, uint32_t slot, bool deferred, bool ahead = false) {
         const int t = tramOf(slot);
         const int cursor = kSCursor + 2 * t + 1;
         const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
@@ -872,9 +901,11 @@ class Translator {
             e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
             return true;
         }
-        const int32_t p = tramOffset(r, size);
+        const int32_t p = prog_.tramDane ? 1 : tramOffset(r, size);
         const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
-        if (p != 0) {
+        if (prog_.tramDane) {
+            daneSlot(r, t, size, ahead);
+        } else if (p != 0) {
             e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
             e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", sreg(kSPos), imm32(0));
             Emitter::Fixup inRange = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
@@ -894,7 +925,7 @@ class Translator {
         e_.cold(false);
         e_.bind(done);
         if (deferred) pending_.push_back(vR);
-        advanceCursor(cursor, t);
+        if (!prog_.tramDane) advanceCursor(cursor, t);
         return true;
     }
     bool tramWrite(const MicroOp& r, uint32_t slot) {
@@ -907,12 +938,13 @@ class Translator {
             e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
             return true;
         }
-        const int32_t p = tramOffset(r, size);
+        const int32_t p = prog_.tramDane ? 1 : tramOffset(r, size);
         const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
         int vA = 2;
         if (r.w[6] & 1u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));
         else if (!row(r.w[2], &vA)) return false;
-        if (p != 0) e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
+        if (prog_.tramDane) daneSlot(r, t, size, false);
+        else if (p != 0) e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
         e_.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSAddr), sreg(kSTramSlots[t]), imm32(t == 0 ? 8192u : 1048576u, true));
         e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSAddr));
         Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
@@ -923,7 +955,7 @@ class Translator {
         e_.waitVmcnt(0);
         e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
         e_.bind(done);
-        advanceCursor(cursor, t);
+        if (!prog_.tramDane) advanceCursor(cursor, t);
         return true;
     }
     bool tram(const MicroOp& r, uint32_t slot) {
@@ -1685,6 +1717,25 @@ int32_t truncX86(uint32_t bits) {  // cvttss2si: 0x80000000 for NaN and anything
     return (int32_t)f;
 }
 
+// tap position of the opt-in DANE model from a uniform operand: whole samples, or a DANE address fraction (value * 2^31,
+// 0x800 per sample); reduced to 0 .. size-1
+int32_t danePosition(uint32_t bits, bool shifted, int32_t size) {
+    int64_t q;
+    if (shifted) {
+        float f;
+        std::memcpy(&f, &bits, 4);
+        const float scaled = f * 2147483648.0f;
+        uint32_t sb;
+        std::memcpy(&sb, &scaled, 4);
+        q = truncX86(sb) >> 11;
+    } else {
+        q = truncX86(bits);
+    }
+    if (size < 1) return 0;
+    q %= size;
+    return (int32_t)(q < 0 ? q + size : q);
+}
+
 // Which TRAM reads can be issued one sample ahead, where, and for which cursor distances that is unsafe (fx_xlate.hpp HoistPlan)
 HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, const XlateProgram& p) {
     HoistPlan H;
@@ -1695,6 +1746,7 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
     auto sizeOf = [&](int t) { return t == 0 ? p.iSize : p.xSize; };
     auto offsetOf = [&](const MicroOp& r) {
         const int32_t size = sizeOf(tramOf(r.w[0]));
+        if (p.tramDane) return danePosition(r.w[4], (r.w[6] & 32u) != 0, size);
         int32_t q = truncX86(r.w[4]);
         q = q > size - 1 ? size - 1 : q;
         return q < 0 ? 0 : q;
@@ -1705,7 +1757,7 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
     while ((size_t)lead < steady.size() && (size_t)lead < last.size() && lead < 32) {
         const MicroOp& r = steady[(size_t)lead];
         if (!isRead(r.w[0]) || last[(size_t)lead].w[0] != r.w[0] || last[(size_t)lead].w[5] != r.w[5] || last[(size_t)lead].w[4] != r.w[4]) break;
-        if (sizeOf(tramOf(r.w[0])) < 1 || offsetOf(r) != 0 || std::find(rows.begin(), rows.end(), r.w[5]) != rows.end()) break;
+        if (sizeOf(tramOf(r.w[0])) < 1 || (!p.tramDane && offsetOf(r) != 0) || std::find(rows.begin(), rows.end(), r.w[5]) != rows.end()) break;
         rows.push_back(r.w[5]);
         ++lead;
     }
@@ -1754,7 +1806,17 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
         }
     }
     // writes the early reads overtake: those behind the hoist point
-    for (int t = 0; t < 2; ++t) {
+    if (p.tramDane) {
+        // DANE model: next sample's read of position q uses slot (counter - 1 + q); a write of this sample at position pw
+        // uses (counter + pw): the same slot iff pw == q - 1 (mod size) - all constants, decided here
+        for (int k = 0; k < lead; ++k) {
+            const int t = tramOf(steady[(size_t)k].w[0]);
+            const int64_t size = sizeOf(t), q = offsetOf(steady[(size_t)k]);
+            for (size_t i = (size_t)at + 1; i < steady.size(); ++i)
+                if (isWrite(steady[i].w[0]) && tramOf(steady[i].w[0]) == t && offsetOf(steady[i]) == (q - 1 + size) % size) return H;
+        }
+    }
+    for (int t = 0; t < 2 && !p.tramDane; ++t) {
         if (nLead[t] == 0) continue;
         std::vector<int> later;  // index among the TRAM's writes of a sample
         int w = 0;
@@ -1803,7 +1865,10 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
             else if (slot == AS_UNPRED) shadow = false;
             else if (slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
                 any = true;
-                if (shadow || !(r.w[6] & 4u)) ok = false;
+                if (r.w[6] & 16u) p.tramDane = true;  // (all TRAM records of a program carry the flag, or none)
+                // reference model: a shadowed TRAM instruction makes the lanes' cursors diverge; DANE model: the counter
+                // steps per sample whatever executes, so only the position has to be uniform
+                if ((shadow && !(r.w[6] & 16u)) || !(r.w[6] & 4u)) ok = false;
             }
         }
     }

@@ -72,6 +72,7 @@ struct TrackHeader {
 struct XlateProgram {
     int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
     bool uniformCursors = false;  // all lanes' TRAM cursors move together: kept in SGPRs, TRAM instructions inline
+    bool tramDane = false;        // opt-in DANE delay-line model: s80 / s82 are per-sample address counters, taps at (counter + position) mod size
     // LOG/EXP tables in LDS: the fp32 thresholds, x1[] and the {slope, y1} arrays of the tables the program uses
     // (lutTables = their byte offsets in the LUT blob, in LDS order); empty = tables are read from global memory
     std::vector<uint32_t> lutTables;

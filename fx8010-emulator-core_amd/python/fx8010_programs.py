@@ -191,6 +191,20 @@ def tram_bound(pairs=16):
     return "\n".join(L + body + ["end"])
 
 
+def config5_dane(pairs=4):
+    """config5's 512-instruction reverb in the kX / DANE convention (opt-in FX_OPT_TRAM_DANE, NOT reference behaviour): the
+    four read taps sit at different positions of the line, the four writes at positions 0..3 - multi-tap delay lines."""
+    text = config5(pairs)
+    taps = (1187, 2909, 4523, 7919, 1601, 3301, 5003, 6997)
+    for j in range(pairs):
+        text = text.replace("xdelay read, d%d, at, 0" % j, "xdelay read, d%d, at, %d" % (j, taps[j]))
+        text = text.replace("xdelay write, w%d, at, 0" % j, "xdelay write, w%d, at, %d" % (j, j))
+    return text
+
+
+# programs that need an option of the library (FX_OPT_*) before loading
+CONFIG_OPTIONS = {"config5_dane": 1}
+
 CONFIGS = {
     "config1_shipped": config1_shipped,
     "config1_logtube": config1_logtube,
@@ -199,10 +213,11 @@ CONFIGS = {
     "config4": config4,
     "config5": config5,
     "tram_bound": tram_bound,
+    "config5_dane": config5_dane,
 }
 
 # instances / samples BASELINE.json quotes per config (config 5: per-GPU shard of 2 097 152 / 8)
-CONFIG_INSTANCES = {"config1_shipped": 1, "config1_logtube": 1, "config2": 4096, "config3": 65536, "config4": 262144, "config5": 262144, "tram_bound": 262144}
+CONFIG_INSTANCES = {"config1_shipped": 1, "config1_logtube": 1, "config2": 4096, "config3": 65536, "config4": 262144, "config5": 262144, "tram_bound": 262144, "config5_dane": 262144}
 
 
 def count_instructions(text):

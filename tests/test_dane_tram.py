@@ -124,7 +124,8 @@ def test_gpu_matches_the_oracle_in_the_dane_model(gpu, text, shift, monkeypatch)
         b.set_register_array("speed", np.linspace(0.05, 0.6, n).astype(np.float32))
     ys = [b.process_block(x[:1000]), b.process_block(x[1000:])]
     y = np.concatenate(ys, axis=0)
-    assert b.info("kernel") == 0  # the HIP C++ kernel implements the opt-in model
+    # static taps are generated inline by the translator; per-instance positions (the modulated chorus) run on the HIP C++ kernel
+    assert (b.info("kernel") >= 9) == (text is TWO_TAPS)
     assert b.ood_flags() == 0
     for inst in (0, 63, 64, 99, n - 1):
         o = Oracle(1)
@@ -156,3 +157,48 @@ def test_options_off_is_the_reference(gpu):
     assert np.array_equal(bits(ref), bits(y[:, 9])) and b.ood_flags() == o.ood_flags() != 0
     b2 = gpu.Batch(n, 1, 0)
     assert not b2.load_text(CHORUS)
+
+
+REVERB_DANE = None
+
+
+def dane_reverb():
+    """config5's reverb shape in the DANE convention: ONE write tap per line, reads at different positions of the same line"""
+    L = ["xtramsize 8192 ", "input in 0", "output out 0", "control damp = 0.3", "control decay = 0.45", "static m", "static w"]
+    taps = (1187, 2909, 4523, 7919)
+    L += ["static d%d" % j for j in range(4)] + ["static lp%d" % j for j in range(4)]
+    L += ["xdelay read, d%d, at, %d" % (j, taps[j]) for j in range(4)]
+    L += ["interp lp%d, lp%d, damp, d%d" % (j, j, j) for j in range(4)]
+    L += ["acc3 m, lp0, lp1, lp2", "macs m, m, lp3, 1.0", "macs m, 0, m, 0.25", "macs w, in, m, decay", "xdelay write, w, at, 0", "macs out, 0, m, 0.5", "end"]
+    return "\n".join(L)
+
+
+@pytest.mark.gpu
+def test_static_multi_tap_line_translated_with_reads_a_sample_ahead(gpu, monkeypatch):
+    """four taps on one line + one write: generated inline, the taps' loads issued one sample ahead (the collision rule is a
+    translate-time constant in this model), across block boundaries; vs the oracle"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    n, s = 200, 9000
+    text = dane_reverb()
+    x = progs.stimulus(n, s)
+    b = gpu.Batch(n, 1, 0)
+    b.set_option(gpu.OPT_TRAM_DANE)
+    assert b.load_text(text), b.errors()
+    y = np.concatenate([b.process_block(x[:1]), b.process_block(x[1:4000]), b.process_block(x[4000:])], axis=0)
+    assert b.info("kernel") >= 9 and b.ood_flags() == 0
+    for inst in (0, 64, n - 1):
+        o = Oracle(1)
+        o.set_option(OPT_DANE)
+        assert o.load_text(text)
+        ref = o.process_block(x[:, inst].copy())
+        assert np.array_equal(bits(ref), bits(y[:, inst])), inst
+    # a write one position below a tap is the slot that tap reads NEXT sample: the early read must stay in place
+    clash = text.replace("xdelay write, w, at, 0", "xdelay write, w, at, 1186")
+    b2 = gpu.Batch(n, 1, 0)
+    b2.set_option(gpu.OPT_TRAM_DANE)
+    assert b2.load_text(clash)
+    y2 = b2.process_block(x[:3000])
+    o = Oracle(1)
+    o.set_option(OPT_DANE)
+    assert o.load_text(clash)
+    assert np.array_equal(bits(o.process_block(x[:3000, 5].copy())), bits(y2[:, 5]))

@@ -138,6 +138,24 @@ def test_structure_of_translated_code():
                 assert len(back) == 1, (name, "one loop branch to the head")
 
 
+@needs_llvm
+def test_dane_model_listing_reassembles_and_has_no_cursor_advance():
+    """opt-in DANE delay-line model: taps at (counter + position) mod size generated inline, counters stepped at the end of the
+    sample, next sample's taps loaded early with the translate-time collision rule"""
+    fe = A.FrontEnd(1)
+    fe.set_option(A.OPT_TRAM_DANE)
+    assert fe.load_text(P.CONFIGS["config5_dane"]()), fe.errors()
+    for stream in (0, 1, 2, 3, 4):
+        code, listing = fe.translate(0, stream)
+        assert assemble(listing) == code
+    code, listing = fe.translate(0, 0)
+    assert listing.count("global_load_dword") >= 8 + 1   # 4 taps in place (first sample) + 4 early + the PCM input
+    assert "s_cmp_eq_u32 s95, 0" in listing                # the early reads are compiled in
+    assert listing.count("s_sub_i32 s82, s82, 1") == 1     # one step of the xTRAM counter per sample, nothing per instruction
+    fe2 = A.FrontEnd(1)
+    assert not fe2.load_text(P.CONFIGS["config5_dane"]().replace("at, 1187", "at, &d0"))  # without the option: reference syntax only
+
+
 def test_translate_reports_ineligible_programs():
     fe = A.FrontEnd(1)
     # SKIP over END: multi-pass program, runs on the HIP C++ kernel instead
