@@ -798,16 +798,25 @@ class Translator {
         if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
         e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // x >= xthr[g+1]: one up
         e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));      // x <  xthr[g]  : one down
+        // the segment arithmetic goes ahead on the guess while the scalar unit makes up its mind (the compares' results
+        // reach it a pipeline later: checking first would stall the wave twice per LOG/EXP); a miss redoes it below
+        auto segmentMath = [&]() {
+            e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
+            e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(12), vreg64(2), vreg64(12), nullptr);
+            e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(4), nullptr);
+        };
+        segmentMath();
         e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTemp + 2), vcc, sreg64(kSTemp));
         e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTemp + 2), imm32(0));
-        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");  // (s_cbranch_vccz would save the compare, but VCC must survive for the miss path)
-        // (two instructions lie between the VALU writes of VCC / the SGPR pair and the VALU reads below)
+        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
         e_.cold(true);
         e_.addCarry(6);
         e_.subBorrow(6, kSTemp, kSTemp + 2);
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
         fetchSegment(false);
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
         if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
+        segmentMath();
         e_.cold(false);
         e_.bind(hit);
         if (guarded) {
@@ -826,9 +835,6 @@ class Translator {
             e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(7), zero, flag, &vcc);
             e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, vreg(kVOod), 7);
         }
-        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
-        e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(12), vreg64(2), vreg64(12), nullptr);
-        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(4), nullptr);
         e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
         returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
         if (operandWild && fast_) {  // a wild operand can be Inf / NaN, and then so is the result
