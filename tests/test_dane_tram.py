@@ -202,3 +202,19 @@ def test_static_multi_tap_line_translated_with_reads_a_sample_ahead(gpu, monkeyp
     o.set_option(OPT_DANE)
     assert o.load_text(clash)
     assert np.array_equal(bits(o.process_block(x[:3000, 5].copy())), bits(y2[:, 5]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dane", [False, True], ids=["reference_model", "dane_model"])
+def test_delay_line_fuzz(gpu, dane, monkeypatch):
+    """tools/fuzz_tram.py, 150 programs per model: programs that start with a group of TRAM reads (issued a sample ahead by the
+    translated tier) on tiny lines - an early read meeting a later write of the same slot is the norm there -, balanced and
+    unbalanced read/write counts, offsets, several short blocks"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_tram
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["fuzz_tram.py", "5000", "150"] + (["dane"] if dane else []))
+    assert fuzz_tram.main() == 0
