@@ -394,7 +394,7 @@ enum : uint32_t {
     VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
-    SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5,
+    SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
@@ -806,10 +806,11 @@ class Translator {
             e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(4), nullptr);
         };
         segmentMath();
-        e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTemp + 2), vcc, sreg64(kSTemp));
-        e_.sopc(SOPC_CMP_LG_U64, "s_cmp_lg_u64", sreg64(kSTemp + 2), imm32(0));
-        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        e_.sop2(SOP2_OR_B64, "s_or_b64", vcc, vcc, sreg64(kSTemp));
+        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_VCCZ, "s_cbranch_vccz");
         e_.cold(true);
+        e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // (VCC again: the carry of the correction)
+        e_.sopp(SOPP_NOP, "s_nop", 1, true);
         e_.addCarry(6);
         e_.subBorrow(6, kSTemp, kSTemp + 2);
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
