@@ -8,6 +8,7 @@
 // the compiled reference on a line corpus in tests/test_frontend_golden.py.
 #include "fx_model.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -348,6 +349,35 @@ void lutDomainBounds(float out[2]) {
     const double step = (1.0 - -1.0) / 63.0;
     out[0] = firstFloatReaching(-step);
     out[1] = firstFloatReaching(64.0 * step);
+}
+
+// The generated code's cheap test of a guessed segment g: with d = (double)x - x1[g], "0 <= d < W" must imply that the
+// reference's index for x is g.  d is monotone in x, so it is enough that the smallest float at or above x1[g] has
+// reached threshold g, and that d at threshold g+1 is at least W.  Returns the high word of the largest such W with a
+// zero low word (the test is one unsigned compare of d's high word: sign bit and NaN read as "large"), 0 if the grid
+// does not allow the test.  Only the grid enters (step, x1, thresholds), not the table contents.
+uint32_t lutGuessWindowHi() {
+    const double step = (1.0 - -1.0) / 63.0;
+    auto indexOf = [&](double t) { return (int)(t / step); };
+    double w = HUGE_VAL;
+    float next = 0.0f;
+    for (int k = 0; k <= 63; ++k) {
+        const double x1 = -1.0 + k * step;
+        float lo = (float)x1;
+        if ((double)lo < x1) lo = std::nextafterf(lo, 4.0f);
+        if (indexOf((double)lo - -1.0) < k) return 0;          // a float in [x1[k], threshold k) exists
+        if (k > 0) {
+            // next = threshold k as a float, first x of segment k: d of segment k-1 there bounds its window
+            double t = k * step;
+            while (indexOf(t) >= k) t = std::nextafter(t, 0.0);
+            while (indexOf(t) < k) t = std::nextafter(t, 4.0);
+            next = firstFloatReaching(t);
+            w = std::min(w, (double)next - (-1.0 + (k - 1) * step));
+        }
+    }
+    uint64_t bits;
+    std::memcpy(&bits, &w, 8);
+    return (uint32_t)(bits >> 32);
 }
 
 LutDevice::LutDevice(const Luts& l) : blob(kLutBlobDoubles, 0.0), invStep(63.0 / 2.0) {

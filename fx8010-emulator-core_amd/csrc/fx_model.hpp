@@ -113,6 +113,7 @@ constexpr int kLutXdomOff = kLutXthrOff + 33;          // 2 floats = 1 double
 constexpr int kLutBlobDoubles = kLutXdomOff + 1;
 // xdom[2] of the blob: the fp32 operand range [xdom[0], xdom[1]) inside which the segment index is 0..63
 void lutDomainBounds(float out[2]);
+uint32_t lutGuessWindowHi();  // see fx_frontend.cpp
 struct LutDevice {
     std::vector<double> blob;
     double invStep;  // 63/2: only used to guess idx, the thresholds decide

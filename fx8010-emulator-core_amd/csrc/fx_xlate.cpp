@@ -393,7 +393,7 @@ class Emitter {
 enum : uint32_t {
     VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
-    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca,
+    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
@@ -793,22 +793,39 @@ class Translator {
                 e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                     // slope, y1
             }
         };
-        fetchSegment(true);
-        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
-        if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
-        e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // x >= xthr[g+1]: one up
-        e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));      // x <  xthr[g]  : one down
-        // the segment arithmetic goes ahead on the guess while the scalar unit makes up its mind (the compares' results
-        // reach it a pipeline later: checking first would stall the wave twice per LOG/EXP); a miss redoes it below
-        auto segmentMath = [&]() {
-            e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
+        auto segmentMath = [&](int from) {
+            if (from <= 0) e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
             e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(12), vreg64(2), vreg64(12), nullptr);
             e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(4), nullptr);
         };
-        segmentMath();
-        e_.sop2(SOP2_OR_B64, "s_or_b64", vcc, vcc, sreg64(kSTemp));
-        Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_VCCZ, "s_cbranch_vccz");
+        // Where the operand is known to be in the table (not guarded) the guess is checked without its thresholds: d = x - x1[g]
+        // must lie in [0, W), W a constant of the grid (fx_frontend.cpp lutGuessWindowHi) - one unsigned compare of d's high
+        // word, three LDS reads instead of four.  A miss (one lane in ~10^5 within reach of a threshold) reads the thresholds
+        // after all and corrects the index as the guarded form does.
+        const uint32_t window = (lds && !guarded) ? lutGuessWindowHi() : 0;
+        fetchSegment(window == 0);
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
+        if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
+        // the segment arithmetic goes ahead on the guess while the scalar unit makes up its mind (the compares' results
+        // reach it a pipeline later: checking first would stall the wave twice per LOG/EXP); a miss redoes it below
+        Emitter::Fixup hit;
+        if (window) {
+            e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);         // d = x - x1
+            e_.vopc(VOPC_CMP_LE_U32, "v_cmp_le_u32_e32", imm32(window, true), 13);                     // lanes outside [0, W)
+            segmentMath(1);
+        } else {
+            e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                    // x >= xthr[g+1]: one up
+            e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));  // x <  xthr[g]  : one down
+            segmentMath(0);
+            e_.sop2(SOP2_OR_B64, "s_or_b64", vcc, vcc, sreg64(kSTemp));
+        }
+        hit = e_.branchForward(SOPP_CBRANCH_VCCZ, "s_cbranch_vccz");
         e_.cold(true);
+        if (window) {
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);
+            e_.waitLgkm0();
+            e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));
+        }
         e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // (VCC again: the carry of the correction)
         e_.sopp(SOPP_NOP, "s_nop", 1, true);
         e_.addCarry(6);
@@ -817,7 +834,7 @@ class Translator {
         fetchSegment(false);
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
         if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
-        segmentMath();
+        segmentMath(0);
         e_.cold(false);
         e_.bind(hit);
         if (guarded) {

@@ -154,12 +154,18 @@ def test_opcode_programs(gpu, name, k):
 
 @pytest.mark.parametrize("op,table", [("log", 1), ("log", 3), ("log", 16), ("log", 31), ("exp", 0), ("exp", 2), ("exp", 7), ("exp", 31)])
 @pytest.mark.parametrize("kern", ["xlate", "asm", "asm_lds", "hip"])
-def test_log_exp_dense_sweep(gpu, op, table, kern, monkeypatch):
+@pytest.mark.parametrize("operand", ["input", "saturated"])
+def test_log_exp_dense_sweep(gpu, op, table, kern, operand, monkeypatch):
     """LOG/EXP on the device use precomputed thresholds/slopes instead of the reference's two fp64
-    divisions: sweep random x, every table knot and its float neighbours, the domain edges."""
+    divisions: sweep random x, every table knot and its float neighbours, the domain edges.
+    The translated tier checks its segment guess in two ways: against the thresholds for an operand that can be
+    anything (the input), by the window test for one known to lie in [-1, 1] (the result of a saturating instruction)."""
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
     monkeypatch.setenv("FX_KERNEL", kern)
-    text = HDR + "%s out, in, %d, 0\nend" % (op, table)
+    if operand == "input":
+        text = HDR + "%s out, in, %d, 0\nend" % (op, table)
+    else:
+        text = HDR + "macs a, in, 0, 0\n%s out, a, %d, 0\nend" % (op, table)
     rng = np.random.default_rng(table * 7 + len(op))
     knots = (-1.0 + np.arange(64, dtype=np.float64) * (2.0 / 63.0)).astype(np.float32)
     near = [knots]
