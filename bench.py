@@ -37,7 +37,8 @@ for p in (os.path.join(ROOT, "fx8010-emulator-core_amd", "python"), os.path.join
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SIMDS = 1024           # 256 CUs x 4 SIMD-32
-MAX_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md: max clock; a wave64 VALU instruction takes 2 cycles of a SIMD
+MAX_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md: max clock
+FAST_VALU_CLOCKS = 2.12  # measured: SIMD clocks per wave64 v_mul_f32 / v_add_f32 with >= 2 wavefronts resident (tools/micro/valu_rate.hip)
 
 
 def parse():
@@ -188,6 +189,57 @@ def kernel_name(batch):
             % (vg[kid - 7], batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_unsaturated"), batch.info("xlate_code_bytes")))
 
 
+class ClockSampler:
+    """Shader clock and socket power of one GPU while the timed region runs, from the amdgpu hwmon files (None when the
+    files cannot be found: the numbers are extra information, never part of `value`)."""
+
+    def __init__(self, torch, device_index):
+        import glob
+        import threading
+        self.freq = self.power = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for d in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf):
+                f, w = os.path.join(d, "freq1_input"), os.path.join(d, "power1_input")
+                if os.path.exists(f):
+                    self.freq, self.power = f, (w if os.path.exists(w) else None)
+        except Exception:
+            pass
+
+    def _read(self, path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((self._read(self.freq), self._read(self.power) if self.power else None))
+            self._stop.wait(0.02)
+
+    def start(self):
+        import threading
+        if self.freq is None:
+            return
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        """-> (mean shader clock in MHz, mean power in W) over the samples taken, either None when unknown"""
+        if self._thread is None:
+            return None, None
+        self._stop.set()
+        self._thread.join()
+        f = [a for a, _ in self.samples if a]
+        w = [b for _, b in self.samples if b]
+        return (round(sum(f) / len(f) / 1e6, 1) if f else None), (round(sum(w) / len(w) / 1e6, 1) if w else None)
+
+
 def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warmup, devices, rank, dist, reduce_dev, parity_n):
     """One configuration on this process's device(s).  Returns (fields for the JSON line, batch text)."""
     text = progs.CONFIGS[config]()
@@ -236,6 +288,8 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
     c0 = batch.instruction_counter()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    sampler = ClockSampler(torch, devices[0])
+    sampler.start()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(steps):
@@ -243,6 +297,7 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
     ev1.record()
     barrier()
     t1 = time.perf_counter()
+    clock_mhz, power_w = sampler.stop()
     elapsed = t1 - t0
     # HIP events on the launch stream (single device); a sharded batch launches from its own threads on its own
     # streams: the slowest shard's last launch, measured by the library's events on that stream
@@ -282,12 +337,21 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
         valu = None
         if valu_per_wave_sample > 0:
             per_s = valu_per_wave_sample * waves * S / (kernel_ms * 1e-3)
-            peak = SIMDS * MAX_CLOCK_HZ / 2.0
+            peak = SIMDS * MAX_CLOCK_HZ / FAST_VALU_CLOCKS
+            # issue time of the instructions a wave executes per sample, by class (cost table: fx_xlate.cpp Emitter::issueCost,
+            # measured by tools/micro/mix_cost.hip), against the SIMD cycles that were available at the clock the chip held
+            clocks = batch.info("xlate_valu_clocks")
+            hz = (clock_mhz * 1e6) if clock_mhz else MAX_CLOCK_HZ
+            busy = clocks * (waves / float(SIMDS)) * S / (kernel_ms * 1e-3 * hz)
             valu = {"bound": "valu issue", "achieved": round(per_s / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
                     "frac": round(per_s / peak, 4), "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves / float(SIMDS), 3),
                     "valu_per_emulated_instr": round(valu_per_wave_sample / max(executed / float(steps * S * n_inst * n_dev), 1e-9), 3),
-                    "note": "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction; the chip holds a lower clock under this load (DVFS), "
-                            "and below 2 wavefronts per SIMD one wavefront issues only every 4th cycle (DESIGN.md section 5)"}
+                    "valu_4clock_class_per_wave_sample": batch.info("xlate_valu_slow"),
+                    "issue_clocks_per_wave_sample": clocks, "clock_mhz": clock_mhz, "power_w": power_w,
+                    "simd_issue_busy": round(busy, 4),
+                    "note": "peak = 1024 SIMDs x 2.4 GHz / 2.12 clocks, the rate of plain fp32 add / mul; conversions, fp64, min/max and compares "
+                            "cost 2.7-4.4 clocks each: simd_issue_busy = modelled issue clocks of the executed mix / SIMD clocks available at the "
+                            "measured clock (DESIGN.md section 5); below 2 wavefronts per SIMD a wavefront issues only every ~5th clock"}
         res = {
             "value": round(mips, 1),
             "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 4),
@@ -400,6 +464,8 @@ def main():
                                    "kernel_ms": r["roofline"]["kernel_ms"], "hbm_frac": r["roofline"]["frac"],
                                    "valu_frac": (r["roofline"]["valu"] or {}).get("frac"), "waves_per_simd": (r["roofline"]["valu"] or {}).get("waves_per_simd"),
                                    "valu_per_emulated_instr": (r["roofline"]["valu"] or {}).get("valu_per_emulated_instr"),
+                                   "simd_issue_busy": (r["roofline"]["valu"] or {}).get("simd_issue_busy"), "clock_mhz": (r["roofline"]["valu"] or {}).get("clock_mhz"),
+                                   "power_w": (r["roofline"]["valu"] or {}).get("power_w"),
                                    "parity_checked": (r.get("parity") or {}).get("parity_checked"), "parity_ok": (r.get("parity") or {}).get("parity_ok")}
                 except Exception as e:  # an extra must never take the headline line down
                     extra[name] = {"error": str(e)[:200]}

@@ -239,6 +239,13 @@ int Batch::ensureLowered() {
                 // smallest VGPR build that holds the register file = most wavefronts per SIMD
                 int v = ASM_V64;
                 while (v < ASM_V256 && fresh.nRows > kAsmVgprRows[v]) ++v;
+                // ... and a larger one while that costs no residency this batch can use: the translator keeps uniform
+                // constants in the spare VGPRs (a literal or SGPR source slows a plain fp32 instruction down, fx_xlate.hpp)
+                {
+                    const int wavesPerSimd = (int)((((size_t)n_ + 63) / 64 + 1023) / 1024);  // 256 CUs x 4 SIMDs
+                    auto usable = [&](int q) { return std::min(kAsmWavesPerSimd[q], std::max(wavesPerSimd, 1)); };
+                    while (v < ASM_V256 && kAsmVgprRows[v] - fresh.nRows < kMaxVgprConstants && usable(v + 1) >= usable(v)) ++v;
+                }
                 const char* pin = forceHip ? std::strstr(forceHip, "_v") : nullptr;
                 if (pin && (std::strncmp(forceHip, "asm_v", 5) == 0 || std::strncmp(forceHip, "xlate_v", 7) == 0)) {
                     // diagnostics: pin a (large enough) build of the interpreter (asm_vNN) or of the translator (xlate_vNN)
@@ -321,6 +328,9 @@ int Batch::ensureLowered() {
             xlateInlined_ = image.steady.inlined;
             xlateCalled_ = image.steady.called;
             xlateValu_ = image.steady.valu;
+            xlateValuSlow_ = image.steady.valuSlow;
+            xlateValuClocks_ = image.steady.valuClocks;
+            xlateVgprConstants_ = image.vgprConstants;
             useXlate_ = true;
         }
     }
@@ -759,6 +769,9 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;
         case FXB_INFO_XLATE_UNSATURATED: return useXlate_ ? xlateUnsaturated_ : 0;
         case FXB_INFO_XLATE_VALU: return useXlate_ ? xlateValu_ : 0;
+        case FXB_INFO_XLATE_VALU_SLOW: return useXlate_ ? xlateValuSlow_ : 0;
+        case FXB_INFO_XLATE_VALU_CLOCKS: return useXlate_ ? xlateValuClocks_ : 0;
+        case FXB_INFO_XLATE_VGPR_CONSTANTS: return useXlate_ ? xlateVgprConstants_ : 0;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
         case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? 0 : (int64_t)low_.nRows * 256 * instPerLane_;

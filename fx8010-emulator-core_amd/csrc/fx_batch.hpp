@@ -115,7 +115,7 @@ private:
     hipFunction_t xlateFn_ = nullptr;
     uint64_t xlateSteady_ = 0, xlateLast_ = 0;  // {fast, exact} stream offsets as the kernel takes them
     uint32_t xlateCodeBytes_ = 0, xlateInitOff_ = 0, xlateLdsBytes_ = 0;
-    int xlateInlined_ = 0, xlateCalled_ = 0, xlateUnsaturated_ = 0, xlateValu_ = 0;
+    int xlateInlined_ = 0, xlateCalled_ = 0, xlateUnsaturated_ = 0, xlateValu_ = 0, xlateValuSlow_ = 0, xlateValuClocks_ = 0, xlateVgprConstants_ = 0;
     std::vector<uint8_t> xlateWildRow_;
     std::string xlateWhyNot_;
     // control changes re-lower; while they keep coming the interpreter tier is used (see ensureLowered)

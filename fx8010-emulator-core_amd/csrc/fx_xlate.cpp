@@ -6,7 +6,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 
 namespace fx {
@@ -176,7 +178,17 @@ class Emitter {
     // vector-ALU instructions on the path a finite, in-domain wave takes every sample (cold(true) brackets code that
     // such a wave does not execute: entry stubs, out-of-range paths, the second LUT trip)
     int valu() const { return valu_; }
+    int valuSlow() const { return valuSlow_; }
+    int valuClocks() const { return (int)((valuClocksX100_ + 50) / 100); }
     void cold(bool on) { cold_ = on; }
+    // uniform constants kept in VGPRs for the whole launch (XlateProgram::vconst)
+    void constants(const std::vector<std::pair<uint32_t, int>>* pool) { pool_ = pool; }
+    int pooled(uint32_t bits) const {
+        if (pool_)
+            for (const auto& c : *pool_)
+                if (c.first == bits) return c.second;
+        return -1;
+    }
     // the listing is kept as lines until the stream is complete (forward branches are patched in place)
     void finish() {
         if (!text_) return;
@@ -226,23 +238,23 @@ class Emitter {
     }
 
     void vop2(uint32_t op, const char* name, int vdst, const Src& src0, int vsrc1, const char* tail = "") {
-        tally();
+        tally(name);
         put((op << 25) | ((uint32_t)vdst << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
         if (text_) line(std::string(name) + " v" + std::to_string(vdst) + ", " + src0.text + ", v" + std::to_string(vsrc1) + tail);
     }
     void vop1(uint32_t op, const char* name, const Src& vdst, const Src& src0) {
-        tally();
+        tally(name);
         put(0x7e000000u | ((vdst.code & 0xffu) << 17) | (op << 9) | src0.code, src0);
         if (text_) line(std::string(name) + " " + vdst.text + ", " + src0.text);
     }
     void vopc(uint32_t op, const char* name, const Src& src0, int vsrc1) {
-        tally();
+        tally(name);
         put(0x7c000000u | (op << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
         if (text_) line(std::string(name) + " vcc, " + src0.text + ", v" + std::to_string(vsrc1));
     }
     // VOP3A: no literals on gfx9; neg = per-source negate bits
     void vop3(uint32_t op, const char* name, const Src& vdst, const Src& s0, const Src& s1, const Src* s2, uint32_t neg = 0) {
-        tally();
+        tally(name);
         w_.push_back(0xd0000000u | (op << 16) | (vdst.code & 0xffu));
         w_.push_back(s0.code | (s1.code << 9) | ((s2 ? s2->code : 0u) << 18) | (neg << 29));
         ++count_;
@@ -253,7 +265,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form, result to VCC, |src0| when abs0
     void vop3cmp(uint32_t op, const char* name, const Src& s0, bool abs0, const Src& s1) {
-        tally();
+        tally("v_other");
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | 106u);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -323,14 +335,14 @@ class Emitter {
     }
     // v = v + carry (VCC in and out)
     void addCarry(int v) {
-        tally();
+        tally("v_other");
         w_.push_back((VOP2_ADDC_OP << 25) | ((uint32_t)v << 17) | ((uint32_t)v << 9) | 128u);
         ++count_;
         if (text_) line("v_addc_co_u32_e32 v" + std::to_string(v) + ", vcc, 0, v" + std::to_string(v) + ", vcc");
     }
     // v = v - borrow, borrow in from the SGPR pair `sin`, borrow out to the pair `sout`
     void subBorrow(int v, int sin, int sout) {
-        tally();
+        tally("v_other");
         w_.push_back(0xd0000000u | (0x11eu << 16) | ((uint32_t)sout << 8) | (uint32_t)v);
         w_.push_back(128u | ((256u + (uint32_t)v) << 9) | ((uint32_t)sin << 18));
         ++count_;
@@ -344,7 +356,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
     void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
-        tally();
+        tally("v_other");
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | (sdst.code & 0xffu));
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -352,7 +364,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form with an SGPR-pair destination
     void vop3cmpTo(uint32_t op, const char* name, int sdst, const Src& s0, const Src& s1) {
-        tally();
+        tally("v_other");
         w_.push_back(0xd0000000u | (op << 16) | (uint32_t)sdst);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -384,9 +396,32 @@ class Emitter {
     std::vector<uint32_t>& w_;
     std::string* text_;
     std::vector<std::string> lines_;
-    int count_ = 0, valu_ = 0;
+    int count_ = 0, valu_ = 0, valuSlow_ = 0;
+    long valuClocksX100_ = 0;
     bool cold_ = false;
-    void tally() { if (!cold_) ++valu_; }
+    const std::vector<std::pair<uint32_t, int>>* pool_ = nullptr;
+    // Issue cost of a wave64 VALU instruction on a busy SIMD, in clocks x 100.  Measured on MI355X as the time an instruction
+    // adds to a realistic mix at four waves per SIMD (tools/micro/mix_cost.hip; the homogeneous loops of valu_rate.hip
+    // bound it from above): plain fp32 add / sub / mul, moves, 32-bit integer add / sub / and 2.1; v_fma_f32 2.5;
+    // v_med3 / min / max 2.7; conversions to and from fp64 and all fp64 arithmetic 4.4; everything else (compares,
+    // integer conversions, shifts, selects, carries) 4.1.
+    static bool startsWith(const char* name, const char* prefix) { return std::strncmp(name, prefix, std::strlen(prefix)) == 0; }
+    static int issueCost(const char* name) {
+        static const char* const fast[] = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32"};
+        for (const char* f : fast)
+            if (startsWith(name, f)) return 212;
+        if (startsWith(name, "v_fma_f32")) return 250;
+        if (startsWith(name, "v_med3_f32") || startsWith(name, "v_max_f32") || startsWith(name, "v_min_f32")) return 270;
+        if (std::strstr(name, "f64")) return 440;
+        return 410;
+    }
+    void tally(const char* name) {
+        if (cold_) return;
+        ++valu_;
+        const int cost = issueCost(name);
+        if (cost > 300) ++valuSlow_;
+        valuClocksX100_ += cost;
+    }
 };
 
 // gfx950 opcodes used (checked against llvm-mc by tests/test_xlate.py, which re-assembles the listing)
@@ -402,7 +437,7 @@ enum : uint32_t {
     SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
     VOP2_ADDC_CO_U32 = 0x1c, VOP3B_SUBBREV_CO_U32 = 0x11e,
     VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49, VOPC_CMP_NGT_F32 = 0x4b, VOPC_CMP_NLE_F32 = 0x4c,
-    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
+    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOP2_AND_B32 = 0x13, VOP2_LSHRREV_B32 = 0x10, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F32 = 0x1cb, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
@@ -445,6 +480,16 @@ constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may 
 
 int32_t danePosition(uint32_t bits, bool shifted, int32_t size);  // (defined with the hoist planning below)
 
+// the four VGPR constants of the quick LOG/EXP index guess (Translator::lut)
+struct LutGuessConstants {
+    uint32_t scale = 0x437c0000u;   // 252.0
+    uint32_t bias = 0x437b8000u;    // 251.5
+    uint32_t magic = 0x4b400000u;   // 1.5 * 2^23
+    uint32_t mask = 0x000001f8u;
+    bool available(const Emitter& e) const { return e.pooled(scale) >= 0 && e.pooled(bias) >= 0 && e.pooled(magic) >= 0 && e.pooled(mask) >= 0; }
+};
+const LutGuessConstants kLutGuess;
+
 class Translator {
   public:
     // exactReturns == nullptr: the exact stream (NaN passes every saturation).  Otherwise the fast stream, which
@@ -453,7 +498,7 @@ class Translator {
     Translator(const XlateTemplate& t, const XlateProgram& prog, uint32_t codeBase, bool isLast, uint32_t nextBase, std::vector<uint32_t>* code,
                std::string* listing, const std::vector<uint32_t>* exactReturns)
         : tmpl_(t), prog_(prog), base_(codeBase), isLast_(isLast), nextBase_(nextBase), e_(code, listing), fast_(exactReturns != nullptr),
-          exactReturns_(exactReturns) {}
+          exactReturns_(exactReturns) { e_.constants(&prog_.vconst); }
 
     // Layout of a stream:  head (hot entry) | program | PCM out, advance, loop branch / exit | cold entry stub
     bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::vector<uint32_t>* returns, uint32_t* coldEntry, std::string* err) {
@@ -572,6 +617,7 @@ class Translator {
         }
         for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
         for (const auto& c : pool_) e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(c.second), imm32(c.first, true));
+        for (const auto& c : prog_.vconst) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(c.second), imm32(c.first, true));
         if (anyLut && prog_.lutTables.empty()) {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutXthr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutXthr + 1), sreg(kSLut + 1), imm32(0));
@@ -581,7 +627,7 @@ class Translator {
         if (!e_.branchBack(SOPP_BRANCH, "s_branch", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
         e_.finish();
         if (returns) *returns = returns_;
-        if (stats) { *stats = stats_; stats->instructions = e_.count(); stats->valu = e_.valu(); stats->nonFiniteImmediate = nonFinite_; }
+        if (stats) { *stats = stats_; stats->instructions = e_.count(); stats->valu = e_.valu(); stats->valuSlow = e_.valuSlow(); stats->valuClocks = e_.valuClocks(); stats->nonFiniteImmediate = nonFinite_; }
         return true;
     }
 
@@ -765,19 +811,30 @@ class Translator {
         // exact stream, which a wave enters precisely when that invariant broke) the index is clamped and the flag derived.
         const bool guarded = operandWild || !fast_;
         Src zero = imm32(0), top = imm32(63), vcc = named(106, "vcc");
-        if (pooled(0x41fc0000u) >= 0) {  // (x + 1) * 31.5 as fma(x, 31.5, 31.5): it is only a guess, checked below
-            Src k = sreg(pooled(0x41fc0000u));
-            e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(6), vreg(vA), k, &k);
+        // The guess.  Bounded operand, tables in LDS and the four constants in VGPRs: three instructions of the double-rate
+        // class give 8 * floor((x + 1) * 31.5) directly - t = fma(x, 252, 251.5) = 8 * (x + 1) * 31.5 - 0.5; adding
+        // 1.5 * 2^23 rounds t to the nearest integer q, which lands in the low mantissa bits (q = floor(8 * ...) unless the
+        // fraction is within 2^-15 of a whole number; at x = +-1, the only floats where the tie can matter, round-to-even
+        // picks 504 and 0); q & 0x1f8 is the byte offset of the segment.  Otherwise (x + 1) * 31.5 truncated by v_cvt.
+        const uint32_t window = (lds && !guarded) ? lutGuessWindowHi() : 0;   // (see below)
+        const bool quick = window != 0 && kLutGuess.available(e_);
+        if (quick) {
+            Src half = vreg(e_.pooled(kLutGuess.bias));
+            e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(6), vreg(vA), vreg(e_.pooled(kLutGuess.scale)), &half);
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, vreg(e_.pooled(kLutGuess.magic)), 6);
+            e_.vop2(VOP2_AND_B32, "v_and_b32_e32", 7, vreg(e_.pooled(kLutGuess.mask)), 6);
         } else {
             e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x3f800000u), vA);
             e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 6, imm32(0x41fc0000u), 6);              // * 31.5
+            e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
         }
-        e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
         const uint32_t slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes, y1Off = slopeOff + 512;
+        bool withThresholdsFirst = true;  // (first fetch of the quick form: v7 holds the offset already)
         auto fetchSegment = [&](bool withThresholds) {
             if (lds) {
-                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+                if (!quick || !withThresholdsFirst) e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+                withThresholdsFirst = false;
                 if (withThresholds) e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);   // xthr[g], xthr[g+1]
                 e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, kLdsX1);                       // x1[g]
                 e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 2, 7, slopeOff);
@@ -802,7 +859,6 @@ class Translator {
         // must lie in [0, W), W a constant of the grid (fx_frontend.cpp lutGuessWindowHi) - one unsigned compare of d's high
         // word, three LDS reads instead of four.  A miss (one lane in ~10^5 within reach of a threshold) reads the thresholds
         // after all and corrects the index as the guarded form does.
-        const uint32_t window = (lds && !guarded) ? lutGuessWindowHi() : 0;
         fetchSegment(window == 0);
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
         if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
@@ -823,6 +879,7 @@ class Translator {
         e_.cold(true);
         if (window) {
             e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);
+            if (quick) e_.vop2(VOP2_LSHRREV_B32, "v_lshrrev_b32_e32", 6, imm32(3), 7);
             e_.waitLgkm0();
             e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));
         }
@@ -1102,21 +1159,20 @@ class Translator {
     }
 
     // ---- constants held in SGPRs for the whole loop (VOP3 takes no literal on gfx9): the multipliers of "R = 0 + X * c"
-    // with |c| > 0.5, and 31.5 for the LOG/EXP index guess.  s88..s93 are free unless the LOG/EXP tables are read from
-    // global memory (more than four tables).
+    // with |c| > 0.5.  s88..s93 are free unless the LOG/EXP tables are read from global memory (more than four tables).
+    // (Held in VGPRs instead they issue no faster inside a mix and the chip, which runs config5 against its power limit,
+    // clocks ~0.5 % lower; replacing the 32-bit literals of plain multiplications by VGPRs costs another ~1 % the same way.)
     void buildConstantPool(const std::vector<MicroOp>& records, bool anyLut) {
         pool_.clear();
         if (!fast_ || (anyLut && prog_.lutTables.empty())) return;
         std::vector<std::pair<uint32_t, int>> freq;
-        auto bump = [&](uint32_t bits, int by) {
-            for (auto& f : freq)
-                if (f.first == bits) { f.second += by; return; }
-            freq.emplace_back(bits, by);
-        };
         for (const MicroOp& r : records) {
             uint32_t c;
-            if (r.w[0] == AS_LUT && !(r.w[6] & 1u)) bump(0x41fc0000u, 1);
-            else if (zeroPlusScaled(r, &c, nullptr)) bump(c, 1);
+            if (!zeroPlusScaled(r, &c, nullptr)) continue;
+            bool seen = false;
+            for (auto& f : freq)
+                if (f.first == c) { ++f.second; seen = true; }
+            if (!seen) freq.emplace_back(c, 1);
         }
         std::stable_sort(freq.begin(), freq.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.second > b.second; });
         for (size_t k = 0; k < freq.size() && k < 6; ++k) pool_.emplace_back(freq[k].first, 88 + (int)k);
@@ -1965,7 +2021,18 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     // size everything with dummy targets, lay out, translate the exact streams (their sync points are the fast
     // streams' escape targets), then the fast ones.
     const std::vector<MicroOp>* recs[2] = {&steadyRecords, &lastRecords};
-    XlateProgram prog[2] = {program, program};
+    // VGPRs above the register file: the four constants of the quick LOG/EXP index guess (Translator::lut), when there is room
+    XlateProgram pooledProgram = program;
+    pooledProgram.vconst.clear();
+    {
+        const char* knob = std::getenv("FX_XLATE_VCONST");  // diagnostics: 0 = none
+        const int firstFree = kRegFileBase + (int)program.wildRow.size();
+        if (!program.lutTables.empty() && tmpl.vgprs - firstFree >= 4 && !(knob && std::atoi(knob) == 0)) {
+            int v = tmpl.vgprs;
+            for (uint32_t c : {kLutGuess.scale, kLutGuess.bias, kLutGuess.magic, kLutGuess.mask}) pooledProgram.vconst.emplace_back(c, --v);
+        }
+    }
+    XlateProgram prog[2] = {pooledProgram, pooledProgram};
     uint32_t bytes[4] = {0, 0, 0, 0};  // steady fast, steady exact, last fast, last exact
     bool fastOk = true;
     for (int k = 0; k < 2; ++k) {
@@ -2006,6 +2073,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     out->steady = stats[0];
     out->last = stats[2];
     out->wildRow = program.wildRow;
+    out->vgprConstants = (int)pooledProgram.vconst.size();
     out->initOff = 0;
     out->ldsBytes = 0;
     code[4].clear();

@@ -82,7 +82,11 @@ struct XlateProgram {
     int tramOpsInline = 0;        // inline TRAM instructions per sample of the steady stream (each issues one VMEM operation)
     std::vector<int> trackRows;   // register-file row of track slot t (at most kMaxTracks); such rows are of the WILD class
     HoistPlan hoist;
+    // uniform constants kept in VGPRs above the register file for the whole launch: (bit pattern, VGPR), set by planXlate
+    // (the constants of the LOG/EXP index guess, which must be VGPR sources to stay in the double-rate instruction class)
+    std::vector<std::pair<uint32_t, int>> vconst;
 };
+constexpr int kMaxVgprConstants = 4;
 // nRows = rows of the register file, inputRows = the rows the PCM input goes to (-1: unused channel), latchRows = the
 // rows the PCM output comes from; one entry per channel
 XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
@@ -94,6 +98,8 @@ struct XlateStats {
     int called = 0;      // records executed by a call to the interpreter's handler
     int instructions = 0;
     int valu = 0;        // vector-ALU instructions a finite, in-domain wave executes per sample period
+    int valuSlow = 0;    // ... of which of the ~4-clock class (fp64 arithmetic and conversions, compares, shifts, selects)
+    int valuClocks = 0;  // ... and their modelled issue time on a busy SIMD, clocks (cost table in fx_xlate.cpp Emitter::tally)
     int fusedSkips = 0;  // SKIPs translated as a predicate on the value that would have set their CCR
     int regions = 0;     // SKIP shadows run under one EXEC mask (no per-instruction PRED)
     int unitMultipliers = 0;  // multiplications by +-1.0 that were not emitted
@@ -134,6 +140,7 @@ struct XlateImage {
     uint32_t codeBytes = 0;
     XlateStats steady, last;  // of the stream a finite wave runs
     std::vector<uint8_t> wildRow;  // row classes the code relies on: the loader flags BOUNDED rows in the row table
+    int vgprConstants = 0;         // uniform constants the code keeps in VGPRs above the register file
 };
 // Lays the four streams out ([steady fast][steady exact][last fast][last exact]) and translates them; code[k] /
 // listing[k] in that order (listing may be nullptr); code[4] = the run-once code (LDS tables), empty when none.  Without a fast stream (non-finite uniform operand) the

@@ -205,7 +205,10 @@ enum {
     FXB_INFO_XLATE_INLINED = 19,   /* records of the steady stream turned into straight-line code */
     FXB_INFO_XLATE_CALLED = 20,    /* records of the steady stream that call an interpreter handler */
     FXB_INFO_XLATE_UNSATURATED = 21,/* saturating instructions translated without a saturation (result provably in [-1, 1]) */
-    FXB_INFO_XLATE_VALU = 22        /* translated program: vector-ALU instructions per wavefront and sample period (steady fast stream) */
+    FXB_INFO_XLATE_VALU = 22,       /* translated program: vector-ALU instructions per wavefront and sample period (steady fast stream) */
+    FXB_INFO_XLATE_VALU_SLOW = 23,  /* ... those of the ~4-clock issue class (conversions, min/max/med3, compares, fp64, SGPR sources) */
+    FXB_INFO_XLATE_VALU_CLOCKS = 24,/* ... modelled SIMD issue clocks of all of them per wavefront and sample period */
+    FXB_INFO_XLATE_VGPR_CONSTANTS = 25 /* uniform constants the translated code keeps in spare VGPRs */
 };
 int64_t fxb_info(fxb_handle* h, int what);
 

@@ -172,3 +172,41 @@ def test_vgpr_budget_is_enforced():
     code96, _ = fe.translate(96)
     code0, _ = fe.translate(0)
     assert code96 == code0
+
+
+def test_quick_lut_guess_is_within_one_segment():
+    """The translated LOG/EXP code guesses the segment with three double-rate instructions (fx_xlate.cpp Translator::lut):
+    q = RN(RN(x * 252 + 251.5) + 1.5 * 2^23), byte offset = bits(q) & 0x1f8.  Its miss path can move the index by one
+    only, so the guess must never be further than that from the reference's (int)((x + 1.0) / step), and always in the table."""
+    rng = np.random.default_rng(5)
+    knots = (-1.0 + np.arange(64, dtype=np.float64) * (2.0 / 63.0)).astype(np.float32)
+    near = [knots]
+    for d in range(1, 5):
+        up, dn = knots.copy(), knots.copy()
+        for _ in range(d):
+            up = np.nextafter(up, np.float32(2.0)); dn = np.nextafter(dn, np.float32(-2.0))
+        near += [up, dn]
+    x = np.concatenate(near + [rng.uniform(-1.0, 1.0, size=2_000_000).astype(np.float32),
+                               np.array([1.0, -1.0, 0.0, -0.0, 1e-30, -1e-30, 1e-45, 0.99999994, -0.99999994], dtype=np.float32)])
+    x = np.clip(x, -1.0, 1.0).astype(np.float32)
+    # fp32 fma and add, each one rounding: the exact values fit a double
+    t = (x.astype(np.float64) * 252.0 + 251.5).astype(np.float32)
+    q = (t.astype(np.float64) + 12582912.0).astype(np.float32)
+    offset = q.view(np.uint32) & np.uint32(0x1F8)
+    guess = (offset >> 3).astype(np.int64)
+    step = (1.0 - -1.0) / 63.0
+    truth = ((x.astype(np.float64) - -1.0) / step).astype(np.int64)
+    assert guess.min() >= 0 and guess.max() <= 63
+    assert np.abs(guess - truth).max() <= 1
+    assert (guess != truth).mean() < 1e-4          # the second LDS round trip stays rare
+    assert guess[x == np.float32(1.0)].min() == 63 and guess[x == np.float32(-1.0)].max() == 0   # saturated operands hit
+
+
+@needs_llvm
+def test_quick_lut_guess_is_generated_for_bounded_operands():
+    fe = A.FrontEnd(1)
+    assert fe.load_text(P.CONFIGS["config4"]())
+    code, listing = fe.translate(0, 0)
+    assert listing.count("v_and_b32_e32 v7") == listing.count("v_cmp_le_u32_e32 vcc") > 0
+    assert "v_cvt_i32_f32" not in listing           # config4's LOG/EXP operands are all results of saturating instructions
+    assert assemble(listing) == code
