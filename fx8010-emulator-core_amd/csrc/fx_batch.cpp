@@ -239,9 +239,9 @@ int Batch::ensureLowered() {
                 // smallest VGPR build that holds the register file = most wavefronts per SIMD
                 int v = ASM_V64;
                 while (v < ASM_V256 && fresh.nRows > kAsmVgprRows[v]) ++v;
-                // ... and a larger one while that costs no residency this batch can use: the translator keeps uniform
-                // constants in the spare VGPRs (a literal or SGPR source slows a plain fp32 instruction down, fx_xlate.hpp)
-                {
+                // ... and, for a program with LOG / EXP, a larger one while that costs no residency this batch can use: the
+                // translator keeps the constants of its index guess in VGPRs above the register file (fx_xlate.hpp vconst)
+                if (fresh.usesLut) {
                     const int wavesPerSimd = (int)((((size_t)n_ + 63) / 64 + 1023) / 1024);  // 256 CUs x 4 SIMDs
                     auto usable = [&](int q) { return std::min(kAsmWavesPerSimd[q], std::max(wavesPerSimd, 1)); };
                     while (v < ASM_V256 && kAsmVgprRows[v] - fresh.nRows < kMaxVgprConstants && usable(v + 1) >= usable(v)) ++v;

@@ -80,6 +80,13 @@ __global__ void __launch_bounds__(64) k(float* out, uint64_t* clocks, int iters)
         else if (KIND == 37) asm volatile(REP16(BIN8("v_subrev_f32", "%8")) : F8 : "v"(zero));
         else if (KIND == 38) asm volatile(REP16(BIN8("v_fmac_f32", "%8")) : F8 : "v"(zero));
         else if (KIND == 39) asm volatile(REP16(BIN8("v_mul_f32", "-%8")) : F8 : "v"(one));                         // source modifier (VOP3 encoding)
+        else if (KIND == 40) asm volatile(REP16("v_add_co_u32 %0, vcc, %8, %0\n v_add_co_u32 %1, vcc, %8, %1\n v_add_co_u32 %2, vcc, %8, %2\n v_add_co_u32 %3, vcc, %8, %3\n v_add_co_u32 %4, vcc, %8, %4\n v_add_co_u32 %5, vcc, %8, %5\n v_add_co_u32 %6, vcc, %8, %6\n v_add_co_u32 %7, vcc, %8, %7\n") : F8 : "v"(zero) : "vcc");
+        else if (KIND == 41) asm volatile(REP16(CMP8("v_cmp_le_u32", "vcc", "%8")) : F8 : "v"(zero) : "vcc");
+        else if (KIND == 42) asm volatile(REP16(UN8("v_trunc_f32")) : F8);
+        else if (KIND == 43) asm volatile(REP16(BIN8("v_or_b32", "%8")) : F8 : "v"(zero));
+        else if (KIND == 44) asm volatile(REP16(BIN8("v_xor_b32", "%8")) : F8 : "v"(zero));
+        else if (KIND == 45) asm volatile(REP16(BIN8("v_mul_u32_u24", "%8")) : F8 : "v"(one));
+        else if (KIND == 46) asm volatile(REP16(BIN8("v_lshrrev_b32", "1")) : F8);
     }
     uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
     out[blockIdx.x * 64 + lane] = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
@@ -153,6 +160,13 @@ int main() {
         run<37>("v_subrev_f32", 128, d, dc, waves, iters);
         run<38>("v_fmac_f32", 128, d, dc, waves, iters);
         run<39>("v_mul_f32 neg", 128, d, dc, waves, iters);
+        run<40>("v_add_co_u32", 128, d, dc, waves, iters);
+        run<41>("v_cmp_le_u32", 128, d, dc, waves, iters);
+        run<42>("v_trunc_f32", 128, d, dc, waves, iters);
+        run<43>("v_or_b32", 128, d, dc, waves, iters);
+        run<44>("v_xor_b32", 128, d, dc, waves, iters);
+        run<45>("v_mul_u32_u24", 128, d, dc, waves, iters);
+        run<46>("v_lshrrev_b32", 128, d, dc, waves, iters);
     }
     return 0;
 }

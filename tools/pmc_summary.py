@@ -4,8 +4,10 @@
     python tools/pmc_summary.py <dir with pmc_*/..._counter_collection.csv> <samples per launch> [kernel prefix]
 
 Prints one JSON object: counters averaged over the kernel's dispatches, per wavefront and per wave-sample,
-plus the derived figures DESIGN.md section 5 quotes (VALU per wave-sample, clocks per VALU and SIMD, wait shares).
-SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, constants table).
+plus the shares DESIGN.md section 5 quotes (waiting / issuing as a fraction of a wave's resident time).  Only ratios of SQ
+counters are derived here: absolute clocks per instruction come from bench.py, which times the launches and reads the
+shader clock while they run (SQ_WAVE_CYCLES x 4 agrees with that for one wave per SIMD - config3 - and reads ~30 % low with
+four, so it is not used as a clock).
 """
 import csv
 import glob
@@ -43,12 +45,7 @@ def main():
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_SCA"):
             if k in per_ws:
                 d[k.lower() + "_share_of_wave_cycles"] = round(per_ws[k] / wc, 4)
-        waves_per_simd = waves / 1024.0
-        if "SQ_INSTS_VALU" in per_ws:
-            # a SIMD holds waves_per_simd waves; in the wall time of one wave-sample (4 * quad-cycles) it issues
-            # waves_per_simd * VALU instructions
-            d["waves_per_simd"] = round(waves_per_simd, 3)
-            d["clocks_per_valu_per_simd"] = round(4.0 * wc / (max(waves_per_simd, 1.0) * per_ws["SQ_INSTS_VALU"]), 3)
+        d["waves_per_simd"] = round(waves / 1024.0, 3)
     out["derived"] = d
     print(json.dumps(out, indent=1))
 
