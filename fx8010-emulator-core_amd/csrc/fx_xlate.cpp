@@ -428,7 +428,7 @@ class Emitter {
 enum : uint32_t {
     VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
-    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb,
+    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_GT_U32 = 0xcc,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
@@ -1492,19 +1492,17 @@ class Translator {
     }
     // vcc = lanes whose CCR would equal `want`, straight from the value in vR (setCCR inverted)
     bool ccrPredicate(float want, int vR) {
-        const Src vcc = named(106, "vcc"), t0 = sreg64(62), r = vreg(vR), zero = imm32(0), one = imm32(0x3f800000u), mone = imm32(0xbf800000u);
+        const Src vcc = named(106, "vcc"), r = vreg(vR), zero = imm32(0), one = imm32(0x3f800000u), mone = imm32(0xbf800000u);
         if (want == 8.0f) e_.vopc(VOPC_CMP_EQ_F32, "v_cmp_eq_f32_e32", zero, vR);
         else if (want == 16.0f) e_.vopc(VOPC_CMP_EQ_F32, "v_cmp_eq_f32_e32", one, vR);
         else if (want == 20.0f) e_.vopc(VOPC_CMP_EQ_F32, "v_cmp_eq_f32_e32", mone, vR);
         else if (want == 0.0f) e_.vop3cmpG(VOP3_CMP_NLE_F32, "v_cmp_nle_f32_e64", vcc, r, true, one);  // |r| > 1 or NaN
-        else if (want == 2.0f) {  // 0 < r < 1
-            e_.vopc(VOPC_CMP_LT_F32, "v_cmp_lt_f32_e32", zero, vR);
-            e_.vop3cmpG(VOP3_CMP_GT_F32, "v_cmp_gt_f32_e64", t0, one, false, r);
-            e_.sop2(SOP2_AND_B64, "s_and_b64", vcc, vcc, t0);
-        } else if (want == 6.0f) {  // -1 < r < 0
-            e_.vopc(VOPC_CMP_GT_F32, "v_cmp_gt_f32_e32", zero, vR);
-            e_.vop3cmpG(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", t0, mone, false, r);
-            e_.sop2(SOP2_AND_B64, "s_and_b64", vcc, vcc, t0);
+        else if (want == 2.0f || want == 6.0f) {
+            // 0 < r < 1 (bits 0x00000001 .. 0x3F7FFFFF) or -1 < r < 0 (0x80000001 .. 0xBF7FFFFF): an open interval of floats is a
+            // closed interval of bit patterns - denormals inside, +-0, +-1, Inf and NaN outside - so one integer add (double-rate
+            // class) and one unsigned compare do for the two float compares and the scalar AND
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 5, imm32(want == 2.0f ? 0xffffffffu : 0x7fffffffu), vR);
+            e_.vopc(VOPC_CMP_GT_U32, "v_cmp_gt_u32_e32", imm32(0x3f7fffffu), 5);
         } else return false;  // CCR never takes this value
         return true;
     }
