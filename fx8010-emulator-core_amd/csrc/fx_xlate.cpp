@@ -429,7 +429,7 @@ enum : uint32_t {
     VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_GT_U32 = 0xcc,
-    SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6,
+    SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6, SOPP_CBRANCH_VCCNZ = 7,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
@@ -607,6 +607,7 @@ class Translator {
             e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSEndSample));  // the template's epilogue
         }
 
+        if (!emitDeferred()) { if (err) *err = err_; return false; }
         // ---- cold entry (from the template): scalar copies of what the loop keeps in SGPRs
         e_.cold(true);
         if (coldEntry) *coldEntry = base_ + (uint32_t)e_.bytes();
@@ -829,71 +830,44 @@ class Translator {
             e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
         }
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
-        const uint32_t slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes, y1Off = slopeOff + 512;
-        bool withThresholdsFirst = true;  // (first fetch of the quick form: v7 holds the offset already)
-        auto fetchSegment = [&](bool withThresholds) {
-            if (lds) {
-                if (!quick || !withThresholdsFirst) e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
-                withThresholdsFirst = false;
-                if (withThresholds) e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);   // xthr[g], xthr[g+1]
-                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, kLdsX1);                       // x1[g]
-                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 2, 7, slopeOff);
-                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 4, 7, y1Off);
-            } else {
-                if (withThresholds) {
-                    e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
-                    e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSLutXthr);                // xthr[g], xthr[g+1]
-                }
-                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
-                e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                     // x1[g]
-                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
-                e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                     // slope, y1
-            }
-        };
-        auto segmentMath = [&](int from) {
-            if (from <= 0) e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
-            e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(12), vreg64(2), vreg64(12), nullptr);
-            e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(4), nullptr);
-        };
+        LutSite site;
+        site.vA = vA;
+        site.lds = lds;
+        site.guarded = guarded;
+        site.quick = quick;
+        site.window = window;
+        site.slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes;
         // Where the operand is known to be in the table (not guarded) the guess is checked without its thresholds: d = x - x1[g]
         // must lie in [0, W), W a constant of the grid (fx_frontend.cpp lutGuessWindowHi) - one unsigned compare of d's high
         // word, three LDS reads instead of four.  A miss (one lane in ~10^5 within reach of a threshold) reads the thresholds
         // after all and corrects the index as the guarded form does.
-        fetchSegment(window == 0);
+        lutFetch(site, window == 0, quick);
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
         if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
         // the segment arithmetic goes ahead on the guess while the scalar unit makes up its mind (the compares' results
-        // reach it a pipeline later: checking first would stall the wave twice per LOG/EXP); a miss redoes it below
-        Emitter::Fixup hit;
+        // reach it a pipeline later: checking first would stall the wave twice per LOG/EXP); a miss redoes it
         if (window) {
             e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);         // d = x - x1
             e_.vopc(VOPC_CMP_LE_U32, "v_cmp_le_u32_e32", imm32(window, true), 13);                     // lanes outside [0, W)
-            segmentMath(1);
+            lutSegmentMath(1);
         } else {
             e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                    // x >= xthr[g+1]: one up
             e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));  // x <  xthr[g]  : one down
-            segmentMath(0);
+            lutSegmentMath(0);
             e_.sop2(SOP2_OR_B64, "s_or_b64", vcc, vcc, sreg64(kSTemp));
         }
-        hit = e_.branchForward(SOPP_CBRANCH_VCCZ, "s_cbranch_vccz");
-        e_.cold(true);
-        if (window) {
-            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);
-            if (quick) e_.vop2(VOP2_LSHRREV_B32, "v_lshrrev_b32_e32", 6, imm32(3), 7);
-            e_.waitLgkm0();
-            e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(vA), vreg(8));
+        if (lds) {
+            // the miss path lives behind the loop (emitDeferred): the hit path falls through its branch
+            Deferred d;
+            d.entry = e_.branchForward(SOPP_CBRANCH_VCCNZ, "s_cbranch_vccnz");
+            d.resume = e_.words();
+            d.lut = site;
+            deferred_.push_back(d);
+        } else {
+            Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_VCCZ, "s_cbranch_vccz");
+            lutMiss(site);
+            e_.bind(hit);
         }
-        e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(vA), 9);                        // (VCC again: the carry of the correction)
-        e_.sopp(SOPP_NOP, "s_nop", 1, true);
-        e_.addCarry(6);
-        e_.subBorrow(6, kSTemp, kSTemp + 2);
-        if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
-        fetchSegment(false);
-        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
-        if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
-        segmentMath(0);
-        e_.cold(false);
-        e_.bind(hit);
         if (guarded) {
             // the index can leave 0..63 (x outside the table, or NaN): out-of-domain flag, as h_lut sets it.  The two
             // bounds are constants of the table grid (fx_model.hpp xdom): !(lo <= x) or !(hi > x)
@@ -916,6 +890,67 @@ class Translator {
             taintIfNonFinite(vR);
             if (!leaveIfTainted((*exactReturns_)[syncIndex(1)])) return false;
         }
+        return true;
+    }
+
+    // one LOG / EXP site: what its fetch and its miss path need to know
+    struct LutSite { int vA = 0; bool lds = false, guarded = false, quick = false; uint32_t window = 0, slopeOff = 0; };
+    // segment v6 (index) or, first fetch of the quick form, v7 (byte offset): x1 -> v[10:11], slope -> v[2:3], y1 -> v[4:5],
+    // thresholds -> v[8:9]
+    void lutFetch(const LutSite& s, bool withThresholds, bool offsetReady) {
+        if (s.lds) {
+            if (!offsetReady) e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+            if (withThresholds) e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);   // xthr[g], xthr[g+1]
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, kLdsX1);                       // x1[g]
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 2, 7, s.slopeOff);
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 4, 7, s.slopeOff + 512);
+        } else {
+            if (withThresholds) {
+                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
+                e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 8, 7, kSLutXthr);                // xthr[g], xthr[g+1]
+            }
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
+            e_.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 10, 7, kSLutX1);                     // x1[g]
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(4), 6);
+            e_.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 2, 7, kSLutSeg);                     // slope, y1
+        }
+    }
+    void lutSegmentMath(int from) {
+        if (from <= 0) e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(10), nullptr, 2);   // x - x1
+        e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(12), vreg64(2), vreg64(12), nullptr);
+        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(12), vreg64(12), vreg64(4), nullptr);
+    }
+    // the guess was off by one in some lane: thresholds (read now if the window test stood in for them), corrected index,
+    // second trip.  Leaves the segment arithmetic's result in v[12:13] like the hit path.
+    void lutMiss(const LutSite& s) {
+        const Src zero = imm32(0), top = imm32(63);
+        e_.cold(true);
+        if (s.window) {
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);
+            if (s.quick) e_.vop2(VOP2_LSHRREV_B32, "v_lshrrev_b32_e32", 6, imm32(3), 7);
+            e_.waitLgkm0();
+            e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(s.vA), vreg(8));
+        }
+        e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", vreg(s.vA), 9);                      // (VCC again: the carry of the correction)
+        e_.sopp(SOPP_NOP, "s_nop", 1, true);
+        e_.addCarry(6);
+        e_.subBorrow(6, kSTemp, kSTemp + 2);
+        if (s.guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
+        lutFetch(s, false, false);
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(s.vA));
+        if (s.lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
+        lutSegmentMath(0);
+        e_.cold(false);
+    }
+    // code that almost never runs, kept out of the loop body: entered by a forward branch, returns by a backward one
+    struct Deferred { Emitter::Fixup entry; size_t resume = 0; LutSite lut; };
+    bool emitDeferred() {
+        for (const Deferred& d : deferred_) {
+            e_.bind(d.entry);
+            lutMiss(d.lut);
+            if (!e_.branchBack(SOPP_BRANCH, "s_branch", d.resume)) return fail("translated loop too long for a branch");
+        }
+        deferred_.clear();
         return true;
     }
 
@@ -1668,6 +1703,7 @@ class Translator {
     std::vector<uint32_t> returns_;  // sync points of this stream (see run())
     std::vector<int> pending_;       // VGPRs with a TRAM read in flight
     std::vector<std::pair<uint32_t, int>> pool_;  // uniform constants kept in SGPRs for the whole loop: (bits, SGPR)
+    std::vector<Deferred> deferred_;
     const std::vector<MicroOp>* records_ = nullptr;
     size_t consumed_ = (size_t)-1;   // record already translated together with its predecessor
     bool predOpen_ = false;          // EXEC is restricted by a PRED / a simple shadow

@@ -207,6 +207,14 @@ def test_quick_lut_guess_is_generated_for_bounded_operands():
     fe = A.FrontEnd(1)
     assert fe.load_text(P.CONFIGS["config4"]())
     code, listing = fe.translate(0, 0)
+    # the miss paths live behind the loop: every LOG/EXP falls through an s_cbranch_vccnz whose target lies behind the loop
+    # branch, and each miss path returns to the instruction after its branch
+    lines, offs, branches = branch_targets(listing)
+    loop = [k for k, t, end in branches if t == 0 and lines[k].startswith("s_cbranch_scc1")][0]
+    misses = [(k, t) for k, t, end in branches if lines[k].startswith("s_cbranch_vccnz")]
+    assert len(misses) == listing.count("v_cmp_le_u32_e32 vcc") and all(t > offs[loop] for k, t in misses)
+    returns = sorted(t for k, t, end in branches if lines[k].startswith("s_branch") and k > loop and 0 < t < offs[loop])
+    assert returns == sorted(int(offs[k + 1]) for k, t in misses)
     assert listing.count("v_and_b32_e32 v7") == listing.count("v_cmp_le_u32_e32 vcc") > 0
     assert "v_cvt_i32_f32" not in listing           # config4's LOG/EXP operands are all results of saturating instructions
     assert assemble(listing) == code
