@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 
@@ -523,16 +524,17 @@ class Translator {
             // the leading TRAM reads were issued one sample ago (s94 = 1) or are issued here (first sample of a launch, or
             // a launch whose cursor distance rules the early issue out)
             e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSPrefetched), imm32(1));
-            Emitter::Fixup toHot = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
-            e_.cold(true);
-            for (int k = 0; k < H.leadCount; ++k)
-                if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false)) { if (err) *err = err_; return false; }
-            e_.waitVmcnt(0);
-            e_.cold(false);
-            Emitter::Fixup toJoin = e_.branchForward(SOPP_BRANCH, "s_branch");
-            e_.bind(toHot);
+            Emitter::Fixup inPlace = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
             e_.waitVmcnt(H.vmemAfterHoist + storesPerSample);  // younger than the reads: the rest of that sample's TRAM traffic and its PCM stores
-            e_.bind(toJoin);
+            // (the in-place reads sit behind the loop: a steady sample falls through)
+            const int leadCount = H.leadCount;
+            defer(inPlace, [this, &records, leadCount]() {
+                e_.cold(true);
+                for (int k = 0; k < leadCount; ++k)
+                    if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false)) deferredFailed_ = true;
+                e_.waitVmcnt(0);
+                e_.cold(false);
+            });
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSPrefetched), imm32(0));
         } else {
             e_.waitVmcnt(prog_.tramOpsInline + storesPerSample);  // the PCM input requested one sample ago
@@ -858,11 +860,7 @@ class Translator {
         }
         if (lds) {
             // the miss path lives behind the loop (emitDeferred): the hit path falls through its branch
-            Deferred d;
-            d.entry = e_.branchForward(SOPP_CBRANCH_VCCNZ, "s_cbranch_vccnz");
-            d.resume = e_.words();
-            d.lut = site;
-            deferred_.push_back(d);
+            defer(e_.branchForward(SOPP_CBRANCH_VCCNZ, "s_cbranch_vccnz"), [this, site]() { lutMiss(site); });
         } else {
             Emitter::Fixup hit = e_.branchForward(SOPP_CBRANCH_VCCZ, "s_cbranch_vccz");
             lutMiss(site);
@@ -943,11 +941,21 @@ class Translator {
         e_.cold(false);
     }
     // code that almost never runs, kept out of the loop body: entered by a forward branch, returns by a backward one
-    struct Deferred { Emitter::Fixup entry; size_t resume = 0; LutSite lut; };
+    struct Deferred { Emitter::Fixup entry; size_t resume = 0; std::function<void()> body; };
+    // the hot path continues at the current position; `body` runs behind the loop when the branch at `entry` is taken
+    void defer(const Emitter::Fixup& entry, std::function<void()> body) {
+        Deferred d;
+        d.entry = entry;
+        d.resume = e_.words();
+        d.body = std::move(body);
+        deferred_.push_back(std::move(d));
+    }
     bool emitDeferred() {
-        for (const Deferred& d : deferred_) {
+        for (size_t k = 0; k < deferred_.size(); ++k) {  // (a body may defer paths of its own)
+            const Deferred d = deferred_[k];
             e_.bind(d.entry);
-            lutMiss(d.lut);
+            d.body();
+            if (deferredFailed_) return false;
             if (!e_.branchBack(SOPP_BRANCH, "s_branch", d.resume)) return fail("translated loop too long for a branch");
         }
         deferred_.clear();
@@ -1033,13 +1041,12 @@ class Translator {
         Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
         slotAddress(pos, t);
         e_.global(GLOBAL_LOAD_DWORD, true, vR, kVLane4, kSAddr);
-        Emitter::Fixup done = e_.branchForward(SOPP_BRANCH, "s_branch");
-        e_.bind(outside);
-        e_.waitVmcnt(0);
-        e_.cold(true);
-        e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
-        e_.cold(false);
-        e_.bind(done);
+        defer(outside, [this, vR]() {  // slot beyond the allocation (behind the loop): no load, everything drained instead
+            e_.waitVmcnt(0);
+            e_.cold(true);
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+            e_.cold(false);
+        });
         if (deferred) pending_.push_back(vR);
         if (!prog_.tramDane) advanceCursor(cursor, t);
         return true;
@@ -1066,11 +1073,10 @@ class Translator {
         Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
         slotAddress(pos, t);
         e_.global(GLOBAL_STORE_DWORD, false, vA, kVLane4, kSAddr);
-        Emitter::Fixup done = e_.branchForward(SOPP_BRANCH, "s_branch");
-        e_.bind(outside);
-        e_.waitVmcnt(0);
-        e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
-        e_.bind(done);
+        defer(outside, [this]() {
+            e_.waitVmcnt(0);
+            e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
+        });
         if (!prog_.tramDane) advanceCursor(cursor, t);
         return true;
     }
@@ -1704,6 +1710,7 @@ class Translator {
     std::vector<int> pending_;       // VGPRs with a TRAM read in flight
     std::vector<std::pair<uint32_t, int>> pool_;  // uniform constants kept in SGPRs for the whole loop: (bits, SGPR)
     std::vector<Deferred> deferred_;
+    bool deferredFailed_ = false;
     const std::vector<MicroOp>* records_ = nullptr;
     size_t consumed_ = (size_t)-1;   // record already translated together with its predecessor
     bool predOpen_ = false;          // EXEC is restricted by a PRED / a simple shadow
