@@ -305,6 +305,8 @@ int Batch::ensureLowered() {
         std::vector<int> trackRows;
         for (int reg : trackRegs_) trackRows.push_back(low_.rowOfReg[(size_t)reg]);
         XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow, low_.latchRow, trackRows);
+        // 256 bytes per wavefront and slot; the Infinity Cache holds 256 MiB
+        xprog.tramStreaming = ((size_t)iSlotsAlloc_ + (size_t)xSlotsAlloc_) * (((size_t)n_ + 63) / 64) * 256 > ((size_t)512 << 20);
         XlateImage image;
         const XlateTemplate* tmpl = nullptr;
         bool built = false;

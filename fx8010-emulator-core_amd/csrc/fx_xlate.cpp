@@ -287,14 +287,14 @@ class Emitter {
         if (text_) line(std::string(name) + " " + sdst.text + ", " + s0.text + ", " + s1.text);
     }
     // global_{load,store}_dword with an SGPR base pair and a VGPR byte offset, no immediate offset
-    void global(uint32_t op, bool load, int vdata, int vaddr, int sbase) {
-        w_.push_back(0xdc008000u | (op << 18));  // (offset field 0)
+    void global(uint32_t op, bool load, int vdata, int vaddr, int sbase, bool nt = false) {
+        w_.push_back(0xdc008000u | (op << 18) | (nt ? 1u << 17 : 0u));  // (offset field 0)
         w_.push_back((uint32_t)vaddr | (load ? 0u : (uint32_t)vdata << 8) | ((uint32_t)sbase << 16) | (load ? (uint32_t)vdata << 24 : 0u));
         ++count_;
         const std::string base = "s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]";
         if (!text_) return;
-        if (load) line("global_load_dword v" + std::to_string(vdata) + ", v" + std::to_string(vaddr) + ", " + base);
-        else line("global_store_dword v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + ", " + base);
+        if (load) line("global_load_dword v" + std::to_string(vdata) + ", v" + std::to_string(vaddr) + ", " + base + (nt ? " nt" : ""));
+        else line("global_store_dword v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + ", " + base + (nt ? " nt" : ""));
     }
     void waitVmcnt0() { waitVmcnt(0); }
     // global_load_dwordx2 / x4 into v[vdata ..], VGPR byte offset, SGPR base pair
@@ -636,6 +636,12 @@ class Translator {
 
   private:
     bool fail(const std::string& m) { err_ = m; return false; }
+    // non-temporal hint per access class (1 TRAM load, 2 TRAM store, 4 PCM load, 8 PCM store); FX_XLATE_NT overrides (diagnostics)
+    bool streaming(int cls) const {
+        static const int mask = std::getenv("FX_XLATE_NT") ? std::atoi(std::getenv("FX_XLATE_NT")) : -1;
+        if (mask >= 0) return (mask & cls) != 0;
+        return prog_.tramStreaming && (cls & 3) != 0;
+    }
 
     static int vrow(uint32_t r) { return kRegFileBase + (int)r; }
 
@@ -671,9 +677,9 @@ class Translator {
         }
         for (int c = 0; c < channels; ++c) {
             if (load) {
-                if (prog_.inRows[(size_t)c] >= 0) e_.global(GLOBAL_LOAD_DWORD, true, kVInput + c, kVInstance4, kSAddr);
+                if (prog_.inRows[(size_t)c] >= 0) e_.global(GLOBAL_LOAD_DWORD, true, kVInput + c, kVInstance4, kSAddr, streaming(4));
             } else {
-                e_.global(GLOBAL_STORE_DWORD, false, vrow((uint32_t)prog_.latchRows[(size_t)c]), kVInstance4, kSAddr);
+                e_.global(GLOBAL_STORE_DWORD, false, vrow((uint32_t)prog_.latchRows[(size_t)c]), kVInstance4, kSAddr, streaming(8));
             }
             if (c + 1 < channels) {
                 e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSAddr), sreg(kSChannelBytes));
@@ -1040,7 +1046,7 @@ class Translator {
         e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSTramSlots[t]));
         Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
         slotAddress(pos, t);
-        e_.global(GLOBAL_LOAD_DWORD, true, vR, kVLane4, kSAddr);
+        e_.global(GLOBAL_LOAD_DWORD, true, vR, kVLane4, kSAddr, streaming(1));
         defer(outside, [this, vR]() {  // slot beyond the allocation (behind the loop): no load, everything drained instead
             e_.waitVmcnt(0);
             e_.cold(true);
@@ -1072,7 +1078,7 @@ class Translator {
         e_.sopc(SOPC_CMP_LT_I32, "s_cmp_lt_i32", pos, sreg(kSAddr));
         Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
         slotAddress(pos, t);
-        e_.global(GLOBAL_STORE_DWORD, false, vA, kVLane4, kSAddr);
+        e_.global(GLOBAL_STORE_DWORD, false, vA, kVLane4, kSAddr, streaming(2));
         defer(outside, [this]() {
             e_.waitVmcnt(0);
             e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));

@@ -82,6 +82,9 @@ struct XlateProgram {
     int tramOpsInline = 0;        // inline TRAM instructions per sample of the steady stream (each issues one VMEM operation)
     std::vector<int> trackRows;   // register-file row of track slot t (at most kMaxTracks); such rows are of the WILD class
     HoistPlan hoist;
+    // delay lines far larger than the caches (set by the batch from slots x instances): TRAM loads and stores carry the
+    // non-temporal hint - every slot is written once and read once, a whole delay later (+2 % at the memory-bound probe)
+    bool tramStreaming = false;
     // uniform constants kept in VGPRs above the register file for the whole launch: (bit pattern, VGPR), set by planXlate
     // (the constants of the LOG/EXP index guess, which must be VGPR sources to stay in the double-rate instruction class)
     std::vector<std::pair<uint32_t, int>> vconst;
