@@ -239,12 +239,12 @@ int Batch::ensureLowered() {
                 // smallest VGPR build that holds the register file = most wavefronts per SIMD
                 int v = ASM_V64;
                 while (v < ASM_V256 && fresh.nRows > kAsmVgprRows[v]) ++v;
-                // ... and, for a program with LOG / EXP, a larger one while that costs no residency this batch can use: the
-                // translator keeps the constants of its index guess in VGPRs above the register file (fx_xlate.hpp vconst)
-                if (fresh.usesLut) {
+                // ... and a larger one while that costs no residency this batch can use: the translator keeps the constants of
+                // its LOG / EXP index guess and a small cache of products in VGPRs above the register file (fx_xlate.hpp)
+                {
                     const int wavesPerSimd = (int)((((size_t)n_ + 63) / 64 + 1023) / 1024);  // 256 CUs x 4 SIMDs
                     auto usable = [&](int q) { return std::min(kAsmWavesPerSimd[q], std::max(wavesPerSimd, 1)); };
-                    while (v < ASM_V256 && kAsmVgprRows[v] - fresh.nRows < kMaxVgprConstants && usable(v + 1) >= usable(v)) ++v;
+                    while (v < ASM_V256 && kAsmVgprRows[v] - fresh.nRows < kSpareVgprsWanted && usable(v + 1) >= usable(v)) ++v;
                 }
                 const char* pin = forceHip ? std::strstr(forceHip, "_v") : nullptr;
                 if (pin && (std::strncmp(forceHip, "asm_v", 5) == 0 || std::strncmp(forceHip, "xlate_v", 7) == 0)) {

@@ -559,6 +559,11 @@ class Translator {
         if (fast_ && !leaveIfTainted((*exactReturns_)[syncIndex(0)])) { if (err) *err = err_; return false; }
 
         // ---- the program
+        products_.assign((size_t)(fast_ ? prog_.cseEntries : 0), Product());
+        for (size_t k = 0; k < products_.size(); ++k) {
+            products_[k].vP64 = prog_.cseBase + 2 * (int)k;
+            products_[k].vP = prog_.cseBase + 2 * prog_.cseEntries + (int)k;
+        }
         bool ended = false;
         for (size_t i = 0; i < records.size(); ++i) {
             const MicroOp& r = records[i];
@@ -566,6 +571,7 @@ class Translator {
             index_ = i;
             if (slot == AS_ENDSAMPLE) { ended = true; break; }
             if ((int)i >= H.leadCount && i != consumed_ && !one(r, slot)) { if (err) *err = err_; return false; }
+            if (slot != AS_NOP && slot != AS_PRED && slot != AS_UNPRED && slot != AS_SKIP) cseKill(r.w[5]);  // (its R row, if it has one)
             if (!isLast_ && H.leadCount > 0 && (int)i == std::max(H.hoistAfter, H.leadCount - 1)) {
                 // the next sample's leading reads, unless this launch keeps them in place (s95 = 0, see emitInit)
                 if (predOpen_ || regionPreds_ > 0) { if (err) *err = "internal: hoist point inside a SKIP shadow"; return false; }
@@ -575,6 +581,7 @@ class Translator {
                 Emitter::Fixup skip = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
                 for (int k = 0; k < H.leadCount; ++k)
                     if (!tramRead(records[(size_t)k], records[(size_t)k].w[0], false, true)) { if (err) *err = err_; return false; }
+                for (int k = 0; k < H.leadCount; ++k) cseKill(records[(size_t)k].w[5]);
                 e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSPrefetched), imm32(1));
                 e_.bind(skip);
             }
@@ -1181,13 +1188,65 @@ class Translator {
         return true;
     }
 
-    // p = X * Y into v3 unless both are uniform (then the record's X word holds the folded product)
-    bool product(const MicroOp& r, uint32_t kind, bool* inV3) {
+    // ---- products of a uniform multiplier and a row, kept while the row is not rewritten (fast streams only).
+    // "interp s1, s1, k, a ; interp s2, s2, k, a ; ..." or a bank of "macs t, s_i, a, 0.03" multiply the same row by the same
+    // constant over and over: the product (and, for INTERP, its conversion to fp64) is computed once into a spare VGPR above
+    // the register file and reused until an instruction writes the row.  Entries are created outside SKIP shadows only (all
+    // lanes valid) and only when a later instruction asks for the same product; every sample starts with an empty cache.
+    struct Product { uint32_t c = 0, row = 0; int vP = -1, vP64 = -1; bool live = false, wide = false; };
+    bool inShadow() const { return predOpen_ || regionPreds_ > 0; }
+    // the (constant, row) a record multiplies, if it multiplies at all (mirrors macs() / interp())
+    bool productKey(const MicroOp& r, uint32_t* c, uint32_t* row) const {
+        const uint32_t slot = r.w[0];
+        if (slot < AS_MACS || slot >= (uint32_t)kAsmSlots) return false;
+        const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2;
+        if (family == 2 || kind == 7) return false;
+        uint32_t cb, rw;
+        if ((kind & 6u) == 2u) { cb = r.w[3]; rw = r.w[4]; }
+        else if ((kind & 6u) == 4u) { cb = r.w[4]; rw = r.w[3]; }
+        else return false;
+        if ((cb & 0x7fffffffu) == 0x3f800000u) return false;  // +-1.0: no multiplication (INTERP: only a unit Y)
+        uint32_t zc;
+        if (family == 0 && zeroPlusScaled(r, &zc, nullptr) && pooled(zc) >= 0) return false;  // one fma, no separate product
+        *c = cb;
+        *row = rw;
+        return true;
+    }
+    bool usedAgain(size_t from, uint32_t c, uint32_t row) const {
+        const std::vector<MicroOp>& rec = *records_;
+        for (size_t k = from + 1; k < rec.size() && k < from + 600; ++k) {
+            if (rec[k].w[0] == AS_ENDSAMPLE) return false;
+            uint32_t c2, row2;
+            if (productKey(rec[k], &c2, &row2) && c2 == c && row2 == row) return true;
+            if (rec[k].w[0] != AS_NOP && rec[k].w[0] != AS_PRED && rec[k].w[0] != AS_UNPRED && rec[k].w[0] != AS_SKIP && rec[k].w[5] == row) return false;
+        }
+        return false;
+    }
+    void cseKill(uint32_t row) {
+        for (Product& p : products_)
+            if (p.live && p.row == row) p.live = false;
+    }
+    void cseReset() {
+        for (Product& p : products_) p.live = false;
+    }
+    int cseAlloc() {
+        for (size_t k = 0; k < products_.size(); ++k)
+            if (!products_[k].live) return (int)k;
+        for (size_t k = 0; k < products_.size(); ++k)
+            if (!usedAgain(index_, products_[k].c, products_[k].row)) return (int)k;
+        return -1;
+    }
+
+    // p = X * Y: *pv = the VGPR that holds it (v3, or a cache register: then *entry is its cache entry), unless both are
+    // uniform (*inV3 false: the record's X word holds the folded product)
+    bool product(const MicroOp& r, uint32_t kind, bool* inV3, int* pv = nullptr, int* entry = nullptr) {
         const bool uX = kind & 2, uY = kind & 4;
         *inV3 = !(uX && uY);
+        if (pv) *pv = 3;
+        if (entry) *entry = -1;
         if (uX && uY) return true;
         Src a;
-        int b;
+        int b, dst = 3;
         if (!uX && !uY) {
             if (!operand(r.w[3], false, &a) || !row(r.w[4], &b)) return false;
         } else if (uX) {
@@ -1201,7 +1260,28 @@ class Translator {
             a = value(r.w[4]);
             if (!row(r.w[3], &b)) return false;
         }
-        e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 3, a, b);
+        if (fast_ && pv && entry && !products_.empty() && (uX != uY)) {
+            const uint32_t c = uX ? r.w[3] : r.w[4], rw = uX ? r.w[4] : r.w[3];
+            for (size_t k = 0; k < products_.size(); ++k)
+                if (products_[k].live && products_[k].c == c && products_[k].row == rw) {
+                    *pv = products_[k].vP;
+                    *entry = (int)k;
+                    ++stats_.reusedProducts;
+                    return true;
+                }
+            int k;
+            if (!inShadow() && usedAgain(index_, c, rw) && (k = cseAlloc()) >= 0) {
+                Product& p = products_[(size_t)k];
+                p.c = c;
+                p.row = rw;
+                p.live = true;
+                p.wide = false;
+                dst = p.vP;
+                *pv = dst;
+                *entry = k;
+            }
+        }
+        e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", dst, a, b);
         return true;
     }
 
@@ -1281,8 +1361,9 @@ class Translator {
             if (unitWord >> 31) neg = !neg;
             inV3 = true;
             ++stats_.unitMultipliers;
-        } else if (!product(r, kind, &inV3)) {
-            return false;
+        } else {
+            int entry;
+            if (!product(r, kind, &inV3, &pv, &entry)) return false;
         }
         const bool within = resultWithinUnit(neg ? 1 : 0, kind, r);  // then the sum goes straight to its row
         const int d = within ? vR : 2;
@@ -1384,11 +1465,25 @@ class Translator {
             return interpTail(r, kind, vreg(vX), vR);
         }
         bool inV3;
-        if (!product(r, kind, &inV3)) return false;
-        return interpTail(r, kind, inV3 ? vreg(3) : value(r.w[3]), vR);
+        int pv, entry;
+        if (!product(r, kind, &inV3, &pv, &entry)) return false;
+        return interpTail(r, kind, inV3 ? vreg(pv) : value(r.w[3]), vR, entry);
     }
-    // p = fp32 product X*Y (a VGPR or the folded constant)
-    bool interpTail(const MicroOp& r, uint32_t kind, const Src& p, int vR) {
+    // the fp32 product as an fp64 operand: converted into v[tmp:tmp+1], or taken from / put into its cache entry
+    Src wideProduct(const Src& p, int entry, int tmp) {
+        if (entry >= 0 && products_[(size_t)entry].vP64 >= 0) {
+            Product& e = products_[(size_t)entry];
+            if (!e.wide && !inShadow()) {
+                e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(e.vP64), p);
+                e.wide = true;
+            }
+            if (e.wide) return vreg64(e.vP64);
+        }
+        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(tmp), p);
+        return vreg64(tmp);
+    }
+    // p = fp32 product X*Y (a VGPR or the folded constant); entry = its product-cache entry or -1
+    bool interpTail(const MicroOp& r, uint32_t kind, const Src& p, int vR, int entry = -1) {
         const bool within = resultWithinUnit(3, kind, r);
         const int d = within ? vR : 2;
         if (within) ++stats_.unsaturated;
@@ -1407,8 +1502,7 @@ class Translator {
             const Src m = inl ? named(inl->code, inl->text) : sreg64(kSRecord + 6);
             if (productWithFloatIsExact(omx)) {
                 // (1-X)*A is exact in fp64 for every float A, so mul-then-add rounds once - exactly what one fma does
-                e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(10), p);
-                Src addend = vreg64(10);
+                Src addend = wideProduct(p, entry, 10);
                 e_.vop3(VOP3_FMA_F64, "v_fma_f64", vreg64(6), m, vreg64(8), &addend);
                 e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(d), vreg64(6));
                 if (!within) satStore(vR);
@@ -1424,8 +1518,8 @@ class Translator {
             e_.vop3(VOP3_FMA_F64, "v_fma_f64", vreg64(6), vreg64(6), named(243, "-1.0"), &plusOne);
             e_.vop3(VOP3_MUL_F64, "v_mul_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
         }
-        e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(8), p);
-        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), vreg64(6), vreg64(8), nullptr);
+        const Src wide = wideProduct(p, entry, 8);
+        e_.vop3(VOP3_ADD_F64, "v_add_f64", vreg64(6), vreg64(6), wide, nullptr);
         e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(d), vreg64(6));
         if (!within) satStore(vR);
         return true;
@@ -1716,6 +1810,7 @@ class Translator {
     std::vector<int> pending_;       // VGPRs with a TRAM read in flight
     std::vector<std::pair<uint32_t, int>> pool_;  // uniform constants kept in SGPRs for the whole loop: (bits, SGPR)
     std::vector<Deferred> deferred_;
+    std::vector<Product> products_;
     bool deferredFailed_ = false;
     const std::vector<MicroOp>* records_ = nullptr;
     size_t consumed_ = (size_t)-1;   // record already translated together with its predecessor
@@ -2078,6 +2173,16 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
             int v = tmpl.vgprs;
             for (uint32_t c : {kLutGuess.scale, kLutGuess.bias, kLutGuess.magic, kLutGuess.mask}) pooledProgram.vconst.emplace_back(c, --v);
         }
+    }
+    // ... and the product cache of the fast streams (Translator::product): per entry an even-aligned pair and a single
+    {
+        const char* knob = std::getenv("FX_XLATE_CSE");  // diagnostics: number of entries (0 = none)
+        const int top = tmpl.vgprs - (int)pooledProgram.vconst.size();
+        const int base = (kRegFileBase + (int)program.wildRow.size() + 1) & ~1;
+        int entries = std::min(kProductCacheEntries, knob ? std::atoi(knob) : kProductCacheEntries);
+        while (entries > 0 && base + 3 * entries > top) --entries;
+        pooledProgram.cseBase = base;
+        pooledProgram.cseEntries = entries;
     }
     XlateProgram prog[2] = {pooledProgram, pooledProgram};
     uint32_t bytes[4] = {0, 0, 0, 0};  // steady fast, steady exact, last fast, last exact

@@ -88,8 +88,13 @@ struct XlateProgram {
     // uniform constants kept in VGPRs above the register file for the whole launch: (bit pattern, VGPR), set by planXlate
     // (the constants of the LOG/EXP index guess, which must be VGPR sources to stay in the double-rate instruction class)
     std::vector<std::pair<uint32_t, int>> vconst;
+    // product cache of the fast streams (fx_xlate.cpp Translator::product): cseEntries entries in the spare VGPRs from cseBase
+    // (even) on - the fp64 pairs first, then the fp32 products; set by planXlate
+    int cseBase = 0, cseEntries = 0;
 };
 constexpr int kMaxVgprConstants = 4;
+constexpr int kProductCacheEntries = 2;
+constexpr int kSpareVgprsWanted = kMaxVgprConstants + 3 * kProductCacheEntries + 1;  // what a VGPR build with room to spare is chosen for
 // nRows = rows of the register file, inputRows = the rows the PCM input goes to (-1: unused channel), latchRows = the
 // rows the PCM output comes from; one entry per channel
 XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, int iSize, int xSize,
@@ -106,6 +111,7 @@ struct XlateStats {
     int fusedSkips = 0;  // SKIPs translated as a predicate on the value that would have set their CCR
     int regions = 0;     // SKIP shadows run under one EXEC mask (no per-instruction PRED)
     int unitMultipliers = 0;  // multiplications by +-1.0 that were not emitted
+    int reusedProducts = 0;   // products of a uniform multiplier and a row taken from the product cache
     int fusedZeroAdds = 0;    // "R = 0 + X * c", |c| > 0.5, emitted as one fma (bit-identical, see fx_xlate.cpp zeroPlusScaled)
     int unsaturated = 0; // saturating instructions whose result provably lies in [-1, 1]: no v_med3 in the fast stream
     bool nonFiniteImmediate = false;  // a NaN / Inf among the uniform operands: no fast stream for this program

@@ -118,8 +118,12 @@ def test_structure_of_translated_code():
             budget = vgprs if vgprs else 256
             for m in re.finditer(r"\bv(\d+)\b", listing):
                 assert int(m.group(1)) < budget
+            fe.lower()
+            first_spare = 32 + fe.lower_info("num_rows")
             for m in re.finditer(r"v\[(\d+):(\d+)\]", listing):
-                assert int(m.group(2)) < 14  # temporaries only (v[2:5] .. v[12:13])
+                lo, hi = int(m.group(1)), int(m.group(2))
+                # temporaries (v[2:5] .. v[12:13]), or an even-aligned pair of the product cache above the register file
+                assert hi < 14 or (lo % 2 == 0 and lo >= first_spare and hi < budget and stream in (0, 2)), (name, m.group(0))
             # SGPR writes: sample index, PCM pointers, the record window, return address, scratch, TRAM cursors / LUT bases,
             # the two flags of the early TRAM reads
             allowed = {3, 12, 13, 14, 15} | set(range(18, 26)) | set(range(62, 68)) | set(range(80, 96))

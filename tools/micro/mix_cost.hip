@@ -27,6 +27,12 @@ __global__ void __launch_bounds__(64) k(float* out, int iters) {
         else if (KIND == 3) asm volatile(".rept 10\n" MACS(0, "") MACS(1, "") INTERP_MULONLY ".endr\n" OPS);                  // fast only: 5
         else if (KIND == 4) asm volatile(".rept 10\n" MACS(0, MED(0)) MACS(1, MED(1)) INTERP_FAST5 MED(3) ".endr\n" OPS);   // fp64-class replaced by fast ops: 12
         else if (KIND == 5) asm volatile(".rept 10\n" MACS(0, MED(0)) MACS(1, MED(1)) "v_mul_f32 %2, %11, %2\n v_cvt_f64_f32 %8, %0\n v_fma_f64 %8, %8, %10, %8\n v_cvt_f32_f64 %3, %8\n" MED(3) ".endr\n" OPS);  // one cvt fewer: 11
+        else if (KIND == 6)  // the full mix, fp64-class instructions spread between the others instead of in a row
+            asm volatile(".rept 10\n"
+                         "v_mul_f32 %0, %11, %0\n v_cvt_f64_f32 %8, %4\n v_add_f32 %0, %12, %0\n v_med3_f32 %0, %0, -1.0, 1.0\n"
+                         "v_cvt_f64_f32 %9, %5\n v_mul_f32 %1, %11, %1\n v_add_f32 %1, %12, %1\n v_fma_f64 %8, %8, %10, %9\n"
+                         "v_med3_f32 %1, %1, -1.0, 1.0\n v_mul_f32 %2, %11, %2\n v_cvt_f32_f64 %3, %8\n v_med3_f32 %6, %6, -1.0, 1.0\n"
+                         ".endr\n" OPS);
     }
     out[blockIdx.x * 64 + lane] = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + (float)(d0 + d1);
 }
@@ -57,6 +63,7 @@ int main() {
         run<3>("plain fp32 only (5 mul / add)", 5, d);
         run<4>("fp64-class replaced by 4 more mul / add", 12, d);
         run<5>("one v_cvt_f64_f32 fewer", 11, d);
+        run<6>("full mix, fp64-class spread out", 12, d);
     }
     return 0;
 }
