@@ -403,18 +403,20 @@ class Emitter {
     const std::vector<std::pair<uint32_t, int>>* pool_ = nullptr;
     // Issue cost of a wave64 VALU instruction on a busy SIMD, in clocks x 100.  Measured on MI355X as the time an instruction
     // adds to a realistic mix at four waves per SIMD (tools/micro/mix_cost.hip; the homogeneous loops of valu_rate.hip
-    // bound it from above): plain fp32 add / sub / mul, moves, 32-bit integer add / sub / and 2.1; v_fma_f32 2.5;
-    // v_med3 / min / max 2.7; conversions to and from fp64 and all fp64 arithmetic 4.4; everything else (compares,
-    // integer conversions, shifts, selects, carries) 4.1.
+    // bound it from above) and scaled so that the table reproduces that mix's own time (12 instructions in 14.8 ns at
+    // 2.35 GHz): plain fp32 add / sub / mul, moves, 32-bit integer add / sub / and / or / xor 2.05; v_fma_f32 2.4;
+    // v_med3 / min / max 2.6; conversions to and from fp64 and all fp64 arithmetic 4.25; everything else (compares,
+    // integer conversions, left shifts, selects, carries) 3.95.
     static bool startsWith(const char* name, const char* prefix) { return std::strncmp(name, prefix, std::strlen(prefix)) == 0; }
     static int issueCost(const char* name) {
-        static const char* const fast[] = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32"};
+        static const char* const fast[] = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32",
+                                           "v_or_b32", "v_xor_b32", "v_lshrrev_b32"};
         for (const char* f : fast)
-            if (startsWith(name, f)) return 212;
-        if (startsWith(name, "v_fma_f32")) return 250;
-        if (startsWith(name, "v_med3_f32") || startsWith(name, "v_max_f32") || startsWith(name, "v_min_f32")) return 270;
-        if (std::strstr(name, "f64")) return 440;
-        return 410;
+            if (startsWith(name, f)) return 205;
+        if (startsWith(name, "v_fma_f32")) return 240;
+        if (startsWith(name, "v_med3_f32") || startsWith(name, "v_max_f32") || startsWith(name, "v_min_f32")) return 260;
+        if (std::strstr(name, "f64")) return 425;
+        return 395;
     }
     void tally(const char* name) {
         if (cold_) return;
