@@ -1262,7 +1262,8 @@ class Translator {
             a = value(r.w[4]);
             if (!row(r.w[3], &b)) return false;
         }
-        if (fast_ && pv && entry && !products_.empty() && (uX != uY)) {
+        // (row 0 is the CCR: every instruction with a live CCR writes it on the side - never cached)
+        if (fast_ && pv && entry && !products_.empty() && (uX != uY) && (uX ? r.w[4] : r.w[3]) != 0u) {
             const uint32_t c = uX ? r.w[3] : r.w[4], rw = uX ? r.w[4] : r.w[3];
             for (size_t k = 0; k < products_.size(); ++k)
                 if (products_[k].live && products_[k].c == c && products_[k].row == rw) {

@@ -843,7 +843,7 @@ def product_cache_program(rng, length):
     for _ in range(length):
         kind = rng.integers(0, 10)
         r = regs[rng.integers(0, 3)]
-        y = regs[rng.integers(0, 3)] if rng.integers(0, 4) else "in"
+        y = regs[rng.integers(0, 3)] if rng.integers(0, 4) else ("in", "ccr")[rng.integers(0, 2)]  # (the CCR changes on the side)
         k = coef[rng.integers(0, 3)]
         if kind < 4:
             body.append("%s %s, %s, %s, %s" % (("macs", "macsn")[rng.integers(0, 2)], r, regs[rng.integers(0, 3)], y, k))
@@ -859,7 +859,7 @@ def product_cache_program(rng, length):
     return "\n".join(lines + body + ["end"])
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_product_cache_patterns(gpu, seed, monkeypatch):
     monkeypatch.delenv("FX_KERNEL", raising=False)
     rng = np.random.default_rng(4200 + seed)
