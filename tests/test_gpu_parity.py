@@ -832,38 +832,15 @@ def test_random_api_sequences(gpu, seed, monkeypatch):
     assert len(tiers) >= 1
 
 
-def product_cache_program(rng, length):
-    """Random program over a tiny vocabulary - three state registers, two coefficients, the input - so that the same
-    (coefficient x register) product turns up again and again: with the register unchanged in between (the translated tier
-    reuses the product), rewritten in between, rewritten inside a SKIP shadow, or first computed inside one."""
-    regs = ["a", "b", "c"]
-    coef = ["0.3", "0.75", "cut"]
-    lines = ["static a = 0.1", "static b = 0.2", "static c", "static t", "input in 0", "output out 0", "control cut = 0.4"]
-    body = []
-    for _ in range(length):
-        kind = rng.integers(0, 10)
-        r = regs[rng.integers(0, 3)]
-        y = regs[rng.integers(0, 3)] if rng.integers(0, 4) else ("in", "ccr")[rng.integers(0, 2)]  # (the CCR changes on the side)
-        k = coef[rng.integers(0, 3)]
-        if kind < 4:
-            body.append("%s %s, %s, %s, %s" % (("macs", "macsn")[rng.integers(0, 2)], r, regs[rng.integers(0, 3)], y, k))
-        elif kind < 8:
-            body.append("interp %s, %s, %s, %s" % (r, regs[rng.integers(0, 3)], k, y))
-        elif kind == 8:
-            body.append("macs t, %s, 0, 0" % r)
-            body.append("skip ccr, ccr, %d, %d" % ((6, 2, 8)[rng.integers(0, 3)], rng.integers(1, 3)))
-        else:
-            body.append("macs %s, %s, %s, %s" % (r, k, y, regs[rng.integers(0, 3)]))   # a product of two rows in between
-    # pad so that no SKIP reaches the end, then mix everything into the output
-    body += ["macs out, a, b, 0.5", "macs out, out, c, 0.5", "macs out, out, in, 0.1"]
-    return "\n".join(lines + body + ["end"])
-
-
 @pytest.mark.parametrize("seed", range(40))
 def test_product_cache_patterns(gpu, seed, monkeypatch):
+    import os
+    import sys
     monkeypatch.delenv("FX_KERNEL", raising=False)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_fuzz
     rng = np.random.default_rng(4200 + seed)
-    text = product_cache_program(rng, int(rng.integers(6, 60)))
+    text = stress_fuzz.product_cache_program(rng, int(rng.integers(6, 60)))
     N, S = 70, 40
     x = (rng.uniform(-1.0, 1.0, size=(S, N)) * rng.choice([1.0, 0.5, 1e-3], size=(1, N))).astype(np.float32)
     b, _ = check_batch(gpu, text, x, regs=("a", "b", "c", "t", "out", "ccr"))

@@ -42,6 +42,33 @@ def random_program(rng, n_instr, n_regs):
     return "\n".join(L)
 
 
+def product_cache_program(rng, length):
+    """Random program over a tiny vocabulary - three state registers, two coefficients, the input - so that the same
+    (coefficient x register) product turns up again and again: with the register unchanged in between (the translated tier
+    reuses the product), rewritten in between, rewritten inside a SKIP shadow, or first computed inside one."""
+    regs = ["a", "b", "c"]
+    coef = ["0.3", "0.75", "cut"]
+    lines = ["static a = 0.1", "static b = 0.2", "static c", "static t", "input in 0", "output out 0", "control cut = 0.4"]
+    body = []
+    for _ in range(length):
+        kind = rng.integers(0, 10)
+        r = regs[rng.integers(0, 3)]
+        y = regs[rng.integers(0, 3)] if rng.integers(0, 4) else ("in", "ccr")[rng.integers(0, 2)]  # (the CCR changes on the side)
+        k = coef[rng.integers(0, 3)]
+        if kind < 4:
+            body.append("%s %s, %s, %s, %s" % (("macs", "macsn")[rng.integers(0, 2)], r, regs[rng.integers(0, 3)], y, k))
+        elif kind < 8:
+            body.append("interp %s, %s, %s, %s" % (r, regs[rng.integers(0, 3)], k, y))
+        elif kind == 8:
+            body.append("macs t, %s, 0, 0" % r)
+            body.append("skip ccr, ccr, %d, %d" % ((6, 2, 8)[rng.integers(0, 3)], rng.integers(1, 3)))
+        else:
+            body.append("macs %s, %s, %s, %s" % (r, k, y, regs[rng.integers(0, 3)]))   # a product of two rows in between
+    # pad so that no SKIP reaches the end, then mix everything into the output
+    body += ["macs out, a, b, 0.5", "macs out, out, c, 0.5", "macs out, out, in, 0.1"]
+    return "\n".join(lines + body + ["end"])
+
+
 def random_program2(rng, n_instr, n_regs):
     """a second flavour: TRAM instructions anywhere (also inside SKIP shadows), longer and negative skip counts,
     LOG/EXP of registers, more `ccr` traffic"""
