@@ -239,8 +239,10 @@ int Batch::ensureLowered() {
                 // smallest VGPR build that holds the register file = most wavefronts per SIMD
                 int v = ASM_V64;
                 while (v < ASM_V256 && fresh.nRows > kAsmVgprRows[v]) ++v;
+                const int smallest = v;
                 // ... and a larger one while that costs no residency this batch can use: the translator keeps the constants of
-                // its LOG / EXP index guess and a small cache of products in VGPRs above the register file (fx_xlate.hpp)
+                // its LOG / EXP index guess and a small cache of products in VGPRs above the register file (fx_xlate.hpp).
+                // (The interpreter tier has no use for spare registers, but runs the same build: it is the translator's fallback.)
                 {
                     const int wavesPerSimd = (int)((((size_t)n_ + 63) / 64 + 1023) / 1024);  // 256 CUs x 4 SIMDs
                     auto usable = [&](int q) { return std::min(kAsmWavesPerSimd[q], std::max(wavesPerSimd, 1)); };
@@ -250,7 +252,7 @@ int Batch::ensureLowered() {
                 if (pin && (std::strncmp(forceHip, "asm_v", 5) == 0 || std::strncmp(forceHip, "xlate_v", 7) == 0)) {
                     // diagnostics: pin a (large enough) build of the interpreter (asm_vNN) or of the translator (xlate_vNN)
                     static const char* const tags[ASM_VARIANTS] = {"", "_v64", "_v72", "_v80", "_v96", "_v128", "_v168", "_v256"};
-                    for (int q = v; q < ASM_VARIANTS; ++q)
+                    for (int q = smallest; q < ASM_VARIANTS; ++q)
                         if (std::strcmp(pin, tags[q]) == 0) v = q;
                 }
                 asmVariant_ = (AsmVariant)v;
