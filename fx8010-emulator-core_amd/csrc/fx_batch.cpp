@@ -68,6 +68,8 @@ Batch::~Batch() {
     (void)hipFree(dTracks_);
     (void)hipFree(dIn_);
     (void)hipFree(dOut_);
+    if (hPinIn_) (void)hipHostFree(hPinIn_);
+    if (hPinOut_) (void)hipHostFree(hPinOut_);
     if (xlateModule_) (void)hipModuleUnload(xlateModule_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
@@ -630,7 +632,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     a.countHi = stateLayout_.countHi;
     a.staticCount = low_.staticCount;
     a.nRows = low_.nRows;
-    hipError_t e = hipEventRecord(ev0_, s);
+    hipError_t e = untimed_ ? hipSuccess : hipEventRecord(ev0_, s);
     if (e == hipSuccess) {
         if (useAsm_) {
             AsmArgs g{};
@@ -660,16 +662,18 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             e = launchStepBlock(a, low_.multipass, s);
         }
     }
-    if (e == hipSuccess) e = hipEventRecord(ev1_, s);
+    if (e == hipSuccess && !untimed_) e = hipEventRecord(ev1_, s);
     if (e != hipSuccess) return hipFail(e, "launch fx_step_block");
-    launched_ = true;
-    timed_ = true;
+    launched_ = !untimed_;  // (an untimed launch is synchronised by its caller before anything else happens)
+    timed_ = !untimed_;
     lastGrid_ = (unsigned)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
     return 0;
 }
 
 // pitch: instances per PCM row of the HOST buffers (>= n_); a shard of a larger batch reads / writes its columns of the
 // caller's [sample][channel][all instances] arrays in place (fx_shard.cpp)
+namespace { constexpr size_t kPinnedFloats = 512; }
+
 int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch) {
     (void)hipSetDevice(device_);
     if (pitch <= 0) pitch = n_;
@@ -678,6 +682,31 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
     if (nSamples == 0) return ensureLowered();
     if (!in || !out) return fail(FX_E_ARG, "null buffer");
     const size_t count = (size_t)nSamples * prog_.numChannels * (size_t)n_;
+    // A few KB of PCM (per-sample calls on a handful of instances): two staged copies cost more than the launch.  The kernel
+    // reads and writes pinned host memory instead - one launch, one synchronisation.
+    if (count <= kPinnedFloats && pitch == n_) {
+        if (!pinTried_) {
+            pinTried_ = true;
+            if (hipHostMalloc(reinterpret_cast<void**>(&hPinIn_), kPinnedFloats * 4, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc(reinterpret_cast<void**>(&hPinOut_), kPinnedFloats * 4, hipHostMallocDefault) != hipSuccess) {
+                if (hPinIn_) (void)hipHostFree(hPinIn_);
+                hPinIn_ = hPinOut_ = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        if (hPinIn_ && hPinOut_) {
+            std::memcpy(hPinIn_, in, count * 4);
+            waitLastLaunch();
+            untimed_ = true;  // no event pair around a launch that is waited for right here (last_kernel_ms: -1)
+            int rc = processDevice(hPinIn_, hPinOut_, nSamples, stream_);
+            untimed_ = false;
+            if (rc != 0) return rc;
+            hipError_t se = hipStreamSynchronize(stream_);
+            if (se != hipSuccess) return hipFail(se, "synchronising a small block");
+            std::memcpy(out, hPinOut_, count * 4);
+            return 0;
+        }
+    }
     if (count > ioCap_) {
         (void)hipStreamSynchronize(stream_);
         (void)hipFree(dIn_);

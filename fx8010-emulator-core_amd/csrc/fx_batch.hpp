@@ -140,6 +140,10 @@ private:
     float* dIn_ = nullptr;
     float* dOut_ = nullptr;
     size_t ioCap_ = 0;
+    // small blocks (the reference's one process() per sample): pinned host buffers the kernel reads and writes directly
+    float* hPinIn_ = nullptr;
+    float* hPinOut_ = nullptr;
+    bool pinTried_ = false, untimed_ = false;
     unsigned lastGrid_ = 0;
 
     std::string lastError_;
