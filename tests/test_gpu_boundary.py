@@ -291,3 +291,33 @@ def test_track_limits_and_sharded_tracks(gpu):
         bb.set_register_track("decay", [0.45, 0.2], 20)
     assert np.array_equal(bits(b.process_block(x)), bits(one.process_block(x)))
     assert np.array_equal(bits(b.get_register_array("damp")), bits(vals[2]))
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_small_host_blocks_take_the_pinned_path_and_large_ones_the_staged_copies(gpu, channels):
+    """Host blocks of up to 2 KB of PCM are read and written by the kernel in pinned host memory (fx_batch.cpp processHost);
+    larger ones are copied.  The same instances fed in blocks of both sizes, interleaved, must follow the oracle bit for bit."""
+    if channels == 1:
+        text = progs.config3()
+    else:
+        text = "input l 0\ninput r 1\noutput ol 0\noutput or 1\nstatic a\nitramsize 40 \nidelay read, a, at, 0\nmacs ol, l, a, 0.5\nmacs or, r, ol, 0.25\nidelay write, ol, at, 0\nend"
+    n = 6
+    cuts = [1, 1, 40, 1, 85, 3, 200, 1, 1]          # 6 instances x {1, 3, 40} samples: pinned; x {85, 200}: staged (mono)
+    s_total = sum(cuts)
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-0.9, 0.9, size=(s_total, n) if channels == 1 else (s_total, channels, n)).astype(np.float32)
+    b = gpu.Batch(n, channels, 0)
+    assert b.load_text(text), b.errors()
+    at, parts = 0, []
+    for c in cuts:
+        parts.append(b.process_block(np.ascontiguousarray(x[at:at + c])))
+        at += c
+    y = np.concatenate(parts, axis=0)
+    for inst in range(n):
+        o = Oracle(channels)
+        assert o.load_text(text)
+        xin = x[:, inst] if channels == 1 else np.ascontiguousarray(x[:, :, inst])
+        ref = o.process_block(xin.copy())
+        got = y[:, inst] if channels == 1 else y[:, :, inst]
+        assert np.array_equal(ref.view(np.uint32), np.ascontiguousarray(got).view(np.uint32)), inst
+        assert b.instruction_counter_i(inst) == o.instruction_counter()
