@@ -266,7 +266,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form, result to VCC, |src0| when abs0
     void vop3cmp(uint32_t op, const char* name, const Src& s0, bool abs0, const Src& s1) {
-        tally("v_other");
+        tally(name);
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | 106u);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -336,14 +336,14 @@ class Emitter {
     }
     // v = v + carry (VCC in and out)
     void addCarry(int v) {
-        tally("v_other");
+        tally("v_addc_co_u32");
         w_.push_back((VOP2_ADDC_OP << 25) | ((uint32_t)v << 17) | ((uint32_t)v << 9) | 128u);
         ++count_;
         if (text_) line("v_addc_co_u32_e32 v" + std::to_string(v) + ", vcc, 0, v" + std::to_string(v) + ", vcc");
     }
     // v = v - borrow, borrow in from the SGPR pair `sin`, borrow out to the pair `sout`
     void subBorrow(int v, int sin, int sout) {
-        tally("v_other");
+        tally("v_subbrev_co_u32");
         w_.push_back(0xd0000000u | (0x11eu << 16) | ((uint32_t)sout << 8) | (uint32_t)v);
         w_.push_back(128u | ((256u + (uint32_t)v) << 9) | ((uint32_t)sin << 18));
         ++count_;
@@ -357,7 +357,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
     void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
-        tally("v_other");
+        tally(name);
         w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | (sdst.code & 0xffu));
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
@@ -365,7 +365,7 @@ class Emitter {
     }
     // VOPC in its VOP3 form with an SGPR-pair destination
     void vop3cmpTo(uint32_t op, const char* name, int sdst, const Src& s0, const Src& s1) {
-        tally("v_other");
+        tally(name);
         w_.push_back(0xd0000000u | (op << 16) | (uint32_t)sdst);
         w_.push_back(s0.code | (s1.code << 9));
         ++count_;
