@@ -190,7 +190,9 @@ __device__ __forceinline__ float lutInterpolate(const double* __restrict__ lut, 
     int idx = 0;
     if (!(t >= 0.0) || t > 2.0) {
         // outside [-1,1] (or NaN): outside the parity domain; follow the reference's arithmetic, then clamp
-        idx = cvtt_f64(t / ((1.0 - -1.0) / 63.0));
+        // (the quotient is clamped as a number: NaN and anything below 0 -> 0, anything from 64 up, +Inf included, -> 63)
+        const double q = t / ((1.0 - -1.0) / 63.0);
+        idx = !(q >= 0.0) ? (q == q && q > -1.0 ? 0 : -1) : (q >= 64.0 ? 64 : cvtt_f64(q));
         if (idx < 0 || idx > 63) { ood |= OOD_LUT_INDEX; idx = idx < 0 ? 0 : 63; }
     } else {
         idx = (int)(t * 31.5);

@@ -181,7 +181,7 @@ class Emitter {
     int valu() const { return valu_; }
     int valuSlow() const { return valuSlow_; }
     int valuClocks() const { return (int)((valuClocksX100_ + 50) / 100); }
-    void cold(bool on) { cold_ = on; }
+    void cold(bool on) { coldDepth_ += on ? 1 : -1; cold_ = coldDepth_ > 0; }
     // uniform constants kept in VGPRs for the whole launch (XlateProgram::vconst)
     void constants(const std::vector<std::pair<uint32_t, int>>* pool) { pool_ = pool; }
     int pooled(uint32_t bits) const {
@@ -400,6 +400,7 @@ class Emitter {
     int count_ = 0, valu_ = 0, valuSlow_ = 0;
     long valuClocksX100_ = 0;
     bool cold_ = false;
+    int coldDepth_ = 0;
     const std::vector<std::pair<uint32_t, int>>* pool_ = nullptr;
     // Issue cost of a wave64 VALU instruction on a busy SIMD, in clocks x 100.  Measured on MI355X as the time an instruction
     // adds to a realistic mix at four waves per SIMD (tools/micro/mix_cost.hip; the homogeneous loops of valu_rate.hip
@@ -809,6 +810,8 @@ class Translator {
     // thresholds included - is fetched in ONE round trip (LDS: four conflict-light ds_read_b64), the thresholds
     // check the guess, and the rare miss takes a second trip with the corrected index.
     // Bit-identical to the interpreter's h_lut (dense sweep in tests/test_gpu_parity.py).
+    // one LOG / EXP site: what its fetch and its miss path need to know
+    struct LutSite { int vA = 0; bool lds = false, guarded = false, quick = false; uint32_t window = 0, slopeOff = 0; };
     bool lut(const MicroOp& r) {
         int vA, vR;
         if (!touch(r, true, false, false, true) || !row(r.w[2], &vA) || !row(r.w[5], &vR)) return false;
@@ -827,15 +830,61 @@ class Translator {
         // An operand of the BOUNDED class lies in [-1, 1] while the wave runs the fast stream: the guess and the corrected
         // index are in 0..63 by construction and nothing can be out of the domain.  Everywhere else (wild operand, or the
         // exact stream, which a wave enters precisely when that invariant broke) the index is clamped and the flag derived.
-        const bool guarded = operandWild || !fast_;
+        LutSite site;
+        site.vA = vA;
+        site.lds = lds;
+        site.guarded = operandWild || !fast_;
+        site.slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes;
+        site.window = (lds && fast_) ? lutGuessWindowHi() : 0;
+        site.quick = site.window != 0 && kLutGuess.available(e_);
+        if (fast_ && operandWild && site.quick) {
+            // A wild operand is nearly always inside the table too (the PCM input, a wrap-around result): one compare sends the
+            // wave to the guarded form - behind the loop, with the out-of-domain flag and the taint check of the result - only
+            // when some lane holds |x| > 1 or a NaN; otherwise it runs the bounded form, whose result is finite.
+            e_.vop3cmpG(VOP3_CMP_NLE_F32, "v_cmp_nle_f32_e64", named(106, "vcc"), vreg(vA), true, imm32(0x3f800000u));
+            Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_VCCNZ, "s_cbranch_vccnz");
+            site.guarded = false;
+            lutBody(site);
+            e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
+            LutSite slow = site;
+            slow.guarded = true;
+            slow.quick = false;
+            slow.window = 0;
+            const uint32_t exactSync = (*exactReturns_)[syncIndex(1)];
+            defer(outside, [this, slow, vR, exactSync]() {
+                e_.cold(true);
+                lutBody(slow);
+                e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
+                taintIfNonFinite(vR);
+                if (!leaveIfTainted(exactSync)) deferredFailed_ = true;
+                e_.cold(false);
+            });
+            returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+            return true;
+        }
+        if (site.guarded) site.window = 0, site.quick = false;
+        lutBody(site);
+        e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
+        returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+        if (operandWild && fast_) {  // a wild operand can be Inf / NaN, and then so is the result
+            taintIfNonFinite(vR);
+            if (!leaveIfTainted((*exactReturns_)[syncIndex(1)])) return false;
+        }
+        return true;
+    }
+
+    // guess, fetch, check (second trip behind the loop, or inline for tables in global memory), out-of-domain flag of the
+    // guarded form: leaves slope * (x - x1) + y1 in v[12:13]
+    void lutBody(const LutSite& site) {
+        const int vA = site.vA;
+        const bool lds = site.lds, guarded = site.guarded, quick = site.quick;
+        const uint32_t window = site.window;
         Src zero = imm32(0), top = imm32(63), vcc = named(106, "vcc");
-        // The guess.  Bounded operand, tables in LDS and the four constants in VGPRs: three instructions of the double-rate
+        // The guess.  Operand inside [-1, 1], tables in LDS and the four constants in VGPRs: three instructions of the double-rate
         // class give 8 * floor((x + 1) * 31.5) directly - t = fma(x, 252, 251.5) = 8 * (x + 1) * 31.5 - 0.5; adding
         // 1.5 * 2^23 rounds t to the nearest integer q, which lands in the low mantissa bits (q = floor(8 * ...) unless the
         // fraction is within 2^-15 of a whole number; at x = +-1, the only floats where the tie can matter, round-to-even
         // picks 504 and 0); q & 0x1f8 is the byte offset of the segment.  Otherwise (x + 1) * 31.5 truncated by v_cvt.
-        const uint32_t window = (lds && !guarded) ? lutGuessWindowHi() : 0;   // (see below)
-        const bool quick = window != 0 && kLutGuess.available(e_);
         if (quick) {
             Src half = vreg(e_.pooled(kLutGuess.bias));
             e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(6), vreg(vA), vreg(e_.pooled(kLutGuess.scale)), &half);
@@ -847,13 +896,6 @@ class Translator {
             e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(6));                // saturating, NaN -> 0
         }
         if (guarded) e_.vop3(VOP3_MED3_I32, "v_med3_i32", vreg(6), vreg(6), zero, &top);
-        LutSite site;
-        site.vA = vA;
-        site.lds = lds;
-        site.guarded = guarded;
-        site.quick = quick;
-        site.window = window;
-        site.slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes;
         // Where the operand is known to be in the table (not guarded) the guess is checked without its thresholds: d = x - x1[g]
         // must lie in [0, W), W a constant of the grid (fx_frontend.cpp lutGuessWindowHi) - one unsigned compare of d's high
         // word, three LDS reads instead of four.  A miss (one lane in ~10^5 within reach of a threshold) reads the thresholds
@@ -897,17 +939,8 @@ class Translator {
             e_.vop3(VOP3_CNDMASK, "v_cndmask_b32_e64", vreg(7), zero, flag, &vcc);
             e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, vreg(kVOod), 7);
         }
-        e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
-        returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
-        if (operandWild && fast_) {  // a wild operand can be Inf / NaN, and then so is the result
-            taintIfNonFinite(vR);
-            if (!leaveIfTainted((*exactReturns_)[syncIndex(1)])) return false;
-        }
-        return true;
     }
 
-    // one LOG / EXP site: what its fetch and its miss path need to know
-    struct LutSite { int vA = 0; bool lds = false, guarded = false, quick = false; uint32_t window = 0, slopeOff = 0; };
     // segment v6 (index) or, first fetch of the quick form, v7 (byte offset): x1 -> v[10:11], slope -> v[2:3], y1 -> v[4:5],
     // thresholds -> v[8:9]
     void lutFetch(const LutSite& s, bool withThresholds, bool offsetReady) {

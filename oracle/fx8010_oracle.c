@@ -451,7 +451,11 @@ static inline int32_t logic_ops(float a_, float x_, float y_) {
 static inline double linear_interpolate(fxo_t* f, double x, const double* tbl) {
     const double x_min = -1.0, x_max = 1.0;
     double step = (x_max - x_min) / (double)(64 - 1);
-    int index = cvtt_f64((x - x_min) / step);
+    /* In the domain (x in [-1, 1]) the quotient lies in [0, 63] and this is the reference's (int) cast.  Outside it the
+       reference indexes its vector out of bounds; here the quotient is clamped to 0 .. 63 as a number - a NaN counts as
+       below (the cast would give INT_MIN), and so does nothing else: +Inf or 1e10 clamp to 63, they do not wrap to INT_MIN. */
+    const double q = (x - x_min) / step;
+    int index = !(q >= 0.0) ? (q == q && q > -1.0 ? 0 : -1) : (q >= 64.0 ? 64 : cvtt_f64(q));
     if (index < 0 || index > 63) { f->ood |= FXO_OOD_LUT_INDEX; index = index < 0 ? 0 : 63; }
     double x1 = x_min + index * step;
     double x2 = x_min + (index + 1) * step;

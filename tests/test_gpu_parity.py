@@ -421,6 +421,43 @@ def test_log_of_a_bounded_row_that_was_set_beyond_one(gpu, k):
     assert clean.ood_flags() == 0
 
 
+@pytest.mark.parametrize("op,table", [("log", 3), ("exp", 7)])
+def test_log_of_the_input_inside_and_beyond_the_table(gpu, op, table, k):
+    """LOG/EXP of a wild operand (the PCM input): the translated tier runs the bounded form while every lane of a wave
+    holds |x| <= 1 and the guarded form - index clamp, out-of-domain flag 16, taint check of the result - as soon as one
+    lane does not.  Waves that are entirely inside, waves with one lane at 1.01 / -1.5 / +-Inf / NaN, per instance
+    against the oracle (whose restatement defines the clamped read beyond the table)."""
+    text = HDR + "%s b, in, %d, 0\nmacs out, b, in, 0.25\nend" % (op, table)
+    N, S = 200, 12
+    rng = np.random.default_rng(table)
+    x = rng.uniform(-1.0, 1.0, size=(S, N)).astype(np.float32)
+    x[2, 5] = 1.01            # beyond 1.0 but inside the grid's last segment: no flag, clamped index
+    x[3, 70] = -1.5           # out of the domain
+    x[4, 71] = np.float32(np.inf)
+    x[5, 72] = np.float32(np.nan)
+    x[6, 130] = -1.0
+    x[7, 131] = 1.0
+    x[8, 9] = 1e10            # the quotient no longer fits an int32: clamped as a number (63), not wrapped to INT_MIN
+    x[9, 10] = -1e10
+    x[1, 11] = np.float32(-np.inf)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    y = b.process_block(x)
+    flagged = set()
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(text)
+        ref = o.process_block(x[:, n].copy())
+        assert np.array_equal(bits(ref), bits(y[:, n])), "instance %d" % n
+        assert b.get_register_bits_i("b", n) == o.get_register_bits("b")
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+        if o.ood_flags():
+            flagged.add(n)
+            assert o.ood_flags() == 16
+    assert flagged >= {70, 71, 72, 9, 10, 11} and not (flagged & {5, 130, 131, 0, 199})
+    assert b.ood_flags() == 16
+
+
 def test_delay_line_exact(gpu, k):
     text = "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend"
     x = progs.stimulus(66, 64)
