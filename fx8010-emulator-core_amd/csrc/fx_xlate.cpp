@@ -508,7 +508,8 @@ class Translator {
     bool run(const std::vector<MicroOp>& records, XlateStats* stats, std::vector<uint32_t>* returns, uint32_t* coldEntry, std::string* err) {
         // sync points: per record i [4i] after the wait for TRAM reads pending before it, [4i+1] behind its handler call /
         // inline LUT, [4i+2] after the wait in front of the early reads that follow it; [4n] the head of the loop body
-        // (inputs and leading reads consumed, next input requested)
+        // (inputs and leading reads consumed, next input requested), [4n+3] after the wait for reads still pending behind
+        // the last instruction
         returns_.assign(4 * records.size() + 4, 0);
         records_ = &records;
         const HoistPlan& H = prog_.hoist;
@@ -591,7 +592,8 @@ class Translator {
         }
         if (!ended) { if (err) *err = "record stream without ENDSAMPLE"; return false; }
         index_ = records.size();
-        if (!flush()) { if (err) *err = err_; return false; }
+        // (sync point [4n + 3]: [4n] is the head's - a wave that leaves the fast stream at the head must not land here)
+        if (!flush(3)) { if (err) *err = err_; return false; }
 
         // ---- PCM out, next sample
         plainMode();
@@ -1998,6 +2000,8 @@ int32_t danePosition(uint32_t bits, bool shifted, int32_t size) {
 HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, const XlateProgram& p) {
     HoistPlan H;
     if (!p.uniformCursors) return H;
+    if (const char* knob = std::getenv("FX_XLATE_HOIST"))  // diagnostics: 0 = delay-line reads stay in place
+        if (std::atoi(knob) == 0) return H;
     auto isRead = [](uint32_t slot) { return slot == AS_TRAM_IR || slot == AS_TRAM_XR; };
     auto isWrite = [](uint32_t slot) { return slot == AS_TRAM_IW || slot == AS_TRAM_XW; };
     auto tramOf = [](uint32_t slot) { return (slot == AS_TRAM_IR || slot == AS_TRAM_IW) ? 0 : 1; };

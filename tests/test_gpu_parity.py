@@ -458,6 +458,27 @@ def test_log_of_the_input_inside_and_beyond_the_table(gpu, op, table, k):
     assert b.ood_flags() == 16
 
 
+@pytest.mark.parametrize("trigger", ["delay line hands back |x| > 1", "NaN on the input", "Inf on the input"])
+def test_leaving_the_fast_stream_at_the_head_of_a_sample(gpu, trigger, k):
+    """A wave leaves the fast stream for the exact one at the *head* of a sample when the PCM input is non-finite or a
+    delay-line read issued a sample ahead returns a value outside its row's class.  The program ends in a delay-line read
+    that nothing consumes (a wait of its own behind the last instruction): the head's sync point and that wait's used to
+    share one slot, and the wave landed behind the program - the whole sample skipped (fuzz seed 502415 with inputs x 3)."""
+    text = ("input in 0\noutput out 0\ncontrol c = 0.3\nstatic rd\nstatic xd\nitramsize 7 \nxtramsize 30 \nstatic r4\nstatic r5\nstatic r7\n"
+            "static r8\nstatic r9\nstatic r10\nstatic r13\n"
+            "xdelay read, xd, at, 0\nxdelay read, xd, at, 0\nxdelay write, in, at, 0\nskip ccr, ccr, 3, 4\nlimit r9, xd, 0, r8\n"
+            "macs r5, r13, r7, c\nmacints r9, ccr, 0.125, r5\nandxor r10, in, r4, c\nmacs out, xd, r9, 0.5\nidelay read, rd, at, 0\nend")
+    N, S = 70, 40
+    x = progs.stimulus(N, S)
+    if trigger.startswith("delay"):
+        x = x * np.float32(3.0)                 # the inputs go through the delay line into the row `xd`
+    elif trigger.startswith("NaN"):
+        x[17, ::3] = np.float32(np.nan)
+    else:
+        x[17, ::3] = np.float32(np.inf)
+    check_batch(gpu, text, x, regs=("xd", "rd", "r9", "r10", "out", "ccr"))
+
+
 def test_delay_line_exact(gpu, k):
     text = "itramsize 5 \n" + HDR + "idelay read, rd, at, 0\nidelay write, in, at, 0\nmacs out, 0, rd, 1.0\nend"
     x = progs.stimulus(66, 64)
