@@ -31,6 +31,12 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     N, S = 70, 10
     x = P.stimulus(N, S) * np.float32(float(os.environ.get("FX_FUZZ_SCALE", "1")))   # > 1: inputs beyond the LOG/EXP tables
+    if os.environ.get("FX_FUZZ_NAN"):   # non-finite words sprinkled over the input: NaNs of both signs with payloads, a signalling one, +-Inf
+        words = np.array([0x7FC00000, 0xFFC00000, 0x7FC12345, 0xFF800001, 0x7F800000, 0xFF800000, 0x7FA00000], dtype=np.uint32).view(np.float32)
+        r = np.random.default_rng(99)
+        hit = r.random(x.shape) < float(os.environ["FX_FUZZ_NAN"])
+        x = x.copy()
+        x[hit] = words[r.integers(0, words.size, size=int(hit.sum()))]
     failures, kernels = [], {}
     for seed in range(first, first + count):
         rng = np.random.default_rng(500000 + seed)
