@@ -697,7 +697,9 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
         if (hPinIn_ && hPinOut_) {
             std::memcpy(hPinIn_, in, count * 4);
             waitLastLaunch();
-            untimed_ = true;  // no event pair around a launch that is waited for right here (last_kernel_ms: -1)
+            // no event pair around a launch that is waited for right here (last_kernel_ms: -1) - unless schedules are armed:
+            // the tiers that cut the block at every step launch several times and wait for each launch through its event
+            untimed_ = !tracksArmed();
             int rc = processDevice(hPinIn_, hPinOut_, nSamples, stream_);
             untimed_ = false;
             if (rc != 0) return rc;

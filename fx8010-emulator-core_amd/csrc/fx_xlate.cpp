@@ -2020,6 +2020,9 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
         const MicroOp& r = steady[(size_t)lead];
         if (!isRead(r.w[0]) || last[(size_t)lead].w[0] != r.w[0] || last[(size_t)lead].w[5] != r.w[5] || last[(size_t)lead].w[4] != r.w[4]) break;
         if (sizeOf(tramOf(r.w[0])) < 1 || (!p.tramDane && offsetOf(r) != 0) || std::find(rows.begin(), rows.end(), r.w[5]) != rows.end()) break;
+        // a register with a control track takes its scheduled value at the head of the sample, BEFORE the program's first
+        // instruction: a read into it must stay an ordinary instruction behind the head (api fuzz seed 50788)
+        if (std::find(p.trackRows.begin(), p.trackRows.end(), (int)r.w[5]) != p.trackRows.end()) break;
         rows.push_back(r.w[5]);
         ++lead;
     }

@@ -321,3 +321,57 @@ def test_small_host_blocks_take_the_pinned_path_and_large_ones_the_staged_copies
         got = y[:, inst] if channels == 1 else y[:, :, inst]
         assert np.array_equal(ref.view(np.uint32), np.ascontiguousarray(got).view(np.uint32)), inst
         assert b.instruction_counter_i(inst) == o.instruction_counter()
+
+
+def _replay_with_schedules(text, x_col, plans, inst):
+    """the oracle doing what the schedules do: set_register between its process() calls"""
+    o = Oracle(1)
+    assert o.load_text(text)
+    ref = np.empty(x_col.shape[0], dtype=np.float32)
+    for t in range(x_col.shape[0]):
+        for name, period, vals in plans:
+            if t % period == 0 and t // period < vals.shape[0]:
+                v = vals[t // period]
+                o.set_register(name, float(v if vals.ndim == 1 else v[inst]))
+        ref[t] = o.process_block(x_col[t:t + 1].copy())[0]
+    return ref, o
+
+
+def test_track_on_a_register_the_program_loads_from_a_delay_line_first(gpu, track_tier):
+    """The scheduled value is set at the head of the sample, BEFORE the first instruction - here a delay-line read into the same
+    register, which therefore wins.  The translated tier issues leading delay-line reads a sample ahead: not into a register
+    with a schedule (api fuzz seed 50788)."""
+    text = ("input in 0\noutput out 0\nstatic noise\nxtramsize 23 \nstatic r0\nstatic r2\nstatic r3\nstatic r6\nstatic r12\n"
+            "xdelay read, r0, at, 0\nacc3 r3, r0, noise, r12\ninterp r2, r6, r3, 0.125\nxdelay write, in, at, 0\nmacs out, out, r2, 0.5\nend")
+    N, S = 70, 60
+    x = progs.stimulus(N, S)
+    vals = np.random.default_rng(1).uniform(-1, 1, size=(25, N)).astype(np.float32)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    b.set_register_track("r0", vals, 1)
+    y = b.process_block(x)
+    for inst in (0, 63, 64, N - 1):
+        ref, o = _replay_with_schedules(text, x[:, inst], [("r0", 1, vals)], inst)
+        assert np.array_equal(bits(ref), bits(y[:, inst])), inst
+        assert b.get_register_bits_i("r0", inst) == o.get_register_bits("r0")
+
+
+def test_schedules_in_small_host_blocks_on_the_tiers_that_cut_the_block(gpu, track_tier):
+    """Host blocks of a few samples take the pinned-memory path (no event pair around the launch); the interpreter and HIP tiers
+    apply schedules by cutting the block and must still wait for each piece before they write the next step's values
+    (api fuzz seed 50790: the step at sample 1 was overwritten by the epilogue of the launch before it)."""
+    text = "input in 0\noutput out 0\ncontrol c = 0.5\nstatic r0\nstatic r1\nmacs r0, r0, in, 0.25\nmacs r1, r0, in, c\nmacs out, r1, in, c\nend"
+    N = 64
+    x = progs.stimulus(N, 16)
+    vals = np.random.default_rng(3).uniform(-1, 1, size=(4, N)).astype(np.float32)
+    for r1_period in (3, 2, 1):
+        for S in (2, 3, 7):
+            b = gpu.Batch(N, 1, 0)
+            assert b.load_text(text), b.errors()
+            b.set_register_track("c", vals, 1)
+            b.set_register_track("r1", np.array([0.25], dtype=np.float32), r1_period)
+            y = b.process_block(x[:S])
+            for inst in (0, 33, 63):
+                ref, o = _replay_with_schedules(text, x[:S, inst], [("c", 1, vals), ("r1", r1_period, np.array([0.25], dtype=np.float32))], inst)
+                assert np.array_equal(bits(ref), bits(y[:, inst])), (r1_period, S, inst)
+                assert b.get_register_bits_i("c", inst) == o.get_register_bits("c"), (r1_period, S, inst)

@@ -53,9 +53,55 @@ def run(seed, verbose=False):
     x = P.stimulus(N, 1200)
     pos = 0
     names = ["c", "r0", "r1", "r%d" % (n_regs - 1), "out"]
+    if verbose:
+        print(text)
+        print("N", N, "check", check, "names", names)
     for step in range(30):
-        op = rng.integers(0, 12)
-        if op < 6:
+        op = rng.integers(0, 13)
+        if verbose:
+            for n in check:
+                bad = [(r, "%08x" % b.get_register_bits_i(r, n), "%08x" % oracles[n].get_register_bits(r)) for r in names + ["ccr"]
+                       if b.get_register_bits_i(r, n) != oracles[n].get_register_bits(r)]
+                if bad or b.instruction_counter_i(n) != oracles[n].instruction_counter():
+                    print("  BEFORE step", step, "instance", n, "differs:", bad, "ctr", b.instruction_counter_i(n), oracles[n].instruction_counter())
+            print("step", step, "op", int(op), "kernel", b.info("kernel"))
+        if op == 12:
+            # control tracks: schedules of register values applied inside the next block (fxb_set_register_track), the oracle
+            # gets the same values through set_register between its samples
+            S = int(rng.choice([1, 5, 16, 33]))
+            xs = x[pos:pos + S]
+            pos += S
+            plans = []
+            for name in rng.choice(names[:3], size=int(rng.integers(1, 3)), replace=False):  # (a batch gives at most three registers a schedule slot)
+                period = int(rng.choice([1, 2, 3, 8]))
+                steps = int(rng.integers(1, S // period + 3))
+                if rng.integers(0, 2):
+                    vals = np.array([value(rng) for _ in range(steps)], dtype=np.float32)
+                else:
+                    vals = np.array([[value(rng) for _ in range(N)] for _ in range(steps)], dtype=np.float32)
+                b.set_register_track(str(name), vals, period)
+                plans.append((str(name), period, vals))
+                if verbose:
+                    print("  track", name, "period", period, "steps", steps, "per-instance" if vals.ndim == 2 else "broadcast", "S", S)
+            y = b.process_block(xs)
+            if verbose:
+                for name, period, vals in plans:
+                    print("   ", name, "schedule for instance", check[0], [float(v if vals.ndim == 1 else v[check[0]]) for v in vals],
+                          "register now", b.get_register_i(name, check[0]))
+            for n in check:
+                ref = np.empty(S, dtype=np.float32)
+                for t in range(S):
+                    for name, period, vals in plans:
+                        if t % period == 0 and t // period < vals.shape[0]:
+                            v = vals[t // period]
+                            oracles[n].set_register(name, float(v if vals.ndim == 1 else v[n]))
+                    ref[t] = oracles[n].process_block(xs[t:t + 1, n].copy())[0]
+                if oracles[n].ood_flags():
+                    return True
+                if not same(ref, y[:, n]):
+                    print("MISMATCH (tracks) seed %d step %d instance %d kernel %d" % (seed, step, n, b.info("kernel")))
+                    return False
+        elif op < 6:
             S = int(rng.choice([1, 3, 8, 16, 40]))
             xs = x[pos:pos + S]
             pos += S
@@ -69,16 +115,22 @@ def run(seed, verbose=False):
                     return False
         elif op < 8:
             name, v = str(rng.choice(names)), value(rng)
+            if verbose:
+                print("  set_register", name, v)
             b.set_register(name, v)
             for o in oracles.values():
                 o.set_register(name, v)
         elif op < 9:
             name, n, v = str(rng.choice(names)), int(rng.choice(check)), value(rng)
+            if verbose:
+                print("  set_register_i", name, n, v)
             b.set_register_i(name, n, v)
             oracles[n].set_register(name, v)
         elif op < 10:
             name = str(rng.choice(names))
             vals = np.array([value(rng) for _ in range(N)], dtype=np.float32)
+            if verbose:
+                print("  set_register_array", name)
             b.set_register_array(name, vals)
             for n in check:
                 oracles[n].set_register(name, float(vals[n]))
@@ -96,6 +148,8 @@ def run(seed, verbose=False):
                         print("REGISTER seed %d step %d %s[%d] %08x %08x kernel %d" % (seed, step, r, n, gb, rb, b.info("kernel")))
                         return False
     for n in check:
+        if verbose:
+            print("counter", n, b.instruction_counter_i(n), oracles[n].instruction_counter())
         if b.instruction_counter_i(n) != oracles[n].instruction_counter():
             print("COUNTER seed %d instance %d" % (seed, n))
             return False
@@ -105,6 +159,8 @@ def run(seed, verbose=False):
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    if len(sys.argv) > 3 and sys.argv[3] == "verbose":
+        return 0 if run(first, True) else 1
     bad = [s for s in range(first, first + count) if not run(s)]
     print("api fuzz:", count, "sequences, failures", bad)
     return 1 if bad else 0
