@@ -42,7 +42,8 @@ def run(seed, verbose=False):
     text = gen(rng, int(rng.integers(6, 70)), n_regs)
     N = int(rng.choice([1, 63, 64, 65, 130, 200]))
     check = sorted(set([0, N - 1, N // 2]))
-    b = A.Batch(N, 1, 0)
+    shards = int(os.environ.get("FX_FUZZ_SHARDS", "1"))   # > 1: the same call sequence through a multi-shard handle (all shards on device 0)
+    b = A.Batch(N, 1, devices=[0] * shards) if shards > 1 and (N + 63) // 64 >= shards else A.Batch(N, 1, 0)
     if not b.load_text(text):
         return True
     oracles = {}
