@@ -41,7 +41,8 @@ def main():
     for seed in range(first, first + count):
         rng = np.random.default_rng(500000 + seed)
         gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
-        text = gen(rng, int(rng.integers(4, 100)), int(rng.integers(2, 50)))
+        max_regs = int(os.environ.get("FX_FUZZ_REGS", "50"))   # up to ~250: the larger VGPR builds and, beyond 224 rows, the LDS interpreter
+        text = gen(rng, int(rng.integers(4, 100 if max_regs <= 50 else 400)), int(rng.integers(2, max_regs)))
         b = A.Batch(N, 1, 0)
         if not b.load_text(text):
             continue
