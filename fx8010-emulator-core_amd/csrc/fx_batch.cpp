@@ -70,6 +70,12 @@ Batch::~Batch() {
     (void)hipFree(dOut_);
     if (hPinIn_) (void)hipHostFree(hPinIn_);
     if (hPinOut_) (void)hipHostFree(hPinOut_);
+    for (int k = 0; k < kHostPieces; ++k) {
+        if (evIn_[k]) (void)hipEventDestroy(evIn_[k]);
+        if (evDone_[k]) (void)hipEventDestroy(evDone_[k]);
+    }
+    if (copyIn_) (void)hipStreamDestroy(copyIn_);
+    if (copyOut_) (void)hipStreamDestroy(copyOut_);
     if (xlateModule_) (void)hipModuleUnload(xlateModule_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
@@ -672,7 +678,18 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
 
 // pitch: instances per PCM row of the HOST buffers (>= n_); a shard of a larger batch reads / writes its columns of the
 // caller's [sample][channel][all instances] arrays in place (fx_shard.cpp)
-namespace { constexpr size_t kPinnedFloats = 512; }
+namespace {
+constexpr size_t kPinnedFloats = 512;
+constexpr size_t kPipelinedBytes = (size_t)32 << 20;
+bool pinnedHost(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // (an unregistered pointer is reported as an error by older runtimes)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
 
 int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch) {
     (void)hipSetDevice(device_);
@@ -720,6 +737,12 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
         if (e != hipSuccess) return hipFail(e, "hipMalloc io");
         ioCap_ = count;
     }
+    // Large blocks in PINNED caller buffers are copied by DMA at full rate in both directions at once: worth overlapping with the
+    // kernel (41 instead of 21 GB/s each way for 268 MB blocks).  Pageable buffers go through the driver's staging at ~9 GB/s
+    // whatever is done here (tools/host_block_rate.py).
+    static const bool pipelineOff = std::getenv("FX_HOST_PIPELINE") && std::atoi(std::getenv("FX_HOST_PIPELINE")) == 0;  // diagnostics
+    if (count * 4 >= kPipelinedBytes && nSamples >= 2 * kHostPieces && !tracksArmed() && !pipelineOff && pinnedHost(in) && pinnedHost(out))
+        return processHostPipelined(in, out, nSamples, pitch);
     const size_t rows = (size_t)nSamples * prog_.numChannels, width = (size_t)n_ * 4;
     hipError_t e = pitch == n_ ? hipMemcpyAsync(dIn_, in, count * 4, hipMemcpyHostToDevice, stream_)
                                : hipMemcpy2DAsync(dIn_, width, in, (size_t)pitch * 4, width, rows, hipMemcpyHostToDevice, stream_);
@@ -731,6 +754,61 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
     if (e == hipSuccess) e = hipStreamSynchronize(stream_);
     if (e != hipSuccess) return hipFail(e, "D2H");
     return 0;
+}
+
+// A large host block in pieces (dIn_ / dOut_ hold the whole block): while the kernel works on piece p, piece p + 1 is on its way
+// in and piece p - 1 on its way out - two copy streams beside the compute stream, ordered by events.  The pieces are
+// consecutive blocks to the kernel: state carries over exactly as between two calls.
+int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64_t pitch) {
+    if (!copyIn_) {
+        hipError_t c = hipStreamCreateWithFlags(&copyIn_, hipStreamNonBlocking);
+        if (c == hipSuccess) c = hipStreamCreateWithFlags(&copyOut_, hipStreamNonBlocking);
+        for (int k = 0; k < kHostPieces && c == hipSuccess; ++k) {
+            c = hipEventCreateWithFlags(&evIn_[k], hipEventDisableTiming);
+            if (c == hipSuccess) c = hipEventCreateWithFlags(&evDone_[k], hipEventDisableTiming);
+        }
+        if (c != hipSuccess) return hipFail(c, "streams for the pipelined host block");
+    }
+    const size_t ch = (size_t)prog_.numChannels, width = (size_t)n_ * 4;
+    auto lo = [&](int p) { return (int)((int64_t)nSamples * p / kHostPieces); };
+    auto copyIn = [&](int p) {
+        const size_t first = (size_t)lo(p) * ch, rows = (size_t)(lo(p + 1) - lo(p)) * ch;
+        hipError_t e = pitch == n_ ? hipMemcpyAsync(dIn_ + first * (size_t)n_, in + first * (size_t)n_, rows * width, hipMemcpyHostToDevice, copyIn_)
+                                   : hipMemcpy2DAsync(dIn_ + first * (size_t)n_, width, in + first * (size_t)pitch, (size_t)pitch * 4, width, rows, hipMemcpyHostToDevice, copyIn_);
+        if (e == hipSuccess) e = hipEventRecord(evIn_[p], copyIn_);
+        return e;
+    };
+    auto launch = [&](int p) -> int {
+        hipError_t e = hipStreamWaitEvent(stream_, evIn_[p], 0);
+        if (e != hipSuccess) return hipFail(e, "pipelined host block");
+        const size_t first = (size_t)lo(p) * ch * (size_t)n_;
+        const int rc = processDevice(dIn_ + first, dOut_ + first, lo(p + 1) - lo(p), stream_);
+        if (rc != 0) return rc;
+        e = hipEventRecord(evDone_[p], stream_);
+        return e == hipSuccess ? 0 : hipFail(e, "pipelined host block");
+    };
+    auto copyOut = [&](int p) {
+        const size_t first = (size_t)lo(p) * ch, rows = (size_t)(lo(p + 1) - lo(p)) * ch;
+        hipError_t e = hipStreamWaitEvent(copyOut_, evDone_[p], 0);
+        if (e != hipSuccess) return e;
+        return pitch == n_ ? hipMemcpyAsync(out + first * (size_t)n_, dOut_ + first * (size_t)n_, rows * width, hipMemcpyDeviceToHost, copyOut_)
+                           : hipMemcpy2DAsync(out + first * (size_t)pitch, (size_t)pitch * 4, dOut_ + first * (size_t)n_, width, width, rows, hipMemcpyDeviceToHost, copyOut_);
+    };
+    waitLastLaunch();
+    hipError_t e = copyIn(0);
+    if (e != hipSuccess) return hipFail(e, "H2D");
+    int rc = launch(0);
+    if (rc != 0) return rc;
+    for (int p = 0; p < kHostPieces; ++p) {
+        if (p + 1 < kHostPieces) {
+            if ((e = copyIn(p + 1)) != hipSuccess) return hipFail(e, "H2D");
+            if ((rc = launch(p + 1)) != 0) return rc;
+        }
+        if ((e = copyOut(p)) != hipSuccess) return hipFail(e, "D2H");
+    }
+    e = hipStreamSynchronize(copyOut_);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    return e == hipSuccess ? 0 : hipFail(e, "pipelined host block");
 }
 
 int Batch::sync() {

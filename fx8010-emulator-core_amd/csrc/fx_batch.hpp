@@ -144,6 +144,11 @@ private:
     float* hPinIn_ = nullptr;
     float* hPinOut_ = nullptr;
     bool pinTried_ = false, untimed_ = false;
+    // large host blocks: pieces of the block are copied in, processed and copied out concurrently
+    static constexpr int kHostPieces = 8;
+    hipStream_t copyIn_ = nullptr, copyOut_ = nullptr;
+    hipEvent_t evIn_[kHostPieces] = {}, evDone_[kHostPieces] = {};
+    int processHostPipelined(const float* in, float* out, int nSamples, int64_t pitch);
     unsigned lastGrid_ = 0;
 
     std::string lastError_;

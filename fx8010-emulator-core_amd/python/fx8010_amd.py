@@ -285,12 +285,15 @@ class Batch(_Reports):
     def seed_noise_i(self, inst, x1, x2):
         return self._check(self._lib.fxb_seed_noise_i(self._h, inst, x1, x2), "seed_noise_i")
 
-    def process_block(self, x):
-        """x: float32 [S, N] (mono) or [S, channels, N]; returns the same shape."""
+    def process_block(self, x, out=None):
+        """x: float32 [S, N] (mono) or [S, channels, N]; returns the same shape (into `out` when given: e.g. a view of pinned
+        memory - large blocks from pinned buffers are copied at DMA rate and overlap with the kernel)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         S = x.shape[0]
         assert x.size == S * self.channels * self.n, "input must be [S, channels, N]"
-        out = np.empty_like(x)
+        if out is None:
+            out = np.empty_like(x)
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size == x.size
         self._check(self._lib.fxb_process_block(self._h, x.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p), S), "process_block")
         return out
 

@@ -375,3 +375,32 @@ def test_schedules_in_small_host_blocks_on_the_tiers_that_cut_the_block(gpu, tra
                 ref, o = _replay_with_schedules(text, x[:S, inst], [("c", 1, vals), ("r1", r1_period, np.array([0.25], dtype=np.float32))], inst)
                 assert np.array_equal(bits(ref), bits(y[:, inst])), (r1_period, S, inst)
                 assert b.get_register_bits_i("c", inst) == o.get_register_bits("c"), (r1_period, S, inst)
+
+
+def test_large_host_block_in_pinned_buffers_is_processed_in_overlapping_pieces(gpu):
+    """fxb_process_block on pinned caller buffers of >= 32 MB copies, runs and returns the block in eight pieces on three
+    streams (fx_batch.cpp processHostPipelined).  The pieces are consecutive blocks to the kernel: state, delay lines and
+    counters must come out exactly as from one block through pageable buffers, and as the oracle says."""
+    torch = pytest.importorskip("torch")
+    n, s = 65536, 160                               # 42 MB each way
+    text = progs.config3()
+    x = progs.stimulus(n, s)
+    pin_in = torch.empty(x.shape, dtype=torch.float32).pin_memory()
+    pin_in.numpy()[...] = x
+    pin_out = torch.empty(x.shape, dtype=torch.float32).pin_memory()
+    a, b = gpu.Batch(n, 1, 0), gpu.Batch(n, 1, 0)
+    assert a.load_text(text) and b.load_text(text)
+    ya = a.process_block(x)                         # pageable: one piece
+    yb = b.process_block(pin_in.numpy(), pin_out.numpy())
+    assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+    assert a.instruction_counter() == b.instruction_counter()
+    ya = a.process_block(x[:40])                    # state after the big block is the same
+    yb = b.process_block(x[:40])
+    assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+    for inst in (0, 63, 64, n - 1):
+        o = Oracle(1)
+        assert o.load_text(text)
+        o.process_block(x[:, inst].copy())
+        ref = o.process_block(x[:40, inst].copy())
+        assert np.array_equal(bits(ref), bits(yb[:, inst])), inst
+        assert b.instruction_counter_i(inst) == o.instruction_counter()
