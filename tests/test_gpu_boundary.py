@@ -377,18 +377,20 @@ def test_schedules_in_small_host_blocks_on_the_tiers_that_cut_the_block(gpu, tra
                 assert b.get_register_bits_i("c", inst) == o.get_register_bits("c"), (r1_period, S, inst)
 
 
-def test_large_host_block_in_pinned_buffers_is_processed_in_overlapping_pieces(gpu):
+@pytest.mark.parametrize("shards", [1, 2])
+def test_large_host_block_in_pinned_buffers_is_processed_in_overlapping_pieces(gpu, shards):
     """fxb_process_block on pinned caller buffers of >= 32 MB copies, runs and returns the block in eight pieces on three
     streams (fx_batch.cpp processHostPipelined).  The pieces are consecutive blocks to the kernel: state, delay lines and
     counters must come out exactly as from one block through pageable buffers, and as the oracle says."""
     torch = pytest.importorskip("torch")
-    n, s = 65536, 160                               # 42 MB each way
+    n, s = 65536, 160 * shards                      # 42 MB each way per shard (a shard copies its columns: 2-D copies)
     text = progs.config3()
     x = progs.stimulus(n, s)
     pin_in = torch.empty(x.shape, dtype=torch.float32).pin_memory()
     pin_in.numpy()[...] = x
     pin_out = torch.empty(x.shape, dtype=torch.float32).pin_memory()
-    a, b = gpu.Batch(n, 1, 0), gpu.Batch(n, 1, 0)
+    a = gpu.Batch(n, 1, 0)
+    b = gpu.Batch(n, 1, 0) if shards == 1 else gpu.Batch(n, 1, devices=[0] * shards)
     assert a.load_text(text) and b.load_text(text)
     ya = a.process_block(x)                         # pageable: one piece
     yb = b.process_block(pin_in.numpy(), pin_out.numpy())
