@@ -681,14 +681,6 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
 namespace {
 constexpr size_t kPinnedFloats = 512;
 constexpr size_t kPipelinedBytes = (size_t)32 << 20;
-bool pinnedHost(const void* p) {
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();  // (an unregistered pointer is reported as an error by older runtimes)
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
-}
 }  // namespace
 
 int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch) {
@@ -737,11 +729,11 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
         if (e != hipSuccess) return hipFail(e, "hipMalloc io");
         ioCap_ = count;
     }
-    // Large blocks in PINNED caller buffers are copied by DMA at full rate in both directions at once: worth overlapping with the
-    // kernel (41 instead of 21 GB/s each way for 268 MB blocks).  Pageable buffers go through the driver's staging at ~9 GB/s
-    // whatever is done here (tools/host_block_rate.py).
+    // Large blocks: copy-in, kernel and copy-out of consecutive pieces overlap.  268 MB each way (tools/host_block_rate.py):
+    // pinned caller buffers 6.5 ms instead of 12.7 (both DMA directions at once), pageable ones 9.7 instead of 12.9 (the driver
+    // pins them on the fly; a freshly allocated, untouched output buffer costs 2-3 x that in page faults either way).
     static const bool pipelineOff = std::getenv("FX_HOST_PIPELINE") && std::atoi(std::getenv("FX_HOST_PIPELINE")) == 0;  // diagnostics
-    if (count * 4 >= kPipelinedBytes && nSamples >= 2 * kHostPieces && !tracksArmed() && !pipelineOff && pinnedHost(in) && pinnedHost(out))
+    if (count * 4 >= kPipelinedBytes && nSamples >= 2 * kHostPieces && !tracksArmed() && !pipelineOff)
         return processHostPipelined(in, out, nSamples, pitch);
     const size_t rows = (size_t)nSamples * prog_.numChannels, width = (size_t)n_ * 4;
     hipError_t e = pitch == n_ ? hipMemcpyAsync(dIn_, in, count * 4, hipMemcpyHostToDevice, stream_)

@@ -151,9 +151,9 @@ int fxb_set_register_track(fxb_handle* h, const char* key, const float* values, 
  * every instance starts with the reference's seeds) */
 int fxb_seed_noise_i(fxb_handle* h, int64_t instance, int32_t x1, int32_t x2);
 /* S sample periods for all N instances.  Host buffers: synchronous (returns with `out` filled).  Blocks of a few KB are read
- * and written by the kernel in pinned memory of the library (no staged copies); blocks of >= 32 MB in PINNED caller buffers
- * (hipHostMalloc / hipHostRegister) are copied in, processed and copied out in overlapping pieces; everything else is H2D,
- * kernel, D2H in sequence - through pageable memory at the driver's staging rate. */
+ * and written by the kernel in pinned memory of the library (no staged copies); blocks of >= 32 MB are copied in, processed and
+ * copied out in overlapping pieces (fastest from pinned caller buffers: both DMA directions at once); everything else is H2D,
+ * kernel, D2H in sequence. */
 int fxb_process_block(fxb_handle* h, const float* in, float* out, int n_samples);
 /* Same with device-resident buffers (hipMalloc'ed, on h's device); asynchronous on `stream`
  * (a hipStream_t, NULL = the handle's own stream).  Pair with fxb_sync(). */
