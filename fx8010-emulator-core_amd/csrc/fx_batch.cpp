@@ -786,17 +786,23 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
         return pitch == n_ ? hipMemcpyAsync(out + first * (size_t)n_, dOut_ + first * (size_t)n_, rows * width, hipMemcpyDeviceToHost, copyOut_)
                            : hipMemcpy2DAsync(out + first * (size_t)pitch, (size_t)pitch * 4, dOut_ + first * (size_t)n_, width, width, rows, hipMemcpyDeviceToHost, copyOut_);
     };
+    // (whatever goes wrong: no copy may still touch the caller's buffers when this returns)
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(copyIn_);
+        (void)hipStreamSynchronize(stream_);
+        (void)hipStreamSynchronize(copyOut_);
+    };
     waitLastLaunch();
     hipError_t e = copyIn(0);
-    if (e != hipSuccess) return hipFail(e, "H2D");
+    if (e != hipSuccess) { drain(); return hipFail(e, "H2D"); }
     int rc = launch(0);
-    if (rc != 0) return rc;
+    if (rc != 0) { drain(); return rc; }
     for (int p = 0; p < kHostPieces; ++p) {
         if (p + 1 < kHostPieces) {
-            if ((e = copyIn(p + 1)) != hipSuccess) return hipFail(e, "H2D");
-            if ((rc = launch(p + 1)) != 0) return rc;
+            if ((e = copyIn(p + 1)) != hipSuccess) { drain(); return hipFail(e, "H2D"); }
+            if ((rc = launch(p + 1)) != 0) { drain(); return rc; }
         }
-        if ((e = copyOut(p)) != hipSuccess) return hipFail(e, "D2H");
+        if ((e = copyOut(p)) != hipSuccess) { drain(); return hipFail(e, "D2H"); }
     }
     e = hipStreamSynchronize(copyOut_);
     if (e == hipSuccess) e = hipStreamSynchronize(stream_);
