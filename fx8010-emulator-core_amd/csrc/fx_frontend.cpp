@@ -356,7 +356,12 @@ void lutDomainBounds(float out[2]) {
 // reached threshold g, and that d at threshold g+1 is at least W.  Returns the high word of the largest such W with a
 // zero low word (the test is one unsigned compare of d's high word: sign bit and NaN read as "large"), 0 if the grid
 // does not allow the test.  Only the grid enters (step, x1, thresholds), not the table contents.
+static uint32_t computeGuessWindowHi();
 uint32_t lutGuessWindowHi() {
+    static const uint32_t hi = computeGuessWindowHi();
+    return hi;
+}
+static uint32_t computeGuessWindowHi() {
     const double step = (1.0 - -1.0) / 63.0;
     auto indexOf = [&](double t) { return (int)(t / step); };
     double w = HUGE_VAL;
