@@ -27,6 +27,7 @@ def main():
         rng = np.random.default_rng(770000 + seed)
         text = stress_fuzz.product_cache_program(rng, int(rng.integers(4, 90)))
         x = (rng.uniform(-1.0, 1.0, size=(S, N)) * rng.choice([1.0, 0.5, 1e-3], size=(1, N))).astype(np.float32)
+        x *= np.float32(float(os.environ.get("FX_FUZZ_SCALE", "1")))   # > 1: waves leave the fast streams (and with them the product cache)
         b = A.Batch(N, 1, 0)
         if not b.load_text(text):
             continue
