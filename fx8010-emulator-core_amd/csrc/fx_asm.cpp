@@ -133,10 +133,28 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
             case H_LIMIT: slot = AS_LIMIT; break;
             case H_LIMITN: slot = AS_LIMITN; break;
             case H_LOG:
-            case H_EXP:
+            case H_EXP: {
                 slot = AS_LUT;
                 r.w[3] = (uint32_t)((kLutSegOff + (size_t)m.w[5] * 128) * 8);  // this table's {slope, y1}[64]
+                // a uniform operand inside the table: the result is the same constant for every instance and sample - the
+                // reference's own arithmetic (linearInterpolate, source/FX8010.cpp:283-296), once, here; R = that constant
+                // (outside the table the kernel's code runs: it raises the out-of-domain flag)
+                const float x = asFloat(m.w[2]);
+                if (foldUniform && has(m, F_UA) && x >= -1.0f && x <= 1.0f && m.w[5] < 64u) {
+                    static const Luts luts;
+                    const double* tbl = m.w[5] < 32u ? luts.log_[m.w[5]] : luts.exp_[m.w[5] - 32u];
+                    const double xd = (double)x, step = (1.0 - -1.0) / (double)(64 - 1);
+                    const int idx = (int)((xd - -1.0) / step);
+                    const double x1 = -1.0 + idx * step, x2 = -1.0 + (idx + 1) * step, y1 = tbl[idx], y2 = tbl[idx + 1];
+                    const double y = (y2 - y1) / (x2 - x1) * (xd - x1) + y1;
+                    slot = AS_MOV;
+                    r.w[2] = asBits((float)y);
+                    r.w[3] = 0;
+                    r.w[4] = 0;
+                    r.w[6] = 1u | (ccr << 3);
+                }
                 break;
+            }
             case H_SKIP: slot = AS_SKIP; break;
             case H_TRAM_IR: slot = AS_TRAM_IR; break;
             case H_TRAM_IW: slot = AS_TRAM_IW; break;
