@@ -1,0 +1,38 @@
+#!/bin/bash
+# The differential fuzzers back to back on the GPU box (gpurun): one summary line per run under gpurun_out/<tag>/campaign.txt.
+#   tools/fuzz_campaign.sh <tag> [scale]      scale multiplies the program counts (default 1)
+TAG=${1:-campaign}
+K=${2:-1}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+run() { # label, env..., command
+  local label=$1; shift
+  local line
+  line=$(env "$@" 2>&1 | tail -1 | cut -c1-240)
+  echo "$label: $line" | tee -a "$OUT/campaign.txt"
+}
+: > "$OUT/campaign.txt"
+run "sweep default"            timeout -k 10 900 python3 tools/fuzz_sweep.py 2000000 $((6000*K))
+run "sweep inputs x3 + ood"    FX_FUZZ_SCALE=3 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/fuzz_sweep.py 2100000 $((4000*K))
+run "sweep non-finite inputs"  FX_FUZZ_NAN=0.03 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/fuzz_sweep.py 2200000 $((4000*K))
+run "sweep 250 registers"      FX_FUZZ_REGS=250 timeout -k 10 900 python3 tools/fuzz_sweep.py 2300000 $((1500*K))
+run "sweep interpreter"        FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_sweep.py 2400000 $((2000*K))
+run "sweep interpreter (LDS)"  FX_KERNEL=asm_lds timeout -k 10 900 python3 tools/fuzz_sweep.py 2500000 $((1000*K))
+run "sweep HIP kernel"         FX_KERNEL=hip timeout -k 10 900 python3 tools/fuzz_sweep.py 2600000 $((2000*K))
+run "api"                      timeout -k 10 900 python3 tools/fuzz_api.py 2000000 $((2500*K))
+run "api wild registers"       FX_FUZZ_WILD=1 timeout -k 10 900 python3 tools/fuzz_api.py 2100000 $((2000*K))
+run "api two shards"           FX_FUZZ_SHARDS=2 timeout -k 10 900 python3 tools/fuzz_api.py 2200000 $((1500*K))
+run "api interpreter"          FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_api.py 2300000 $((800*K))
+run "api HIP kernel"           FX_KERNEL=hip timeout -k 10 900 python3 tools/fuzz_api.py 2400000 $((800*K))
+run "stereo"                   timeout -k 10 900 python3 tools/fuzz_stereo.py 2000000 $((800*K))
+run "delay lines"              timeout -k 10 900 python3 tools/fuzz_tram.py 2000000 $((3000*K))
+run "delay lines x3"           FX_FUZZ_SCALE=3 timeout -k 10 900 python3 tools/fuzz_tram.py 2100000 $((3000*K))
+run "delay lines DANE"         timeout -k 10 900 python3 tools/fuzz_tram.py 2200000 $((3000*K)) dane
+run "product cache"            timeout -k 10 900 python3 tools/fuzz_cse.py 2000000 $((4000*K))
+run "product cache x3"         FX_FUZZ_SCALE=3 timeout -k 10 900 python3 tools/fuzz_cse.py 2100000 $((3000*K))
+run "at scale 65553 x3"        FX_FUZZ_SCALE=3 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/stress_fuzz.py $((400*K)) 65553
+run "at scale 262144"          timeout -k 10 900 python3 tools/stress_fuzz.py $((400*K)) 262144
+run "benchmark programs"       timeout -k 10 900 python3 tools/stress_scale.py 3
+echo done
