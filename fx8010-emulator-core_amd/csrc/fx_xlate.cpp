@@ -432,7 +432,7 @@ class Emitter {
 enum : uint32_t {
     VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
-    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_GT_U32 = 0xcc,
+    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_LE_F32 = 0x43, VOPC_CMP_GT_U32 = 0xcc,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6, SOPP_CBRANCH_VCCNZ = 7,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
@@ -1580,6 +1580,60 @@ class Translator {
         value_[k] = value;
     }
 
+    // MACW / MACWN / MACINTW (FX8010.cpp:1126-1143, wrapAround :299-328) inline in the FAST stream: every operand is finite
+    // there, so the order of the sources does not matter; the exact stream keeps calling the interpreter's handler, whose
+    // sources are ordered like the x86 build's.  The result is not saturated: it can overflow, so it is checked like a
+    // value from memory, and the wave leaves for the exact stream behind the same record there - after the CCR, which the
+    // handler writes before it returns.   w(a) = a >= 1 ? a - 2 : (a < -1 ? a + 2 : a)
+    void wrapInto(int dst, int src) {   // dst may be src; v5, v6 scratch
+        const Src vcc = named(106, "vcc");
+        e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 5, imm32(0xc0000000u), src);                   // a - 2
+        e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x40000000u), src);                   // a + 2
+        e_.vopc(VOPC_CMP_GT_F32, "v_cmp_gt_f32_e32", imm32(0xbf800000u), src);                // -1 > a
+        e_.sopp(SOPP_NOP, "s_nop", 1, true);
+        e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", 6, vreg(src), 6, ", vcc");
+        e_.vopc(VOPC_CMP_LE_F32, "v_cmp_le_f32_e32", imm32(0x3f800000u), src);                // 1 <= a
+        e_.sopp(SOPP_NOP, "s_nop", 1, true);
+        e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", dst, vreg(6), 5, ", vcc");
+        (void)vcc;
+    }
+    bool wrapFamily(const MicroOp& r, uint32_t slot, bool ccrLive) {
+        const uint32_t kind = r.w[6] & 7u;
+        int vR;
+        // (the exact stream calls the handler here and waits for every delay-line read in flight first: the two streams must
+        // wait - and define their sync points - at the same records)
+        if (!flush() || !row(r.w[5], &vR)) return false;
+        // ... and leave the record words in s18..s22 as its call does: later calls of EITHER stream skip the words they know
+        // to be there already, and a wave may change streams in between
+        for (int k = 2; k < 7; ++k) setRecordWord(k, k == 6 && !ccrLive ? (r.w[6] & ~8u) : r.w[k]);
+        plainMode();
+        int pv = 3;
+        if ((kind & 6u) == 6u) {  // both factors uniform: the product here (finite: a non-finite uniform disables the fast stream)
+            const float p = asFloat(r.w[3]) * asFloat(r.w[4]);
+            uint32_t pb;
+            std::memcpy(&pb, &p, 4);
+            if ((pb & 0x7f800000u) == 0x7f800000u) return fail("internal: non-finite product of uniforms in a fast stream");
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(3), imm32(pb));
+        } else {
+            bool inV3;
+            int entry;
+            if (!product(r, kind, &inV3, &pv, &entry)) return false;
+        }
+        Src a;
+        if (!operand(r.w[2], kind & 1u, &a)) return false;
+        if (slot == AS_MACINTW) {
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 2, a, pv);                                 // A + X*Y
+            wrapInto(vR, 2);
+        } else {
+            wrapInto(3, pv);                                                                  // (never into a cached product)
+            e_.vop2(slot == AS_MACW ? VOP2_ADD_F32 : VOP2_SUB_F32, slot == AS_MACW ? "v_add_f32_e32" : "v_sub_f32_e32", vR, a, 3);
+        }
+        if (ccrLive) ccrFrom(vR);
+        returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+        taintIfNonFinite(vR);
+        return leaveIfTainted((*exactReturns_)[syncIndex(1)]);
+    }
+
     // run the interpreter's handler for this record: operands in s18..s23, return address in s[24:25]
     bool call(const MicroOp& r, uint32_t slot, uint32_t wordMask) {
         if (slot >= (uint32_t)kAsmSlots) return fail("record with an unknown handler slot");
@@ -1825,6 +1879,10 @@ class Translator {
             if (ccrLive) ccrOrSkip(vR);
             ++stats_.inlined;
             return true;
+        }
+        if (fast_ && (slot == AS_MACW || slot == AS_MACWN || slot == AS_MACINTW)) {
+            ++stats_.inlined;
+            return wrapFamily(r, slot, ccrLive != 0);
         }
         if (slot < AS_MACS && ((r.w[6] >> 3) & 1u) && !ccrLive) {
             MicroOp q = r;

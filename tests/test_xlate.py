@@ -222,3 +222,27 @@ def test_quick_lut_guess_is_generated_for_bounded_operands():
     assert listing.count("v_and_b32_e32 v7") == listing.count("v_cmp_le_u32_e32 vcc") > 0
     assert "v_cvt_i32_f32" not in listing           # config4's LOG/EXP operands are all results of saturating instructions
     assert assemble(listing) == code
+
+
+def test_random_programs_all_translate():
+    """The batch falls back to the interpreter tier silently when a translation fails - e.g. when the fast and the exact stream
+    of a program disagree about where they wait (their sync points).  Every random program of the fuzzers' generators must
+    translate, in all four streams."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_fuzz
+    failures = []
+    for seed in range(400):
+        rng = np.random.default_rng(500000 + 3000000 + seed)
+        gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
+        text = gen(rng, int(rng.integers(4, 100)), int(rng.integers(2, 50)))
+        fe = A.FrontEnd(1)
+        if not fe.load_text(text):
+            continue
+        for stream in range(4):
+            try:
+                fe.translate(0, stream)
+            except RuntimeError as e:
+                failures.append((seed, stream, str(e)[:120]))
+                break
+    assert not failures, failures[:5]

@@ -67,6 +67,10 @@ def main():
                 print("MISMATCH seed", seed, "instance", n, "kernel", b.info("kernel"), flush=True)
                 break
         del b
+    if not os.environ.get("FX_KERNEL") and not os.environ.get("FX_INST_PER_LANE") and any(1 <= k <= 8 for k in kernels):
+        # the default tier ran some programs on the interpreter: a translation failed (the batch falls back silently)
+        print("NOTE: interpreter fallbacks in default mode:", {k: v for k, v in kernels.items() if 1 <= k <= 8})
+        failures.append("interpreter fallback")
     print("fuzz sweep:", count, "programs, kernels", kernels, "failures", failures)
     return 1 if failures else 0
 
