@@ -1580,6 +1580,29 @@ class Translator {
         value_[k] = value;
     }
 
+    // LIMIT / LIMITN (FX8010.cpp:1163-1174): R = (A >= Y) ? X : Y  resp.  (A < Y) ? X : Y - a compare and a select, no
+    // arithmetic: nothing depends on the order of sources, so both streams generate the same code (h_limit / h_limitn are
+    // the interpreter's versions).  An ordered compare is false for a NaN: Y is chosen, as in the reference.
+    bool limitInline(const MicroOp& r, uint32_t slot, bool ccrLive) {
+        const uint32_t kind = r.w[6] & 7u;
+        int vR;
+        if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true) || !row(r.w[5], &vR)) return false;
+        plainMode();
+        Src a, x, y;
+        if (!operand(r.w[2], kind & 1u, &a) || !operand(r.w[3], (kind & 2u) != 0, &x) || !operand(r.w[4], (kind & 4u) != 0, &y)) return false;
+        int vX = 3, vY = 4;
+        if (kind & 2u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(3), x);
+        else if (!row(r.w[3], &vX)) return false;
+        if (kind & 4u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(4), y);
+        else if (!row(r.w[4], &vY)) return false;
+        if (slot == AS_LIMIT) e_.vopc(VOPC_CMP_GE_F32, "v_cmp_ge_f32_e32", a, vY);
+        else e_.vopc(VOPC_CMP_LT_F32, "v_cmp_lt_f32_e32", a, vY);
+        e_.sopp(SOPP_NOP, "s_nop", 1, true);
+        e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", vR, vreg(vY), vX, ", vcc");
+        if (ccrLive) ccrOrSkip(vR);
+        return true;
+    }
+
     // MACW / MACWN / MACINTW (FX8010.cpp:1126-1143, wrapAround :299-328) inline in the FAST stream: every operand is finite
     // there, so the order of the sources does not matter; the exact stream keeps calling the interpreter's handler, whose
     // sources are ordered like the x86 build's.  The result is not saturated: it can overflow, so it is checked like a
@@ -1879,6 +1902,10 @@ class Translator {
             if (ccrLive) ccrOrSkip(vR);
             ++stats_.inlined;
             return true;
+        }
+        if (slot == AS_LIMIT || slot == AS_LIMITN) {
+            ++stats_.inlined;
+            return limitInline(r, slot, ccrLive != 0);
         }
         if (fast_ && (slot == AS_MACW || slot == AS_MACWN || slot == AS_MACINTW)) {
             ++stats_.inlined;
