@@ -403,6 +403,50 @@ int fxo_load_file(fxo_t* f, const char* path) {
 
 /* ------------------------------------------------------------ hot path */
 
+/* The arithmetic of the hot path, operand order included.  The reference is an x86-64 SSE2 build (g++ -O2): every fp32 / fp64
+ * operation is ONE two-operand SSE instruction `op first, second`, and what that instruction does with NaNs is part of the
+ * reference's observable behaviour (tests/golden/nonfinite.json, nan_collisions.json):
+ *   - a NaN in `first` is handed on (quieted, sign and payload kept); otherwise a NaN in `second` is;
+ *   - an invalid operation (Inf - Inf, 0 * Inf) makes the negative default NaN 0xFFC00000 / 0xFFF8000000000000;
+ *   - cvtss2sd / cvtsd2ss quiet a NaN and keep sign and the payload's top bits.
+ * Which C operand g++ made `first` is pinned per expression by nan_collisions.json (generated from the compiled reference) and
+ * written out at each call below.  Plain C `a + b` leaves that choice to the compiler (gcc -O0, clang and sanitizer builds pick
+ * differently), so the checker does not use it where a NaN can arrive. */
+static inline uint32_t f32_bits(float v) { uint32_t u; memcpy(&u, &v, 4); return u; }
+static inline float bits_f32(uint32_t u) { float v; memcpy(&v, &u, 4); return v; }
+static inline uint64_t f64_bits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
+static inline double bits_f64(uint64_t u) { double v; memcpy(&v, &u, 8); return v; }
+static inline int nan32(float v) { return (f32_bits(v) & 0x7fffffffu) > 0x7f800000u; }
+static inline int nan64(double v) { return (f64_bits(v) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull; }
+static inline float sse_pick32(float first, float second, float plain) {
+    if (nan32(first)) return bits_f32(f32_bits(first) | 0x00400000u);
+    if (nan32(second)) return bits_f32(f32_bits(second) | 0x00400000u);
+    if (nan32(plain)) return bits_f32(0xffc00000u);
+    return plain;
+}
+static inline double sse_pick64(double first, double second, double plain) {
+    if (nan64(first)) return bits_f64(f64_bits(first) | 0x0008000000000000ull);
+    if (nan64(second)) return bits_f64(f64_bits(second) | 0x0008000000000000ull);
+    if (nan64(plain)) return bits_f64(0xfff8000000000000ull);
+    return plain;
+}
+static inline float addss(float first, float second) { return sse_pick32(first, second, first + second); }
+static inline float subss(float first, float second) { return sse_pick32(first, second, first - second); }
+static inline float mulss(float first, float second) { return sse_pick32(first, second, first * second); }
+static inline double addsd(double first, double second) { return sse_pick64(first, second, first + second); }
+static inline double subsd(double first, double second) { return sse_pick64(first, second, first - second); }
+static inline double mulsd(double first, double second) { return sse_pick64(first, second, first * second); }
+static inline double cvtss2sd(float v) {
+    if (!nan32(v)) return (double)v;
+    const uint32_t u = f32_bits(v);
+    return bits_f64(((uint64_t)(u >> 31) << 63) | 0x7ff8000000000000ull | ((uint64_t)(u & 0x003fffffu) << 29));
+}
+static inline float cvtsd2ss(double v) {
+    if (!nan64(v)) return (float)v;
+    const uint64_t u = f64_bits(v);
+    return bits_f32((uint32_t)(u >> 63) << 31 | 0x7fc00000u | (uint32_t)((u >> 29) & 0x003fffffu));
+}
+
 /* x86 cvttss2si / cvttsd2si: out-of-range and NaN give the "integer indefinite"
  * 0x80000000 — what every static_cast<int>(float) in the reference compiles to. */
 static inline int32_t cvtt_f32(float v) { if (!(v < 2147483648.0f) || v < -2147483648.0f) return INT32_MIN; return (int32_t)v; }
@@ -461,7 +505,7 @@ static inline double linear_interpolate(fxo_t* f, double x, const double* tbl) {
     double x2 = x_min + (index + 1) * step;
     double y1 = tbl[index];
     double y2 = tbl[index + 1];                  /* index 63 reads the pad (reference: out of bounds) */
-    double y = (y2 - y1) / (x2 - x1) * (x - x1) + y1;
+    double y = addsd(mulsd((y2 - y1) / (x2 - x1), subsd(x, x1)), y1);   /* tables and knots are finite: x is the only NaN source */
     return y;
 }
 static inline const double* lut_row(fxo_t* f, int kind, float xsel) {
@@ -531,31 +575,31 @@ void fxo_process(fxo_t* f, const float* in, float* out) {
                 }
                 switch (I->op) {
                 case OP_MACS: case OP_MACINTS: {                             /* :1077-1085, :1095-1103 */
-                    float p = X->value * Y->value; float t = A->value + p;
+                    float p = mulss(X->value, Y->value); float t = addss(p, A->value);   /* addss product, A: NaN order X, Y, A */
                     f->acc = t; R->value = saturate(t, 1.0f); set_ccr(f, R->value); break; }
                 case OP_MACSN: {                                             /* :1086-1094 */
-                    float p = X->value * Y->value; float t = A->value - p;
+                    float p = mulss(X->value, Y->value); float t = subss(A->value, p);   /* subss A, product: A, X, Y */
                     f->acc = t; R->value = saturate(t, 1.0f); set_ccr(f, R->value); break; }
                 case OP_ACC3: {                                              /* :1104-1112 */
-                    float t = A->value + X->value; t = t + Y->value;
+                    float t = addss(A->value, X->value); t = addss(t, Y->value);           /* A, X, Y */
                     f->acc = t; R->value = saturate(t, 1.0f); set_ccr(f, R->value); break; }
                 case OP_LOG: {                                               /* :1113-1119 */
-                    float r = (float)linear_interpolate(f, (double)A->value, lut_row(f, 0, X->value));
+                    float r = cvtsd2ss(linear_interpolate(f, cvtss2sd(A->value), lut_row(f, 0, X->value)));
                     R->value = r; f->acc = r; set_ccr(f, r); break; }
                 case OP_EXP: {                                               /* :1120-1125 */
-                    float r = (float)linear_interpolate(f, (double)A->value, lut_row(f, 1, X->value));
+                    float r = cvtsd2ss(linear_interpolate(f, cvtss2sd(A->value), lut_row(f, 1, X->value)));
                     R->value = r; f->acc = r; set_ccr(f, r); break; }
                 case OP_MACW: {                                              /* :1126-1131; g++ -O2 reads A before calling wrapAround */
-                    float a = A->value; float p = X->value * Y->value; float w = wrap_around(f, p);
-                    float r = a + w; R->value = r; f->acc = r; set_ccr(f, r); break; }
+                    float a = A->value; float p = mulss(X->value, Y->value); float w = wrap_around(f, p);
+                    float r = addss(a, w);                                                  /* A, X, Y */ R->value = r; f->acc = r; set_ccr(f, r); break; }
                 case OP_MACWN: {                                             /* :1132-1137 */
-                    float a = A->value; float p = X->value * Y->value; float w = wrap_around(f, p);
-                    float r = a - w; R->value = r; f->acc = r; set_ccr(f, r); break; }
+                    float a = A->value; float p = mulss(X->value, Y->value); float w = wrap_around(f, p);
+                    float r = subss(a, w);                                                  /* A, X, Y */ R->value = r; f->acc = r; set_ccr(f, r); break; }
                 case OP_MACINTW: {                                           /* :1138-1143 */
-                    float p = X->value * Y->value; float t = A->value + p; float r = wrap_around(f, t);
+                    float p = mulss(X->value, Y->value); float t = addss(p, A->value); float r = wrap_around(f, t); /* X, Y, A */
                     R->value = r; f->acc = r; set_ccr(f, r); break; }
                 case OP_MACMV: {                                             /* :1144-1149 */
-                    float p = X->value * Y->value; f->acc = f->acc + (double)p;
+                    float p = mulss(X->value, Y->value); f->acc = addsd(f->acc, cvtss2sd(p)); /* acc is never observed */
                     R->value = A->value; set_ccr(f, R->value); break; }
                 case OP_ANDXOR: {                                            /* :1150-1154 */
                     R->value = (float)logic_ops(A->value, X->value, Y->value); set_ccr(f, R->value); break; }
@@ -572,9 +616,9 @@ void fxo_process(fxo_t* f, const float* in, float* out) {
                     if ((float)cvtt_f32(X->value) == regs[0].value) num_skip = cvtt_f32(Y->value);
                     break;
                 case OP_INTERP: {                                            /* :1180-1187 */
-                    float p = X->value * Y->value;
-                    double d = (1.0 - (double)X->value) * (double)A->value + (double)p;
-                    float r = (float)d; f->acc = r; R->value = saturate(r, 1.0f); set_ccr(f, R->value); break; }
+                    float p = mulss(X->value, Y->value);                                    /* NaN order X, A, Y */
+                    double d = addsd(mulsd(subsd(1.0, cvtss2sd(X->value)), cvtss2sd(A->value)), cvtss2sd(p));
+                    float r = cvtsd2ss(d); f->acc = r; R->value = saturate(r, 1.0f); set_ccr(f, R->value); break; }
                 case OP_IDELAY:                                              /* :1188-1199 */
                     if ((f->opts & FXO_OPT_TRAM_DANE) && (R->type == RT_READ || R->type == RT_WRITE)) {
                         if (f->itram_size <= 0) { f->ood |= FXO_OOD_TRAM_SIZE0; if (R->type == RT_READ) A->value = 0.0f; break; }

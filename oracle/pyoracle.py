@@ -19,7 +19,9 @@ import tempfile
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PORT_SO = os.path.join(_HERE, "libfxoracle.so")
+# FXORACLE_SO selects another build of the same restatement (oracle/Makefile `variants`: -O0, clang, ASan+UBSan) for
+# tests/test_oracle_variants.py; everything else uses the pinned gcc -O2 build
+_PORT_SO = os.environ.get("FXORACLE_SO") or os.path.join(_HERE, "libfxoracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libfxref.so")
 
 _f32p = C.POINTER(C.c_float)
