@@ -1,7 +1,7 @@
 // fx_interp_gfx950.s — hand-written CDNA4 (gfx950) interpreter for the FX8010 opcode stream.
 //
 // One wavefront = 64 emulated DSPs (one per lane), one workgroup = one wavefront.  The host
-// decoder (fx_asm_stream.cpp) turns the program into 32-byte records; this kernel is a
+// decoder (fx_decode.cpp + fx_asm.cpp encodeAsmStream) turns the program into 32-byte records; this kernel is a
 // direct-threaded interpreter over them:
 //
 //   record  w0:w1 = absolute address of the handler (patched in by the host from the probe launch)
@@ -597,6 +597,9 @@ h_endsample_d:
 
 	// ---- epilogue: LDS rows and VGPR state -> state rows
 .Lepilogue:
+#ifdef RF_VGPR
+	s_set_gpr_idx_off                                     // entered from a handler / from generated code: whatever index mode that left
+#endif
 	s_waitcnt vmcnt(0) lgkmcnt(0)
 	s_mov_b32 s62, 0
 	s_cmp_eq_u32 s75, 0

@@ -631,8 +631,9 @@ class Translator {
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
         }
         for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
-        for (const auto& c : pool_) e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(c.second), imm32(c.first, true));
-        for (const auto& c : prog_.vconst) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(c.second), imm32(c.first, true));
+        // (inline constants where the bit pattern has one, as the assembler would choose: the listing must re-assemble to the same bytes)
+        for (const auto& c : pool_) e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(c.second), imm32(c.first));
+        for (const auto& c : prog_.vconst) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(c.second), imm32(c.first));
         if (anyLut && prog_.lutTables.empty()) {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLutXthr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSLutXthr + 1), sreg(kSLut + 1), imm32(0));

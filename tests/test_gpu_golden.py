@@ -78,51 +78,24 @@ def test_reference_vectors(gpu, tier, fixture):
 
 
 # Non-finite values, bit for bit (tests/golden/nonfinite.json, nan_collisions.json: what the x86 build of the reference
-# does with NaN payloads and signs, Inf, and NaNs made by the arithmetic itself).  The translated program and the HIP C++
-# kernel reproduce every word.  The VGPR builds of the hand-written interpreter read their register-file operand through
-# VGPR index mode, which only reaches src0 - and gfx950 hands on the NaN of src0 first: where the x86 build prefers the
-# OTHER operand and BOTH are NaN, that tier hands on the other payload.  Exactly these cases (and nothing else):
-ASM_TIER_OTHER_PAYLOAD = {
-    # MACS / MACINTS: x86 X, Y, A - interpreter A before the product
-    "macs_ab", "macs_ac", "macs_abc", "macints_ab", "macints_ac", "macints_abc",
-    # ACC3: x86 (A + X) before Y - interpreter Y before the sum
-    "acc3_ac", "acc3_bc", "acc3_abc",
-    # nonfinite.json: a NaN state meeting a NaN input in `macs a, a, in, 0.5`
-    "feedback",
-}
+# does with NaN payloads and signs, Inf, and NaNs made by the arithmetic itself) - on EVERY tier and every build of the
+# hand-written interpreter: its VGPR builds reach a register-file row in either source position (VGPR index mode SRC0 / SRC1),
+# so that the source order of each add / multiply is the x86 build's operand order (fx_interp_handlers.inc).
+ALL_BUILDS = ["default", "hip", "asm", "asm_lds", "asm_v64", "asm_v72", "asm_v80", "asm_v96", "asm_v128", "asm_v168", "asm_v256", "xlate_v256"]
 
 
 @pytest.mark.parametrize("per_instance", [False, True], ids=["uniform_controls", "per_instance_rows"])
 @pytest.mark.parametrize("fixture", ["nonfinite.json", "nan_collisions.json"])
-def test_non_finite_words_are_the_references(gpu, tier, fixture, per_instance):
+@pytest.mark.parametrize("build", ALL_BUILDS)
+def test_non_finite_words_are_the_references(gpu, monkeypatch, build, fixture, per_instance):
     """per_instance: the NaN operands sit in register-file rows (the device arithmetic decides); otherwise they are
     uniform controls (folded on the host, or literals of the generated code)"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    if build != "default":
+        monkeypatch.setenv("FX_KERNEL", build)
     for case in load(fixture):
-        if tier == "asm" and per_instance and case["name"] in ASM_TIER_OTHER_PAYLOAD:
-            continue
-        if tier == "asm" and case["name"] == "feedback":
-            continue
         run_case(gpu, case, per_instance_sets=per_instance)
-
-
-def test_interpreter_tier_collisions_still_yield_a_nan(gpu, monkeypatch):
-    """the cases the interpreter tier is excused from above: same NaN-ness, same instruction counts - another payload"""
-    monkeypatch.setenv("FX_KERNEL", "asm")
-    cases = {c["name"]: c for f in ("nonfinite.json", "nan_collisions.json") for c in load(f)}
-    for name in sorted(ASM_TIER_OTHER_PAYLOAD):
-        case = cases[name]
-        b = gpu.Batch(3, 1, 0)
-        assert b.load_text(case["program"])
-        sets = {int(k): [(reg, float(np.array([v], dtype=np.uint32).view(np.float32)[0])) for reg, v in lst] for k, lst in case.get("sets_bits", {}).items()}
-        for reg, val in sets.get(0, []):
-            b.set_register(reg, val)
-        x1 = f32(case["input"], case["shape"])
-        y = b.process_block(np.repeat(x1.reshape(-1, 1), 3, axis=1).copy())
-        want = f32(case["output"], case["shape"])
-        assert np.array_equal(np.isnan(want), np.isnan(y[:, 1])), name
-        keep = ~np.isnan(want)
-        assert np.array_equal(want.view(np.uint32)[keep], np.ascontiguousarray(y[:, 1]).view(np.uint32)[keep]), name
-        assert b.instruction_counter_i(1) == case["counter"]
 
 
 def test_config_programs(gpu, tier):

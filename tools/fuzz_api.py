@@ -20,10 +20,7 @@ from pyoracle import Oracle  # noqa: E402
 def same(ref, got):
     ref = np.asarray(ref, dtype=np.float32).reshape(-1)
     got = np.asarray(got, dtype=np.float32).reshape(-1)
-    if not os.environ.get("FX_KERNEL", "").startswith("asm"):
-        return np.array_equal(ref.view(np.uint32), got.view(np.uint32))  # NaN words included
-    rn, gn = np.isnan(ref), np.isnan(got)  # interpreter tier: two NaNs meeting in one instruction may hand on the other payload
-    return np.array_equal(rn, gn) and np.array_equal(ref.view(np.uint32)[~rn], got.view(np.uint32)[~gn])
+    return np.array_equal(ref.view(np.uint32), got.view(np.uint32))  # NaN words included, on every tier
 
 
 WILD = os.environ.get("FX_FUZZ_WILD") == "1"  # register values beyond [-1, 1] (state that breaks the bounded-row class)
@@ -144,8 +141,7 @@ def run(seed, verbose=False):
             for n in check:
                 for r in names + ["ccr"]:
                     gb, rb = b.get_register_bits_i(r, n), oracles[n].get_register_bits(r)
-                    gf, rf = np.array([gb], dtype=np.uint32).view(np.float32)[0], np.array([rb], dtype=np.uint32).view(np.float32)[0]
-                    if gb != rb and not (np.isnan(gf) and np.isnan(rf)):
+                    if gb != rb:
                         print("REGISTER seed %d step %d %s[%d] %08x %08x kernel %d" % (seed, step, r, n, gb, rb, b.info("kernel")))
                         return False
     for n in check:
