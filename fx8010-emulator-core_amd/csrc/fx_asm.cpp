@@ -204,36 +204,51 @@ hipError_t launchRaw(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_
 
 // One wavefront of the build's probe kernel (<name>_probe, same code object) writes the absolute address of
 // each of the build's kAsmSets * kAsmSlots handlers; they stay valid for as long as the module is loaded.
+// g_mu guards the tables only: the probe launch, its wait and the copy back run outside the lock (several shards on several
+// devices initialise at once; two threads racing for the same table both probe, the first to publish wins).
 const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err) {
     hipFunction_t fn;
-    hipError_t e = functionFor(variant, device, &fn);  // loads the module
+    hipError_t e = functionFor(variant, device, &fn);  // loads the module (under the lock, once per device)
+    uint64_t* table = nullptr;
     if (e == hipSuccess) {
-        std::lock_guard<std::mutex> lock(g_mu);
-        if (!g_tables[device][variant]) {
-            const std::string probeName = std::string(kVariantNames[variant]) + "_probe";
-            e = hipModuleGetFunction(&fn, g_modules[device], probeName.c_str());
+        hipModule_t module;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            table = g_tables[device][variant];
+            module = g_modules[device];
         }
-        if (e == hipSuccess && !g_tables[device][variant]) {
+        if (!table) {
+            const std::string probeName = std::string(kVariantNames[variant]) + "_probe";
+            e = hipModuleGetFunction(&fn, module, probeName.c_str());
             const size_t bytes = sizeof(uint64_t) * kAsmSets * kAsmSlots;
             uint64_t* dbuf = nullptr;
-            e = hipMalloc(reinterpret_cast<void**>(&dbuf), bytes);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dbuf), bytes);
             if (e == hipSuccess) {
                 AsmArgs a{};
                 a.out = reinterpret_cast<float*>(dbuf);
                 a.n = 64;
                 a.nPad = 256;
-                e = launchRaw(fn, a, 1, 0, nullptr);
-                if (e == hipSuccess) e = hipDeviceSynchronize();
+                hipStream_t stream = nullptr;
+                e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);  // (a stream of its own: no device-wide wait)
+                if (e == hipSuccess) e = launchRaw(fn, a, 1, 0, stream);
                 uint64_t* host = new uint64_t[kAsmSets * kAsmSlots];
-                if (e == hipSuccess) e = hipMemcpy(host, dbuf, bytes, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpyAsync(host, dbuf, bytes, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (stream) (void)hipStreamDestroy(stream);
                 (void)hipFree(dbuf);
-                if (e == hipSuccess) g_tables[device][variant] = host;
-                else delete[] host;
+                if (e == hipSuccess) {
+                    std::lock_guard<std::mutex> lock(g_mu);
+                    if (!g_tables[device][variant]) g_tables[device][variant] = host;
+                    else delete[] host;
+                    table = g_tables[device][variant];
+                } else {
+                    delete[] host;
+                }
             }
         }
     }
     if (err) *err = e;
-    return e == hipSuccess ? g_tables[device][variant] : nullptr;
+    return e == hipSuccess ? table : nullptr;
 }
 
 hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream) {

@@ -153,6 +153,16 @@ int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instanc
     if (n_instances) *n_instances = h->batch.countOf(shard);
     return 0;
 }
+int fxb_shard_plan(int64_t n, int n_shards, int64_t* first_instance, int64_t* n_instances_out) {
+    if (n_shards < 1 || !first_instance || !n_instances_out) return FX_E_ARG;
+    try {
+        const auto ranges = fx::Sharded::plan(n, n_shards);
+        for (int k = 0; k < n_shards; ++k) { first_instance[k] = ranges[(size_t)k].first; n_instances_out[k] = ranges[(size_t)k].second; }
+        return 0;
+    } catch (...) {
+        return FX_E_ARG;
+    }
+}
 void fxb_destroy(fxb_handle* h) { delete h; }
 int fxb_set_option(fxb_handle* h, unsigned option, int on) { return h ? h->batch.setOption(option, on != 0) : FX_E_ARG; }
 int fxb_load_file(fxb_handle* h, const char* path) { return (h && path) ? guard(&h->batch.front(), 0, [&] { return h->batch.loadFile(path) ? 1 : 0; }) : 0; }

@@ -5,7 +5,7 @@
 // indices, the error list (text + 1-based row) and the metadata/control lists.  The reference
 // drives std::regex; this loader is a hand-written scanner with the same language, including
 // the places where regex backtracking is observable (noted below).  It is exercised against
-// the compiled reference on a line corpus in tests/test_frontend_golden.py.
+// the compiled reference on a 74-program corpus (tests/golden/parser_corpus.json) in tests/test_frontend.py.
 #include "fx_model.hpp"
 
 #include <algorithm>

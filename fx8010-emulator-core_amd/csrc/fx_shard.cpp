@@ -8,29 +8,56 @@
 
 namespace fx {
 
-Sharded::Sharded(int64_t nInstances, int channels, const std::vector<int>& devices) : n_(nInstances) {
-    if (devices.empty()) throw std::runtime_error("no device given");
-    if (nInstances < (int64_t)devices.size()) throw std::runtime_error("fewer instances than shards");
-    const int64_t k = (int64_t)devices.size();
-    // contiguous ranges, whole wavefronts (64 instances) per shard where possible: shard i gets ceil-ish share
+namespace {
+// restores the calling thread's current HIP device: fx::Batch selects its own device in every call
+struct DeviceGuard {
+    int prev = -1;
+    bool armed = false;
+    DeviceGuard() { armed = hipGetDevice(&prev) == hipSuccess; }
+    ~DeviceGuard() { if (armed) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
+std::vector<std::pair<int64_t, int64_t>> Sharded::plan(int64_t nInstances, int nShards) {
+    if (nShards < 1) throw std::runtime_error("no device given");
+    if (nInstances < (int64_t)nShards) throw std::runtime_error("fewer instances than shards");
+    const int64_t k = nShards;
+    // contiguous ranges, whole wavefronts (64 instances) per shard: the first (waves mod k) shards get one wavefront more,
+    // the last shard ends at nInstances (a ragged last wavefront)
     const int64_t waves = (nInstances + 63) / 64;
+    std::vector<std::pair<int64_t, int64_t>> out;
     int64_t first = 0;
     for (int64_t i = 0; i < k; ++i) {
         const int64_t wavesHere = waves / k + (i < waves % k ? 1 : 0);
-        int64_t count = i + 1 == k ? nInstances - first : std::min<int64_t>(wavesHere * 64, nInstances - first);
+        const int64_t count = i + 1 == k ? nInstances - first : std::min<int64_t>(wavesHere * 64, nInstances - first);
         if (count < 1) throw std::runtime_error("a shard would be empty: use fewer devices for this few instances");
-        auto w = std::make_unique<Worker>();
-        w->first = first;
-        w->count = count;
-        w->batch = std::make_unique<Batch>(count, channels, devices[(size_t)i]);
+        out.emplace_back(first, count);
         first += count;
-        shards_.push_back(std::move(w));
     }
-    if (shards_.size() > 1)
-        for (auto& w : shards_) w->thread = std::thread(loop, w.get());
+    return out;
 }
 
-Sharded::~Sharded() {
+Sharded::Sharded(int64_t nInstances, int channels, const std::vector<int>& devices) : n_(nInstances) {
+    const auto ranges = plan(nInstances, (int)devices.size());
+    DeviceGuard guard;  // constructing a Batch selects its device on this (the caller's) thread
+    for (size_t i = 0; i < devices.size(); ++i) {
+        auto w = std::make_unique<Worker>();
+        w->first = ranges[i].first;
+        w->count = ranges[i].second;
+        w->batch = std::make_unique<Batch>(w->count, channels, devices[i]);
+        shards_.push_back(std::move(w));
+    }
+    if (shards_.size() > 1) {
+        try {
+            for (auto& w : shards_) w->thread = std::thread(loop, w.get());
+        } catch (...) {
+            stopThreads();  // a joinable std::thread must not be destroyed: stop the workers that did start, then report
+            throw;
+        }
+    }
+}
+
+void Sharded::stopThreads() {
     for (auto& w : shards_) {
         if (!w->thread.joinable()) continue;
         {
@@ -41,6 +68,8 @@ Sharded::~Sharded() {
         w->thread.join();
     }
 }
+
+Sharded::~Sharded() { stopThreads(); }
 
 void Sharded::loop(Worker* w) {
     std::unique_lock<std::mutex> lock(w->mu);
@@ -65,7 +94,10 @@ void Sharded::loop(Worker* w) {
 }
 
 int Sharded::fan(const std::function<int(int, Batch&)>& f) {
-    if (shards_.size() == 1) return f(0, *shards_[0]->batch);
+    if (shards_.size() == 1) {
+        DeviceGuard guard;
+        return f(0, *shards_[0]->batch);
+    }
     for (size_t k = 0; k < shards_.size(); ++k) {
         Worker* w = shards_[k].get();
         std::lock_guard<std::mutex> lock(w->mu);
@@ -84,6 +116,25 @@ int Sharded::fan(const std::function<int(int, Batch&)>& f) {
         }
     }
     return first;
+}
+
+int Sharded::runOn(int k, const std::function<int(Batch&)>& f) {
+    Worker* w = shards_[(size_t)k].get();
+    if (shards_.size() == 1) {
+        DeviceGuard guard;
+        return f(*w->batch);
+    }
+    {
+        std::lock_guard<std::mutex> lock(w->mu);
+        w->task = [&f, w] { return f(*w->batch); };
+        w->pending = true;
+        w->done = false;
+        w->cv.notify_all();
+    }
+    std::unique_lock<std::mutex> lock(w->mu);
+    w->cv.wait(lock, [&] { return w->done; });
+    if (w->result != 0) lastError_ = w->batch->lastError();
+    return w->result;
 }
 
 int Sharded::shardOf(int64_t inst) const {
@@ -107,17 +158,24 @@ int Sharded::setRegister(const std::string& key, float v) {
     return fan([&](int, Batch& b) { return b.setRegister(key, v); });
 }
 void Sharded::setChannels(int c) {
-    for (auto& w : shards_) w->batch->setChannels(c);
+    fan([&](int, Batch& b) { b.setChannels(c); return 0; });
+}
+int Sharded::setOption(unsigned option, bool on) {
+    lastError_.clear();
+    return fan([&](int, Batch& b) { return b.setOption(option, on) ? -3 : 0; });
 }
 int Sharded::setRegisterAt(const std::string& key, int64_t inst, float v) {
+    lastError_.clear();
     const int k = shardOf(inst);
     if (k < 0) { lastError_ = "instance out of range"; return front().program().findRegister(key) < 0 ? 1 : FX_E_ARG; }
-    return shards_[(size_t)k]->batch->setRegisterAt(key, inst - shards_[(size_t)k]->first, v);
+    return runOn(k, [&](Batch& b) { return b.setRegisterAt(key, inst - shards_[(size_t)k]->first, v); });
 }
 float Sharded::getRegisterAt(const std::string& key, int64_t inst) {
+    lastError_.clear();
     const int k = shardOf(inst);
-    if (k < 0) return front().getRegisterAt(key, -1);
-    return shards_[(size_t)k]->batch->getRegisterAt(key, inst - shards_[(size_t)k]->first);
+    float out = 1.0f;
+    runOn(k < 0 ? 0 : k, [&](Batch& b) { out = b.getRegisterAt(key, k < 0 ? -1 : inst - shards_[(size_t)k]->first); return 0; });
+    return out;
 }
 int Sharded::setRegisterArray(const std::string& key, const float* values) {
     lastError_.clear();
@@ -130,9 +188,10 @@ int Sharded::getRegisterArray(const std::string& key, float* values) {
     return fan([&](int k, Batch& b) { return b.getRegisterArray(key, values + shards_[(size_t)k]->first); });
 }
 int Sharded::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
+    lastError_.clear();
     const int k = shardOf(inst);
     if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
-    return shards_[(size_t)k]->batch->seedNoiseAt(inst - shards_[(size_t)k]->first, x1, x2);
+    return runOn(k, [&](Batch& b) { return b.seedNoiseAt(inst - shards_[(size_t)k]->first, x1, x2); });
 }
 
 int Sharded::setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance) {
@@ -144,7 +203,7 @@ int Sharded::setRegisterTrack(const std::string& key, const float* values, int n
 
 int Sharded::processHost(const float* in, float* out, int nSamples) {
     lastError_.clear();
-    if (shards_.size() == 1) return front().processHost(in, out, nSamples);
+    if (shards_.size() == 1) return runOn(0, [&](Batch& b) { return b.processHost(in, out, nSamples); });
     if (nSamples > 0 && (!in || !out)) { lastError_ = "null buffer"; return FX_E_ARG; }
     return fan([&](int k, Batch& b) {
         const int64_t first = shards_[(size_t)k]->first;
@@ -159,7 +218,7 @@ int Sharded::processDeviceShards(const float* const* dIn, float* const* dOut, in
 int Sharded::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
     lastError_.clear();
     if (shards_.size() != 1) { lastError_ = "a batch of several shards takes one buffer pair per shard: fxb_process_block_dev_shards"; return FX_E_ARG; }
-    return front().processDevice(dIn, dOut, nSamples, stream);
+    return runOn(0, [&](Batch& b) { return b.processDevice(dIn, dOut, nSamples, stream); });
 }
 int Sharded::sync() {
     lastError_.clear();
@@ -178,7 +237,10 @@ int64_t Sharded::instructionCounter() {
 }
 int64_t Sharded::instructionCounterAt(int64_t inst) {
     const int k = shardOf(inst);
-    return k < 0 ? 0 : shards_[(size_t)k]->batch->instructionCounterAt(inst - shards_[(size_t)k]->first);
+    if (k < 0) return 0;
+    int64_t out = 0;
+    runOn(k, [&](Batch& b) { out = b.instructionCounterAt(inst - shards_[(size_t)k]->first); return 0; });
+    return out;
 }
 uint32_t Sharded::oodFlags() {
     std::vector<uint32_t> part(shards_.size(), 0);
@@ -188,17 +250,21 @@ uint32_t Sharded::oodFlags() {
     return all;
 }
 float Sharded::lastKernelMs() {
+    std::vector<float> part(shards_.size(), -1.0f);
+    fan([&](int k, Batch& b) { part[(size_t)k] = b.lastKernelMs(); return 0; });  // (a shard's events belong to its thread's device)
     float worst = -1.0f;
-    for (auto& w : shards_) worst = std::max(worst, w->batch->lastKernelMs());
+    for (float p : part) worst = std::max(worst, p);
     return worst;
 }
 int64_t Sharded::info(int what) {
+    std::vector<int64_t> part(shards_.size(), 0);
+    fan([&](int k, Batch& b) { part[(size_t)k] = b.info(what); return 0; });
     if (what == FXB_INFO_GRID) {
         int64_t sum = 0;
-        for (auto& w : shards_) sum += w->batch->info(what);
+        for (int64_t p : part) sum += p;
         return sum;
     }
-    return front().info(what);
+    return part[0];
 }
 
 }  // namespace fx

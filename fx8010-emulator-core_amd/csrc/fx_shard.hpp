@@ -4,8 +4,11 @@
 // [first_k, first_k + count_k) on device devices[k]; the program, its LUTs and the control values are replicated.
 // There is NO exchange step and no collective: every operation is a fan-out to the shards and a fan-in of their
 // results.  Each shard has its own host thread (so that the devices' copies, launches and waits overlap) and its
-// own HIP stream (inside fx::Batch); a shard's Batch is only ever touched from its thread.  A "sharded" batch with
-// a single shard runs inline on the caller's thread - that is what fxb_create() makes.
+// own HIP stream (inside fx::Batch).  Every call that reaches a shard's device - broadcast or per instance - is posted
+// to that shard's thread (fan / runOn), so the CALLER's current HIP device is never changed by a multi-shard handle; reads of
+// replicated host state (program, error list, controls: front()) stay on the caller's thread.  A "sharded" batch with a
+// single shard (what fxb_create() makes) runs inline on the caller's thread, under a guard that restores the caller's
+// current device afterwards.
 #pragma once
 
 #include <condition_variable>
@@ -14,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "fx_batch.hpp"
@@ -28,6 +32,10 @@ public:
     ~Sharded();
     Sharded(const Sharded&) = delete;
     Sharded& operator=(const Sharded&) = delete;
+
+    // The partition: contiguous ranges of whole wavefronts (64 instances), the remainder in the last shard.  Pure
+    // arithmetic (no device): fxb_shard_plan() exposes it, the constructor uses it.  Throws when a shard would be empty.
+    static std::vector<std::pair<int64_t, int64_t>> plan(int64_t nInstances, int nShards);
 
     int shards() const { return (int)shards_.size(); }
     int64_t instances() const { return n_; }
@@ -47,7 +55,7 @@ public:
     int seedNoiseAt(int64_t inst, int32_t x1, int32_t x2);
     int setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance);
     void setChannels(int c);
-    int setOption(unsigned option, bool on) { int rc = 0; for (auto& w : shards_) rc = w->batch->setOption(option, on) ? -3 : rc; return rc; }
+    int setOption(unsigned option, bool on);
 
     // host buffers [sample][channel][all instances]: every shard copies its columns in, runs, copies them out
     int processHost(const float* in, float* out, int nSamples);
@@ -80,6 +88,9 @@ private:
     int shardOf(int64_t inst) const;
     // run f(k, batch) on every shard's thread, wait for all; returns the first non-zero result (shard order)
     int fan(const std::function<int(int, Batch&)>& f);
+    // run f(batch) on shard k's thread and wait (a single shard: inline, caller's device restored)
+    int runOn(int k, const std::function<int(Batch&)>& f);
+    void stopThreads();
     static void loop(Worker* w);
 
     int64_t n_ = 0;

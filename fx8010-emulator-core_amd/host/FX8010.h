@@ -8,10 +8,10 @@
 // source/main.cpp, or the VST block loop it is meant for - compiles unchanged against this header and
 // runs the instruction loop on an MI355X instead of the host CPU.  tests/test_dropin_harness.py compiles
 // and links the reference's own source/main.cpp + source/helpers.cpp, where they lie, against it:
-//     g++ -std=c++17 -include fx8010-emulator-core_amd/host/FX8010.h -I include \
+//     g++ -std=c++17 -DFX8010_REFERENCE_COMPAT -include fx8010-emulator-core_amd/host/FX8010.h -I include \
 //         /root/reference/source/main.cpp /root/reference/source/helpers.cpp -L fx8010-emulator-core_amd -lfx8010_amd
-// (this header defines the reference's include guard FX8010_H, so main.cpp's own
-// #include "../include/FX8010.h" contributes nothing).
+// (with FX8010_REFERENCE_COMPAT this header defines the reference's include guard FX8010_H, so main.cpp's own
+// #include "../include/FX8010.h" contributes nothing; without it only the classes below are declared).
 //
 //   Klangraum::FX8010         one emulated DSP, one process() call per sample period
 //   Klangraum::FX8010Batch    N independent DSPs stepping one program on one GPU (the data-parallel path) or, built
@@ -26,15 +26,28 @@
 //     one-channel DSP.
 #ifndef FX8010_AMD_HOST_FX8010_H
 #define FX8010_AMD_HOST_FX8010_H
-// the reference header's own guard: whoever includes this file has "included FX8010.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fx8010_amd.h"
+
+// ---- opt-in: everything ELSE the reference header hands its includers (define FX8010_REFERENCE_COMPAT before including, or
+// pass -DFX8010_REFERENCE_COMPAT).  The reference's own callers need it - source/main.cpp relies on `using namespace std`, PI,
+// DEBUG, AUDIOBLOCKSIZE and on <iostream> / <chrono> / <math.h> coming with the header - but a new includer (a plug-in host)
+// should not get a namespace dump and macros called E and DEBUG, so the class below is available without it.
+#ifdef FX8010_REFERENCE_COMPAT
+// the reference header's own guard: whoever includes this file has "included FX8010.h" (a later #include of the reference's
+// include/FX8010.h contributes nothing)
 #ifndef FX8010_H
 #define FX8010_H
 #endif
 
 // what include/FX8010.h:12-24 pulls in for its includers
 #include <stdio.h>
-#include <vector>
-#include <string>
 #include <iostream>
 #include <chrono>
 #include <math.h>
@@ -45,11 +58,6 @@
 #include <map>
 #include <array>
 #include <unordered_map>
-
-#include <cstdint>
-#include <stdexcept>
-
-#include "fx8010_amd.h"
 
 using namespace std;  // include/FX8010.h:25 - part of what the reference header exports (main.cpp relies on it)
 
@@ -78,8 +86,12 @@ using namespace std;  // include/FX8010.h:25 - part of what the reference header
 #ifndef MAX_XDELAY_SIZE
 #define MAX_XDELAY_SIZE 1048576
 #endif
+#endif  // FX8010_REFERENCE_COMPAT
 
 namespace Klangraum {
+
+// the reference's settings as constants (include/FX8010.h:35-36, :41-42), whether or not the macros are exported
+constexpr int kSampleRate = 48000, kAudioBlockSize = 32, kMaxIDelaySize = 8192, kMaxXDelaySize = 1048576;
 
 class FX8010 {
 public:
@@ -111,6 +123,7 @@ public:
 
     int getInstructionCounter() { return (int)fx_instruction_counter(h_); }
     bool loadFile(const std::string& path) { return fx_load_file(h_, path.c_str()) == 1; }
+    bool load(const std::string& path) { return loadFile(path); }  // alias (the reference's member is loadFile, include/FX8010.h:62)
 
     struct MyError {
         std::string errorDescription = "";
@@ -175,6 +188,7 @@ public:
     FX8010Batch& operator=(const FX8010Batch&) = delete;
 
     bool loadFile(const std::string& path) { return fxb_load_file(h_, path.c_str()) == 1; }
+    bool load(const std::string& path) { return loadFile(path); }
     bool loadText(const std::string& text) { return fxb_load_text(h_, text.c_str()) == 1; }
     int setRegisterValue(const std::string& key, float value) { return fxb_set_register(h_, key.c_str(), value); }
     int setRegisterValue(const std::string& key, int64_t instance, float value) { return fxb_set_register_i(h_, key.c_str(), instance, value); }

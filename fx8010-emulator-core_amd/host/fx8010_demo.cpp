@@ -28,19 +28,19 @@ int main(int argc, char** argv) {
         }
         // bipolar ramp -1 .. +1, the stimulus the reference harness uses for LOG/EXP
         std::vector<float> ramp;
-        for (int i = -AUDIOBLOCKSIZE / 2; i < AUDIOBLOCKSIZE / 2; ++i) ramp.push_back((float)i / (AUDIOBLOCKSIZE / 2.0f));
+        for (int i = -Klangraum::kAudioBlockSize / 2; i < Klangraum::kAudioBlockSize / 2; ++i) ramp.push_back((float)i / (Klangraum::kAudioBlockSize / 2.0f));
         const float sliders[4] = {0.1f, 0.25f, 0.5f, 1.0f};
         std::vector<float> in(numChannels), out;
         auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < AUDIOBLOCKSIZE; ++i) {
+        for (int i = 0; i < Klangraum::kAudioBlockSize; ++i) {
             if (i % 8 == 0) fx.setRegisterValue("volume", sliders[i / 8]);
             in[0] = ramp[i];
             out = fx.process(in);
             std::cout << ramp[i] << "," << out[0] << "\n";
         }
         auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-        std::cout << "one instance, " << AUDIOBLOCKSIZE << " process() calls: " << us << " us, " << fx.getInstructionCounter()
-                  << " instructions (real-time budget " << 1e6 * AUDIOBLOCKSIZE / SAMPLERATE << " us)\n";
+        std::cout << "one instance, " << Klangraum::kAudioBlockSize << " process() calls: " << us << " us, " << fx.getInstructionCounter()
+                  << " instructions (real-time budget " << 1e6 * Klangraum::kAudioBlockSize / Klangraum::kSampleRate << " us)\n";
         std::cout << "filter_cutoff = " << fx.getRegisterValue("filter_cutoff") << "\n";
         for (const auto& kv : fx.getMetaData()) std::cout << kv.first << ": " << kv.second << "\n";
         for (const auto& c : fx.getControlRegisters()) std::cout << "control: " << c << "\n";
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
         if (!batch.loadFile(argv[1])) return 1;
         std::vector<float> bin((size_t)S * n), bout((size_t)S * n);
         for (int s = 0; s < S; ++s)
-            for (int64_t k = 0; k < n; ++k) bin[(size_t)s * n + k] = ramp[(s + k) % AUDIOBLOCKSIZE] * 0.9f;
+            for (int64_t k = 0; k < n; ++k) bin[(size_t)s * n + k] = ramp[(s + k) % Klangraum::kAudioBlockSize] * 0.9f;
         batch.process(bin.data(), bout.data(), S);  // warm-up (also uploads the program)
         const int64_t c0 = batch.getInstructionCounter();
         batch.process(bin.data(), bout.data(), S);

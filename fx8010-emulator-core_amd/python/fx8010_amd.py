@@ -30,7 +30,7 @@ SYMBOLS = [
     "fx_create", "fx_destroy", "fx_load_file", "fx_process", "fx_process_block", "fx_set_register", "fx_get_register",
     "fx_instruction_counter", "fx_error_count", "fx_error_desc", "fx_error_row", "fx_control_count", "fx_control_at",
     "fx_meta_get", "fx_set_option", "fxb_set_option", "fxp_set_option", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
-    "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
+    "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_shard_plan", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
     "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
     "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error",
@@ -70,6 +70,7 @@ def load():
     sig("fxb_create", vp, i64, i32, i32); sig("fxb_destroy", None, vp)
     sig("fxb_create_sharded", vp, i64, i32, C.c_uint64); sig("fxb_create_on_devices", vp, i64, i32, C.POINTER(C.c_int), i32)
     sig("fxb_shard_count", i32, vp); sig("fxb_shard_info", i32, vp, i32, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64))
+    sig("fxb_shard_plan", i32, i64, i32, C.POINTER(i64), C.POINTER(i64))
     sig("fxb_process_block_dev_shards", i32, vp, C.POINTER(vp), C.POINTER(vp), i32)
     sig("fxb_load_file", i32, vp, cp); sig("fxb_load_text", i32, vp, cp)
     sig("fxb_set_register", i32, vp, cp, f32); sig("fxb_set_register_i", i32, vp, cp, i64, f32)
@@ -195,6 +196,16 @@ class FrontEnd(_Reports):
     def lut(kind, exponent):
         p = load().fxp_lut(kind, exponent)
         return np.ctypeslib.as_array(p, shape=(64,)).copy()
+
+
+def shard_plan(n_instances, n_shards):
+    """[(first_instance, count)] of the partition fxb_create_sharded / fxb_create_on_devices would use; None when a shard
+    would be empty.  No device needed."""
+    lib = load()
+    first, count = (C.c_int64 * max(n_shards, 1))(), (C.c_int64 * max(n_shards, 1))()
+    if lib.fxb_shard_plan(int(n_instances), int(n_shards), first, count) != 0:
+        return None
+    return [(int(first[k]), int(count[k])) for k in range(n_shards)]
 
 
 class Batch(_Reports):

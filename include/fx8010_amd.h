@@ -55,7 +55,8 @@ extern "C" {
  *   position = floatToInt(value) >> 11 = floor(value * 2^20) (floatToInt as source/FX8010.cpp:1016-1020), and a tap declared
  *   "at 1439" starts with &rd = 1439 * 2^-20.  That keeps addresses inside [-1, 1): MACS / MACSN / INTERP can compute
  *   them (kX's "macs t, &wrt1, rd_max_shifted, sin_abs"); the low 11 bits (the interpolation fraction) are dropped.
- * Implemented by the HIP C++ kernel tier (FXB_INFO_KERNEL 0) and by oracle/ (FXO_OPT_*). */
+ * Implemented as generated code by the translated tier (taps whose position is the same in every instance), by the HIP C++
+ * kernel tier (FXB_INFO_KERNEL 0; also taps with a per-instance position) and, as the checker, by oracle/ (FXO_OPT_*). */
 #define FX_OPT_TRAM_DANE (1u << 0)
 #define FX_OPT_TRAM_ADDR_SHIFT (1u << 1)
 
@@ -123,6 +124,10 @@ fxb_handle* fxb_create_on_devices(int64_t n_instances, int num_channels, const i
 int fxb_shard_count(fxb_handle* h);
 /* device ordinal, first global instance and instance count of a shard; 0 or FX_E_ARG.  Any out pointer may be NULL. */
 int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instance, int64_t* n_instances);
+/* The partition fxb_create_sharded / fxb_create_on_devices use for n_instances over n_shards devices, without creating
+ * anything (no device needed): first_instance[k], n_instances[k] for k < n_shards.  0, or FX_E_ARG when a shard would be
+ * empty (fewer wavefronts than shards) or an argument is invalid. */
+int fxb_shard_plan(int64_t n_instances, int n_shards, int64_t* first_instance, int64_t* n_instances_out);
 void fxb_destroy(fxb_handle* h);
 int fxb_set_option(fxb_handle* h, unsigned option, int on);   /* FX_OPT_*: before loading */
 /* as fx_load_file; the program is parsed once on the host and lowered to the device

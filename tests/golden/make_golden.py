@@ -90,6 +90,14 @@ OPCODE_PROGRAMS = {
     "andxor_or": "macw a, 0, in, 100\nandxor out, a, 12, -13", "andxor_nand": "macw a, 0, in, 100\nandxor out, a, 12, 16777215",
     "andxor_not_unreachable": "macw a, 0, in, 100\nandxor out, a, 268435455, 16777215",
     "andxor_or_from_registers": "macw a, 0, in, 100\nmacw b, -1, a, -1\nandxor out, 5, a, b",
+    # LOG / EXP of a uniform operand (a literal, a control): the result is one constant - the device tiers fold it on the host
+    # (fx_asm.cpp encodeAsmStream) - inside the table, at both ends of it (x == 1.0 reads table entry [idx + 1] times 0), with the
+    # CCR it sets read as an operand and consumed by a SKIP
+    "log_uniform": "log a, 0.5, 3, 0\nmacs out, in, a, 0.5", "exp_uniform_minus_one": "exp a, -1.0, 7, 0\nmacs out, in, a, 0.5",
+    "log_uniform_one_then_skip": "log a, 1.0, 31, 0\nskip ccr, ccr, 16, 1\nmacs out, 0, in, 1.0\nmacs b, out, 0.5, 0.5",
+    "log_uniform_zero_then_skip": "log a, 0, 3, 0\nskip ccr, ccr, 8, 2\nmacs out, 0, in, 1.0\nmacs b, out, 0.5, 0.5\nmacs out, out, a, 0.25",
+    "exp_uniform_ccr_operand": "exp a, 0.25, 2, 0\nmacs out, in, ccr, 0.03125", "log_of_a_control": "log a, vol, 5, 0\nmacs out, in, a, 0.5",
+    "exp_uniform_negative_skip": "exp a, -0.375, 3, 0\nskip ccr, ccr, 6, 1\nmacs out, 0, in, 1.0\nmacs b, a, 0.5, 0.5",
 }
 
 # loader corpus: each entry is a whole program text; only load status / error list / lists are pinned

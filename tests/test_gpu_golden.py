@@ -25,7 +25,7 @@ def f32(hexstr, shape=None):
     return a.reshape(shape) if shape else a
 
 
-@pytest.fixture(params=["default", "asm", "hip"], ids=["xlate", "asm", "hip"])
+@pytest.fixture(params=["default", "asm", "asm_lds", "asm_v256", "hip"], ids=["xlate", "asm", "asm_lds", "asm_v256", "hip"])
 def tier(request, monkeypatch):
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)

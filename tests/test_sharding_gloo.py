@@ -28,6 +28,29 @@ def test_shard_ranges_cover_everything():
     assert shard.weak_shard(262144, 3) == (786432, 262144)
 
 
+def test_library_partition_for_up_to_eight_devices():
+    """The C++ host's partition (fx_shard.cpp Sharded::plan, through the C ABI - no device needed): contiguous, complete, whole
+    wavefronts on every shard but the last, balanced to one wavefront, for 1..8 devices and ragged instance counts; and the
+    sizes BASELINE.json names."""
+    import fx8010_amd as A
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1000, 4096, 65536, 65553, 262144, 262145, 2097152, 2097152 + 17, 3 * 2097152 + 1]
+    for n in sizes:
+        for k in range(1, 9):
+            plan = A.shard_plan(n, k)
+            waves = (n + 63) // 64
+            if plan is None:
+                assert waves < k or n < k, (n, k)     # refused only when a shard would be empty
+                continue
+            assert len(plan) == k and plan[0][0] == 0 and sum(c for _, c in plan) == n, (n, k)
+            for (f0, c0), (f1, c1) in zip(plan[:-1], plan[1:]):
+                assert f0 + c0 == f1 and c0 % 64 == 0 and f1 % 64 == 0, (n, k, plan)   # shards start on a wavefront
+            assert all(c >= 1 for _, c in plan)
+            per = [(c + 63) // 64 for _, c in plan]
+            assert max(per) - min(per) <= 1, (n, k, plan)                             # balanced to one wavefront
+    assert A.shard_plan(2097152, 8) == [(i * 262144, 262144) for i in range(8)]        # BASELINE configs[4]
+    assert A.shard_plan(64, 2) is None and A.shard_plan(0, 1) is None and A.shard_plan(10, 0) is None
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
