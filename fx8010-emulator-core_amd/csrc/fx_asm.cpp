@@ -194,11 +194,11 @@ hipError_t functionFor(AsmVariant variant, int device, hipFunction_t* fn) {
     return hipSuccess;
 }
 
-hipError_t launchRaw(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream) {
+hipError_t launchRaw(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream, unsigned wavesPerGroup = 1) {
     AsmArgs a = args;
     size_t size = sizeof(a);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    return hipModuleLaunchKernel(fn, grid, 1, 1, 64, 1, 1, (unsigned)ldsBytes, stream, nullptr, config);
+    return hipModuleLaunchKernel(fn, grid, 1, 1, 64 * wavesPerGroup, 1, 1, (unsigned)ldsBytes, stream, nullptr, config);
 }
 }  // namespace
 
@@ -251,8 +251,8 @@ const uint64_t* asmHandlerTable(AsmVariant variant, int device, hipError_t* err)
     return e == hipSuccess ? table : nullptr;
 }
 
-hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream) {
-    return launchRaw(fn, args, grid, ldsBytes, stream);
+hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream, unsigned wavesPerGroup) {
+    return launchRaw(fn, args, grid, ldsBytes, stream, wavesPerGroup);
 }
 
 hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBytes, int device, hipStream_t stream) {

@@ -36,6 +36,9 @@ struct AsmArgs {
     int lutX1Off;
     int initOff;  // translated programs: byte offset (from the kernel entry) of code to run once before the first sample, 0 = none
     const uint32_t* tracks;  // translated programs with control tracks: TrackHeader[kMaxTracks] + values (fx_xlate.hpp), else nullptr
+    const uint32_t* stages;  // translated programs cut into stages: StageDescriptor[nStages] (fx_xlate.hpp), else nullptr
+    int nStages;             // wavefronts per workgroup (0 / 1: the whole program in one)
+    int pad0;
 };
 static_assert(offsetof(AsmArgs, lut) == 0x40, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, nLoad) == 0x58, "AsmArgs layout");
@@ -47,7 +50,9 @@ static_assert(offsetof(AsmArgs, cursorRow) == 0x98, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, oodRow) == 0xa0, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, lutX1Off) == 0xb0, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, tracks) == 0xb8, "AsmArgs layout");
-static_assert(sizeof(AsmArgs) == 0xc0, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, stages) == 0xc0, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, nStages) == 0xc8, "AsmArgs layout");
+static_assert(sizeof(AsmArgs) == 0xd0, "AsmArgs layout");
 
 // handler slots of fx_interp_gfx950.S (fx_interp_table.inc)
 enum AsmSlot : uint32_t {
@@ -86,6 +91,6 @@ hipError_t launchAsmInterp(const AsmArgs& args, AsmVariant variant, size_t ldsBy
 
 // Launches a kernel with the interpreter's argument block from another module (a translated program, fx_xlate.hpp):
 // `grid` single-wavefront workgroups, ldsBytes of dynamic LDS each.
-hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream);
+hipError_t launchAsmFunction(hipFunction_t fn, const AsmArgs& args, unsigned grid, size_t ldsBytes, hipStream_t stream, unsigned wavesPerGroup = 1);
 
 }  // namespace fx

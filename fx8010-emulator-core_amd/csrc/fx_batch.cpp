@@ -226,6 +226,15 @@ bool Batch::laneResident(int reg) const {
     return !lowDirty_ ? low_.rowOfReg[reg] >= 0 : (reg < (int)low_.rowOfReg.size() && low_.rowOfReg[reg] >= 0);
 }
 
+// how many pipeline stages to ask the translator for: until ~4 wavefronts per SIMD are in flight (256 CUs x 4 SIMDs);
+// FX_STAGES pins the number (1 = never)
+int Batch::stagesWanted(int variant) const {
+    if (const char* knob = std::getenv("FX_STAGES")) return std::max(1, std::min(16, std::atoi(knob)));
+    const int64_t waves = (n_ + 63) / 64;
+    const int64_t room = std::min<int64_t>(4096, (int64_t)1024 * kAsmWavesPerSimd[variant]);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(8, room / std::max<int64_t>(waves, 1)));
+}
+
 int Batch::ensureLowered() {
     if (!loaded_ || !prog_.ready) return fail(FX_E_NOTREADY, "no program loaded");
     if (!lowDirty_) return 0;
@@ -256,6 +265,10 @@ int Batch::ensureLowered() {
                     auto usable = [&](int q) { return std::min(kAsmWavesPerSimd[q], std::max(wavesPerSimd, 1)); };
                     while (v < ASM_V256 && kAsmVgprRows[v] - fresh.nRows < kSpareVgprsWanted && usable(v + 1) >= usable(v)) ++v;
                 }
+                // a small batch is cut into stages (below): each stage wants spare registers for its packets and its input
+                // bursts, and at most 4 wavefronts per SIMD will be resident anyway - the 128-register build costs nothing
+                if (stagesWanted(v) >= 2)
+                    while (v < ASM_V128) ++v;
                 const char* pin = forceHip ? std::strstr(forceHip, "_v") : nullptr;
                 if (pin && (std::strncmp(forceHip, "asm_v", 5) == 0 || std::strncmp(forceHip, "xlate_v", 7) == 0)) {
                     // diagnostics: pin a (large enough) build of the interpreter (asm_vNN) or of the translator (xlate_vNN)
@@ -301,6 +314,7 @@ int Batch::ensureLowered() {
 
     // upload: steady | last | row table
     useXlate_ = false;
+    xlateStages_ = 1;
     xlateDeferred_ = false;
     // (a block of more than ~half a millisecond of translated code pays for its translation at once)
     const double blockMs = (double)n_ * (double)pendingSamples_ * (double)std::max(low_.staticCount, 1) / 1e10;
@@ -321,7 +335,24 @@ int Batch::ensureLowered() {
         const XlateTemplate* tmpl = nullptr;
         bool built = false;
         tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
-        built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &xlateWhyNot_);
+        // Small batches leave SIMDs empty (and a lone wavefront issues an instruction every ~4.5 clocks): cut the program
+        // into stages run by the wavefronts of one workgroup (fx_xlate.hpp StageInfo) until ~4 wavefronts per SIMD are in
+        // flight.  FX_STAGES pins the number asked for (1 = never).
+        const int wantStages = stagesWanted((int)asmVariant_);
+        stagesWhyNot_.clear();
+        if (tmpl && wantStages >= 2) {
+            const StagePlan plan = planStages(steadyRecords, lastRecords, xprog, low_.nRows, wantStages);
+            stagesWhyNot_ = plan.why;
+            std::string why;
+            if (!plan.cuts.empty()) {
+                // (several workgroups per CU must fit its 160 KiB of LDS together)
+                const int64_t groupsPerCu = std::max<int64_t>(1, ((n_ + 63) / 64 + 255) / 256);
+                const uint32_t ldsBudget = (uint32_t)std::min<int64_t>(144 * 1024, 160 * 1024 / groupsPerCu - 256);
+                built = buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, plan, &image, nullptr, nullptr, &why, ldsBudget);
+                if (!built) { stagesWhyNot_ = why; image = XlateImage(); }
+            }
+        }
+        if (!built) built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &xlateWhyNot_);
         if (built) {
             waitLastLaunch();  // the previous launch may still run the old code
             if (xlateModule_) (void)hipModuleUnload(xlateModule_);
@@ -343,6 +374,9 @@ int Batch::ensureLowered() {
             xlateValuSlow_ = image.steady.valuSlow;
             xlateValuClocks_ = image.steady.valuClocks;
             xlateVgprConstants_ = image.vgprConstants;
+            xlateStages_ = image.stages;
+            xlateStageDesc_ = image.stageDesc;
+            xlateStageStoreRows_ = image.stageStoreRows;
             useXlate_ = true;
         }
     }
@@ -359,7 +393,8 @@ int Batch::ensureLowered() {
         low_.last = encodeAsmStream(low_.last, handlers, fold);
     }
     const size_t nOps = low_.steady.size();
-    const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size();
+    const bool staged = useXlate_ && xlateStages_ > 1;
+    const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size() + (staged ? (size_t)xlateStages_ * 8 : 0);
     if (words > streamCap_) {
         waitLastLaunch();
         (void)hipFree(dStream_);
@@ -377,8 +412,29 @@ int Batch::ensureLowered() {
         const bool bounded = useXlate_ && rcp.ldsRow < xlateWildRow_.size() && !xlateWildRow_[rcp.ldsRow];
         host[p++] = rcp.ldsRow | (bounded ? 0x8000u : 0u) | ((uint32_t)rcp.stateRow << 16);
     }
-    for (const RowCopy& rcp : low_.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+    if (staged) {
+        // the store rows grouped by the stage that owns them; each stage's descriptor names its slice
+        for (int k = 0; k < xlateStages_; ++k) {
+            xlateStageDesc_[(size_t)k].storeFirst = (uint32_t)(p - (nOps * 16 + low_.loadRows.size()));
+            uint32_t count = 0;
+            for (const RowCopy& rcp : low_.storeRows) {
+                const std::vector<int>& mine = xlateStageStoreRows_[(size_t)k];
+                if (std::find(mine.begin(), mine.end(), (int)rcp.ldsRow) == mine.end()) continue;
+                host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+                ++count;
+            }
+            xlateStageDesc_[(size_t)k].storeCount = count;
+        }
+        if (p != nOps * 16 + low_.loadRows.size() + low_.storeRows.size()) return fail(FX_E_PROGRAM, "internal: a store row without a stage");
+    } else {
+        for (const RowCopy& rcp : low_.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+    }
     for (int zr : low_.zeroRows) host[p++] = (uint32_t)zr;
+    if (staged) {
+        static_assert(sizeof(StageDescriptor) == 32, "StageDescriptor layout");
+        std::memcpy(host.data() + p, xlateStageDesc_.data(), (size_t)xlateStages_ * 32);
+        p += (size_t)xlateStages_ * 8;
+    }
     waitLastLaunch();  // the previous launch may still read the old stream
     hipError_t e = hipMemcpy(dStream_, host.data(), words * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipFail(e, "stream upload");
@@ -660,7 +716,11 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                 g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLast_);
                 g.initOff = (int)xlateInitOff_;
                 g.tracks = trackRegs_.empty() ? nullptr : dTracks_;
-                e = launchAsmFunction(xlateFn_, g, (unsigned)((n_ + 63) / 64), xlateLdsBytes_, s);
+                if (xlateStages_ > 1) {
+                    g.stages = dStream_ + nOps * 16 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size();
+                    g.nStages = xlateStages_;
+                }
+                e = launchAsmFunction(xlateFn_, g, (unsigned)((n_ + 63) / 64), xlateLdsBytes_, s, (unsigned)xlateStages_);
             } else {
                 e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
             }
@@ -870,7 +930,7 @@ int64_t Batch::info(int what) {
     if (what == FXB_INFO_NUM_INSTRUCTIONS) return (int64_t)prog_.instrs.size();
     if (what == FXB_INFO_NUM_REGISTERS) return (int64_t)prog_.regs.size();
     if (what == FXB_INFO_GRID) return lastGrid_;
-    if (what == FXB_INFO_WAVES_PER_WG) return 1;
+    if (what == FXB_INFO_WAVES_PER_WG) return (useAsm_ && useXlate_) ? xlateStages_ : 1;
     if (ensureLowered() != 0) return -1;
     switch (what) {
         case FXB_INFO_INST_PER_LANE: return instPerLane_;
@@ -885,7 +945,7 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_VGPR_CONSTANTS: return useXlate_ ? xlateVgprConstants_ : 0;
         case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
         case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
-        case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? 0 : (int64_t)low_.nRows * 256 * instPerLane_;
+        case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? (useXlate_ ? (int64_t)xlateLdsBytes_ : 0) : (int64_t)low_.nRows * 256 * instPerLane_;
         case FXB_INFO_NUM_ROWS: return low_.nRows;
         case FXB_INFO_NUM_MICROOPS: return (int64_t)low_.steady.size();
         case FXB_INFO_ITRAM_SLOTS: return iSlotsAlloc_;

@@ -115,6 +115,11 @@ private:
     hipFunction_t xlateFn_ = nullptr;
     uint64_t xlateSteady_ = 0, xlateLast_ = 0;  // {fast, exact} stream offsets as the kernel takes them
     uint32_t xlateCodeBytes_ = 0, xlateInitOff_ = 0, xlateLdsBytes_ = 0;
+    int stagesWanted(int variant) const;
+    int xlateStages_ = 1;                        // wavefronts per workgroup of the translated program (fx_xlate.hpp StageInfo)
+    std::vector<StageDescriptor> xlateStageDesc_;
+    std::vector<std::vector<int>> xlateStageStoreRows_;
+    std::string stagesWhyNot_;
     int xlateInlined_ = 0, xlateCalled_ = 0, xlateUnsaturated_ = 0, xlateValu_ = 0, xlateValuSlow_ = 0, xlateValuClocks_ = 0, xlateVgprConstants_ = 0;
     std::vector<uint8_t> xlateWildRow_;
     std::string xlateWhyNot_;

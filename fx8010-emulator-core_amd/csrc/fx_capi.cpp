@@ -270,11 +270,12 @@ int64_t fxp_lower_info(fxp_handle* h, int what) {
         default: return -1;
     }
 }
-static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap);
+static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap, int stages, int stage,
+                             int* stagesOut, int* info, int infoCap);
 int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap) {
     if (!h) return FX_E_ARG;
     try {
-        return translateImpl(h, vgprs, stream, code, cap, listing, listing_cap);
+        return translateImpl(h, vgprs, stream, code, cap, listing, listing_cap, 1, 0, nullptr, nullptr, 0);
     } catch (const std::exception& e) {
         h->err = e.what();
         return codeOf(e);
@@ -283,7 +284,8 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t 
         return FX_E_PROGRAM;
     }
 }
-static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap) {
+static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap, int stages, int stage,
+                             int* stagesOut, int* info, int infoCap) {
     if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
     if (listing && listing_cap > 0) listing[0] = 0;
     std::vector<float> values(h->prog.regs.size());
@@ -310,9 +312,28 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     fx::XlateImage plan;
     const std::vector<fx::MicroOp> steadyRecords = fx::encodeAsmStream(low.steady, nullptr, true), lastRecords = fx::encodeAsmStream(low.last, nullptr, true);
     fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow);
-    if (!fx::planXlate(steadyRecords, lastRecords, *tmpl, xprog, &plan, code4, text4, &h->err)) return FX_E_PROGRAM;
-    const std::vector<uint32_t>& words = code4[stream];
-    const std::string& text = text4[stream];
+    std::vector<std::vector<uint32_t>> stagedCode;
+    std::vector<std::string> stagedText;
+    if (stagesOut) *stagesOut = 1;
+    bool staged = false;
+    if (stages >= 2) {
+        const fx::StagePlan sp = fx::planStages(steadyRecords, lastRecords, xprog, low.nRows, stages);
+        if (!sp.cuts.empty()) {
+            if (!fx::buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, sp, &plan, &stagedCode, &stagedText, &h->err)) return FX_E_PROGRAM;
+            staged = true;
+            if (stagesOut) *stagesOut = plan.stages;
+            // info: per cut its record index and the number of rows handed over, then the LDS bytes of a workgroup
+            int q = 0;
+            for (size_t c = 0; c < sp.cuts.size() && info && q + 2 <= infoCap; ++c) { info[q++] = sp.cuts[c]; info[q++] = (int)sp.live[c].size(); }
+            if (info && q < infoCap) info[q++] = (int)plan.ldsBytes;
+        } else {
+            h->err = "not cut into stages: " + sp.why;
+        }
+    }
+    if (staged && (stage < 0 || stage >= plan.stages)) { h->err = "no such stage"; return FX_E_ARG; }
+    if (!staged && !fx::planXlate(steadyRecords, lastRecords, *tmpl, xprog, &plan, code4, text4, &h->err)) return FX_E_PROGRAM;
+    const std::vector<uint32_t>& words = staged ? stagedCode[stream == 4 ? (size_t)plan.stages * 4 : (size_t)stage * 4 + (size_t)stream] : code4[stream];
+    const std::string& text = staged ? stagedText[stream == 4 ? (size_t)plan.stages * 4 : (size_t)stage * 4 + (size_t)stream] : text4[stream];
     const int64_t bytes = (int64_t)words.size() * 4;
     if (code && cap > 0) std::memcpy(code, words.data(), (size_t)std::min<int64_t>(cap, bytes));
     if (listing && listing_cap > 0) {
@@ -321,6 +342,19 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
         listing[n] = 0;
     }
     return bytes;
+}
+int64_t fxp_translate_staged(fxp_handle* h, int vgprs, int stages, int stage, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap,
+                             int* stages_out, int* info, int info_cap) {
+    if (!h) return FX_E_ARG;
+    try {
+        return translateImpl(h, vgprs, stream, code, cap, listing, listing_cap, stages, stage, stages_out, info, info_cap);
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return codeOf(e);
+    } catch (...) {
+        h->err = "unknown error";
+        return FX_E_PROGRAM;
+    }
 }
 const char* fxp_last_error(fxp_handle* h) { return h ? h->err.c_str() : "null handle"; }
 

@@ -84,7 +84,9 @@
 	.set KA_LUTX1OFF, 0xb0      // byte offset of x1[] inside the LUT blob
 	.set KA_INIT,     0xb4      // translated programs: offset of run-once code (LDS tables), 0 = none
 	.set KA_TRACKS,   0xb8      // translated programs: control tracks of this block (fx_batch.hpp TrackHeader[3] + values), 0 = none
-	.set KA_SIZE,     0xc0
+	.set KA_STAGES,   0xc0      // translated programs cut into stages (fx_xlate.hpp StageDescriptor[nStages], 32 bytes each), 0 = none
+	.set KA_NSTAGES,  0xc8      // wavefronts per workgroup = stages of the program (0 or 1: one wavefront runs all of it)
+	.set KA_SIZE,     0xd0
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
 	.set OOD_TRAM_READ_NEG, 1
@@ -143,6 +145,11 @@
 KNAME:
 #ifdef XLATE
 	s_getpc_b64 s[32:33]                                  // KNAME + 4
+	// a program cut into stages runs in workgroups of several wavefronts - wavefront k = stage k, all of them on the
+	// workgroup's 64 instances (fx_xlate.hpp StageInfo); s52 = stage, v0 = lane either way
+	v_readfirstlane_b32 s52, v0
+	v_and_b32 v0, 63, v0
+	s_lshr_b32 s52, s52, 6
 #endif
 	s_load_dwordx16 s[4:19], s[0:1], KA_STEADY            // steady last rowtab state in out itram xtram
 	s_load_dwordx8  s[40:47], s[0:1], KA_LUT              // lut n npad nload nstore
@@ -190,7 +197,14 @@ KNAME:
 	s_mov_b32 s94, 0                                      // no TRAM read of the first sample is in flight yet
 	s_mov_b32 s95, 0                                      // early TRAM reads: allowed only if the run-once code says so
 #endif
+#ifdef XLATE
+	s_load_dwordx4  s[48:51], s[0:1], KA_INOFF            // inOff[4] (s52..s55: stage, stages, first entry of its store table, -)
+	s_load_dwordx2  s[62:63], s[0:1], KA_STAGES
+	s_load_dword    s53, s[0:1], KA_NSTAGES
+	s_mov_b32 s54, 0
+#else
 	s_load_dwordx8  s[48:55], s[0:1], KA_INOFF            // inOff[4] latchOff[4]
+#endif
 	s_load_dwordx4  s[64:67], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
 	s_load_dwordx2  s[76:77], s[0:1], KA_CURSORROW      // cursorRow noiseRow
 	s_load_dword    s61, s[0:1], KA_LUTX1OFF
@@ -199,6 +213,19 @@ KNAME:
 	s_mov_b32 s47, s65
 	s_mov_b32 s56, s66
 	s_mov_b32 s57, s67
+#ifdef XLATE
+	// staged: this wavefront's code streams and its slice of the store-row table
+	s_cmp_lt_u32 s53, 2
+	s_cbranch_scc1 .Lone_stage
+	s_lshl_b32 s64, s52, 5
+	s_load_dwordx8 s[80:87], s[62:63], s64                // steady {fast, exact}, last {fast, exact}, store first, store count
+	s_waitcnt lgkmcnt(0)
+	s_mov_b64 s[6:7], s[80:81]
+	s_mov_b64 s[42:43], s[82:83]
+	s_mov_b32 s54, s84
+	s_mov_b32 s75, s85
+.Lone_stage:
+#endif
 	// TRAM base of this wave: base + wave * slots * 256
 	s_mul_i32 s62, s2, s46
 	s_mul_hi_u32 s63, s2, s46
@@ -606,6 +633,9 @@ h_endsample_d:
 	s_cbranch_scc1 .Lstore_done
 .Lstore_loop:
 	s_add_u32 s63, s62, s74
+#ifdef XLATE
+	s_add_u32 s63, s63, s54                               // (staged: this stage's rows)
+#endif
 	s_lshl_b32 s63, s63, 2
 	s_load_dword s64, s[72:73], s63
 	s_waitcnt lgkmcnt(0)
@@ -625,6 +655,34 @@ h_endsample_d:
 	s_cmp_lt_u32 s62, s75
 	s_cbranch_scc1 .Lstore_loop
 .Lstore_done:
+#ifdef XLATE
+	// staged: every wavefront has stored the rows it owns; the delay-line cursors, the LFSR words, the out-of-domain flags
+	// and the instruction counter are stage 0's - with the other stages' shadowed-instruction counts and flags, which
+	// come through LDS ([stage][2][lane] from offset 0: the loop is over, tables and packets are dead)
+	s_cmp_lt_u32 s53, 2
+	s_cbranch_scc1 .Lsolo
+	s_lshl_b32 s62, s52, 9
+	v_add_u32 v5, s62, v1
+	ds_write_b32 v5, v15
+	ds_write_b32 v5, v22 offset:256
+	s_waitcnt lgkmcnt(0)
+	s_barrier
+	s_cmp_lg_u32 s52, 0
+	s_cbranch_scc1 .Lstaged_done
+	s_mov_b32 s62, 1
+.Lgather:
+	s_lshl_b32 s63, s62, 9
+	v_add_u32 v5, s63, v1
+	ds_read_b32 v6, v5
+	ds_read_b32 v7, v5 offset:256
+	s_waitcnt lgkmcnt(0)
+	v_add_u32 v15, v15, v6
+	v_or_b32 v22, v22, v7
+	s_add_u32 s62, s62, 1
+	s_cmp_lt_u32 s62, s53
+	s_cbranch_scc1 .Lgather
+.Lsolo:
+#endif
 	s_mul_i32 s66, s76, s60
 	s_mul_hi_u32 s67, s76, s60
 	s_add_u32 s66, s66, s10
@@ -681,6 +739,10 @@ h_endsample_d:
 	global_store_dword v27, v3, s[70:71]
 	global_store_dword v27, v4, s[20:21]
 	s_endpgm
+#ifdef XLATE
+.Lstaged_done:
+	s_endpgm
+#endif
 .Lfunc_end0:
 	.size	KNAME, .Lfunc_end0-KNAME
 
@@ -777,12 +839,16 @@ PNAME:
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 192
+        .size: 208
         .value_kind: by_value
     .group_segment_fixed_size: 0
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 192
+    .kernarg_segment_size: 208
+#ifdef XLATE
+    .max_flat_workgroup_size: 1024
+#else
     .max_flat_workgroup_size: 64
+#endif
     .name: KNAME
     .private_segment_fixed_size: 0
     .sgpr_count: 102
@@ -792,11 +858,11 @@ amdhsa.kernels:
 #ifndef XLATE
   - .args:
       - .offset: 0
-        .size: 192
+        .size: 208
         .value_kind: by_value
     .group_segment_fixed_size: 0
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 192
+    .kernarg_segment_size: 208
     .max_flat_workgroup_size: 64
     .name: PNAME
     .private_segment_fixed_size: 0

@@ -320,6 +320,19 @@ class Emitter {
         if (text_) line("ds_read2_b32 v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], v" + std::to_string(vaddr) +
              (dword0 ? " offset0:" + std::to_string(dword0) : "") + " offset1:" + std::to_string(dword1));
     }
+    void dsReadB32(int vdst, int vaddr, uint32_t offset) {
+        w_.push_back(0xd8000000u | (0x36u << 17) | (offset & 0xffffu));
+        w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
+        ++count_;
+        if (text_) line("ds_read_b32 v" + std::to_string(vdst) + ", v" + std::to_string(vaddr) + (offset ? " offset:" + std::to_string(offset) : ""));
+    }
+    void dsWriteB32(int vaddr, int vdata, uint32_t offset) {
+        w_.push_back(0xd8000000u | (0x0du << 17) | (offset & 0xffffu));
+        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
+        ++count_;
+        if (text_) line("ds_write_b32 v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + (offset ? " offset:" + std::to_string(offset) : ""));
+    }
+    void barrier() { sopp(0x0au, "s_barrier", 0, false); }
     void dsWriteB128(int vaddr, int vdata, uint32_t offset) {
         w_.push_back(0xd8000000u | (0xdfu << 17) | (offset & 0xffffu));
         w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
@@ -350,10 +363,19 @@ class Emitter {
         if (text_) line("v_subbrev_co_u32_e64 v" + std::to_string(v) + ", s[" + std::to_string(sout) + ":" + std::to_string(sout + 1) + "], 0, v" +
                         std::to_string(v) + ", s[" + std::to_string(sin) + ":" + std::to_string(sin + 1) + "]");
     }
-    void waitLgkm0() {
-        w_.push_back(0xbf8cc07fu);
+    // VGPR index mode on: M0 = s<n>, mode 1 = src0 relative (SOPC encoding, the mode nibble in the src1 field)
+    void setGprIdxOn(int sreg, uint32_t mode) {
+        w_.push_back(0xbf000000u | (0x11u << 16) | (mode << 8) | (uint32_t)sreg);
         ++count_;
-        if (text_) line("s_waitcnt lgkmcnt(0)");
+        if (text_) line("s_set_gpr_idx_on s" + std::to_string(sreg) + ", gpr_idx(" + (mode == 1u ? "SRC0" : mode == 2u ? "SRC1" : "DST") + ")");
+    }
+    void waitLgkm0() { waitLgkm(0); }
+    // s_waitcnt lgkmcnt(n), the other counters left alone (n <= 15: bits 11:8)
+    void waitLgkm(int n) {
+        if (n > 15) n = 15;
+        w_.push_back(0xbf8cc07fu | ((uint32_t)n << 8));
+        ++count_;
+        if (text_) line("s_waitcnt lgkmcnt(" + std::to_string(n) + ")");
     }
     // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
     void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
@@ -378,10 +400,10 @@ class Emitter {
         ++count_;
         if (text_) line(std::string(name) + " " + s0.text + ", " + s1.text);
     }
-    void sopp(uint32_t op, const char* name, uint32_t simm, bool showImm) {
+    void sopp(uint32_t op, const char* name, uint32_t simm, bool showImm, const std::string& text = std::string()) {
         w_.push_back(0xbf800000u | (op << 16) | (simm & 0xffffu));
         ++count_;
-        if (text_) line(showImm ? std::string(name) + " " + std::to_string(simm) : std::string(name));
+        if (text_) line(!text.empty() ? text : (showImm ? std::string(name) + " " + std::to_string(simm) : std::string(name)));
     }
 
   private:
@@ -435,13 +457,13 @@ enum : uint32_t {
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_LE_F32 = 0x43, VOPC_CMP_GT_U32 = 0xcc,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6, SOPP_CBRANCH_VCCNZ = 7,
     SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
-    SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
+    SOPC_CMP_GT_I32 = 2, SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
-    SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
+    SOP2_AND_B32 = 0x0c, SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
     VOP2_ADDC_CO_U32 = 0x1c, VOP3B_SUBBREV_CO_U32 = 0x11e,
     VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49, VOPC_CMP_NGT_F32 = 0x4b, VOPC_CMP_NLE_F32 = 0x4c,
-    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOP2_AND_B32 = 0x13, VOP2_LSHRREV_B32 = 0x10, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
+    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOP2_AND_B32 = 0x13, VOP2_XOR_B32 = 0x15, VOP2_LSHRREV_B32 = 0x10, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F32 = 0x1cb, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
@@ -481,6 +503,7 @@ constexpr int kSTrackNext[kMaxTracks] = {28, 29, 69};   // sample index at which
 constexpr int kSTrackPtr[kMaxTracks] = {26, 30, 70};    // s[26:27] / s[30:31] / s[70:71]: address of that value
 constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
+constexpr int kVSend = 30, kVRecv = 31;             // staged programs: lane * 4 + the LDS buffer this step's packets go to / come from
 
 int32_t danePosition(uint32_t bits, bool shifted, int32_t size);  // (defined with the hoist planning below)
 
@@ -523,7 +546,11 @@ class Translator {
         buildConstantPool(records, anyLut);
         // ---- head: this sample's operands that come from memory
         const size_t headWord = e_.words();
-        const int storesPerSample = channels;
+        const StageInfo& G = prog_.stage;
+        const bool staged = G.count > 1;
+        int storesPerSample = 0;
+        for (int c = 0; c < channels; ++c) storesPerSample += (G.storeMask >> c) & 1u;
+        const bool ring = staged && G.inRing >= 0;
         if (H.leadCount > 0) {
             // the leading TRAM reads were issued one sample ago (s94 = 1) or are issued here (first sample of a launch, or
             // a launch whose cursor distance rules the early issue out)
@@ -540,23 +567,47 @@ class Translator {
                 e_.cold(false);
             });
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSPrefetched), imm32(0));
-        } else {
-            e_.waitVmcnt(prog_.tramOpsInline + storesPerSample);  // the PCM input requested one sample ago
+        } else if (!ring) {
+            bool anyInput = false;
+            for (int c = 0; c < channels; ++c) anyInput = anyInput || prog_.inRows[(size_t)c] >= 0;
+            // the PCM input requested one sample ago (a stage without input has nothing to wait for: its PCM stores may take
+            // longer than one of its steps)
+            if (anyInput || !staged) e_.waitVmcnt(prog_.tramOpsInline + storesPerSample);
         }
         for (size_t t = 0; t < prog_.trackRows.size(); ++t)
             if (!trackStep((int)t)) { if (err) *err = err_; return false; }
-        if (fast_) {
-            for (int c = 0; c < channels; ++c)
-                if (prog_.inRows[(size_t)c] >= 0) taintIfNonFinite(kVInput + c);
+        if (staged && !G.recvRows.empty()) {
+            // the rows the previous stage handed over for this sample were read into spare registers one step ago; the
+            // next sample's are requested now and land behind this step's work (StageInfo).  (Younger than that request:
+            // the packet written at the end of the last step, which the next barrier's wait covers.)
+            e_.waitLgkm((int)G.sendRows.size());
+            for (size_t i = 0; i < G.recvRows.size(); ++i) {
+                int v;
+                if (!row((uint32_t)G.recvRows[i], &v)) { if (err) *err = err_; return false; }
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(v), vreg(G.recvTmp + (int)i));
+            }
+            if (fast_)
+                for (int r : G.recvRows) taintCheckRow(vrow((uint32_t)r));
+            if (!isLast_) stageRequest();
+        }
+        if (ring) {
+            if (!inputFromRing(storesPerSample)) { if (err) *err = err_; return false; }
+        } else {
+            if (fast_)
+                for (int c = 0; c < channels; ++c)
+                    if (prog_.inRows[(size_t)c] >= 0) taintIfNonFinite(kVInput + c);
+            for (int c = 0; c < channels; ++c) {
+                int v;
+                if (prog_.inRows[(size_t)c] < 0) continue;
+                if (!row((uint32_t)prog_.inRows[(size_t)c], &v)) { if (err) *err = err_; return false; }
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(v), vreg(kVInput + c));
+            }
+            bool anyInput = false;
+            for (int c = 0; c < channels; ++c) anyInput = anyInput || prog_.inRows[(size_t)c] >= 0;
+            if (!isLast_ && (anyInput || !staged)) pcmAccess(true, kSPcmIn, true);  // next sample's input; it lands behind this sample's program
+        }
+        if (fast_)
             for (int k = 0; k < H.leadCount; ++k) taintCheckRow(vrow(records[(size_t)k].w[5]));
-        }
-        for (int c = 0; c < channels; ++c) {
-            int v;
-            if (prog_.inRows[(size_t)c] < 0) continue;
-            if (!row((uint32_t)prog_.inRows[(size_t)c], &v)) { if (err) *err = err_; return false; }
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(v), vreg(kVInput + c));
-        }
-        if (!isLast_) pcmAccess(true, kSPcmIn, true);  // next sample's input; it lands behind this sample's program
         if (usesSkipCounter) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVNumSkip), imm32(0));  // numSkip is local to process() (FX8010.cpp:1030)
         index_ = records.size();
         returns_[syncIndex(0)] = base_ + (uint32_t)e_.bytes();
@@ -598,8 +649,34 @@ class Translator {
         // ---- PCM out, next sample
         plainMode();
         e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
-        pcmAccess(false, kSPcmOut, false);
+        if (staged) {
+            // hand this sample's live rows to the next stage; ONE barrier per step on every path through a sample (all
+            // wavefronts of the workgroup execute the same number of them).  The wait in front of it covers LAST step's writes
+            // and this step's request - everything but the writes just issued.
+            for (size_t i = 0; i < G.sendRows.size(); ++i) {
+                int v;
+                if (!row((uint32_t)G.sendRows[i], &v)) { if (err) *err = err_; return false; }
+                e_.dsWriteB32(kVSend, v, G.bufBase + G.sendOff + 256u * (uint32_t)i);
+            }
+            if (!G.sendRows.empty()) ringStep(kVSend);
+            // ... every group-th sample (the same samples in every wavefront: they all count from 0)
+            if (G.group > 1) {
+                e_.sop2(SOP2_AND_B32, "s_and_b32", sreg(kSTemp), sreg(kSSample), imm32((uint32_t)G.group - 1u));
+                e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp), imm32((uint32_t)G.group - 1u));
+                Emitter::Fixup within = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+                if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
+                e_.barrier();
+                e_.bind(within);
+            } else {
+                if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
+                e_.barrier();
+            }
+        }
+        if (storesPerSample > 0) pcmAccess(false, kSPcmOut, false);
         for (int q : {kSPcmIn, kSPcmOut}) {
+            bool anyInput = false;
+            for (int c = 0; c < channels; ++c) anyInput = anyInput || prog_.inRows[(size_t)c] >= 0;
+            if (staged && ((q == kSPcmIn && !anyInput) || (q == kSPcmOut && storesPerSample == 0))) continue;  // a stage that does not touch that stream
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(q), sreg(q), sreg(kSSampleBytes));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(q + 1), sreg(q + 1), imm32(0));
         }
@@ -618,6 +695,10 @@ class Translator {
                 for (int c = 0; c < 4; ++c) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVCursor + c), sreg(kSCursor + c));
                 e_.vop2(VOP2_OR_B32, "v_or_b32_e32", kVOod, sreg(kSOod), kVOod);
             }
+            if (staged) {
+                if (!G.sendRows.empty()) e_.waitLgkm0();                   // (the last packet: complete before the next barrier)
+                for (int k = 0; k < kStageDepth * (G.count - 1 - G.index); ++k) e_.barrier();  // the later stages are still at work: their steps' barriers
+            }
             e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSEndSample));  // the template's epilogue
         }
 
@@ -629,6 +710,18 @@ class Translator {
             // every TRAM instruction runs on all lanes: the four cursors are the same in every lane, keep them in SGPRs
             for (int c = 0; c < 4; ++c) e_.vop1(VOP1_READFIRSTLANE, "v_readfirstlane_b32", sreg(kSCursor + c), vreg(kVCursor + c));
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSOod), imm32(0));
+        }
+        if (staged) {
+            // stage k starts 3k steps late; packet s lives in buffer s & 3.  The step in front of its first sample requests
+            // that sample's rows.
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVSend), vreg(kVLane4));
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVRecv), vreg(kVLane4));
+            for (int k = 0; k + 1 < kStageDepth * G.index; ++k) e_.barrier();
+            if (G.index > 0) {
+                if (!G.recvRows.empty()) stageRequest();
+                e_.barrier();
+            }
+            if (ring) inputBurst(0, true);
         }
         for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
         // (inline constants where the bit pattern has one, as the assembler would choose: the listing must re-assemble to the same bytes)
@@ -691,7 +784,7 @@ class Translator {
         for (int c = 0; c < channels; ++c) {
             if (load) {
                 if (prog_.inRows[(size_t)c] >= 0) e_.global(GLOBAL_LOAD_DWORD, true, kVInput + c, kVInstance4, kSAddr, streaming(4));
-            } else {
+            } else if ((prog_.stage.storeMask >> c) & 1u) {
                 e_.global(GLOBAL_STORE_DWORD, false, vrow((uint32_t)prog_.latchRows[(size_t)c]), kVInstance4, kSAddr, streaming(8));
             }
             if (c + 1 < channels) {
@@ -700,6 +793,97 @@ class Translator {
             }
         }
         e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+    }
+
+    // ---- staged programs (fx_xlate.hpp StageInfo)
+    // v = lane * 4 + ((sample + 1) & 3) * stride: the next buffer of the ring
+    void ringStep(int v) {
+        const StageInfo& G = prog_.stage;
+        e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", v, imm32(G.bufStride), v);
+        e_.vop2(VOP2_AND_B32, "v_and_b32_e32", v, imm32(4u * (uint32_t)G.group * G.bufStride - 1u), v);
+    }
+    // request the rows of the NEXT sample this stage will work on (the previous stage wrote them two steps ago)
+    void stageRequest() {
+        const StageInfo& G = prog_.stage;
+        for (size_t i = 0; i < G.recvRows.size(); ++i) e_.dsReadB32(G.recvTmp + (int)i, kVRecv, G.bufBase + G.recvOff + 256u * (uint32_t)i);
+        ringStep(kVRecv);
+    }
+    // PCM input in bursts of eight samples (StageInfo::inRing).  inputBurst(first, initial): loads of samples s + first ..
+    // s + first + 7 (s = the current sample, s3) into the "next" half, each only if it exists; the initial one is waited for.
+    void inputBurst(int first, bool initial) {
+        const int channels = (int)prog_.latchRows.size();
+        const StageInfo& G = prog_.stage;
+        e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSTemp + 2), sreg(kSNumSamples), sreg(kSSample));   // samples from s on
+        if (first) {
+            e_.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSTemp + 2), sreg(kSTemp + 2), imm32((uint32_t)first));
+            e_.sop2(SOP2_LSHL_B32, "s_lshl_b32", sreg(kSTemp + 3), sreg(kSSampleBytes), imm32(3));
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSPcmIn), sreg(kSTemp + 3));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSPcmIn + 1), imm32(0));
+        } else {
+            e_.sop1(SOP1_MOV_B64, "s_mov_b64", sreg64(kSAddr), sreg64(kSPcmIn));
+        }
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), sreg64(kSValidLanes));
+        std::vector<Emitter::Fixup> done;
+        for (int j = 0; j < kInputBurst; ++j) {
+            e_.sopc(SOPC_CMP_GT_I32, "s_cmp_gt_i32", sreg(kSTemp + 2), imm32((uint32_t)j));
+            done.push_back(e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0"));
+            e_.sop1(SOP1_MOV_B64, "s_mov_b64", sreg64(kSTemp + 4), sreg64(kSAddr));
+            int used = 0;
+            for (int c = 0; c < channels; ++c) {
+                if (prog_.inRows[(size_t)c] >= 0) {
+                    e_.global(GLOBAL_LOAD_DWORD, true, G.inRing + 2 * kInputBurst * used + kInputBurst + j, kVInstance4, kSTemp + 4, streaming(4));
+                    ++used;
+                }
+                if (c + 1 < channels) {
+                    e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp + 4), sreg(kSTemp + 4), sreg(kSChannelBytes));
+                    e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSTemp + 5), sreg(kSTemp + 5), imm32(0));
+                }
+            }
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSAddr), sreg(kSSampleBytes));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSAddr + 1), imm32(0));
+        }
+        for (const Emitter::Fixup& f : done) e_.bind(f);
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+        if (initial) e_.waitVmcnt(0);
+    }
+    // head of a sample: at the first sample of every eight, the burst requested eight samples ago becomes the current one and
+    // the next is requested; then this sample's value is picked from the current eight (VGPR index mode, src0 relative)
+    bool inputFromRing(int storesPerSample) {
+        const int channels = (int)prog_.latchRows.size();
+        const StageInfo& G = prog_.stage;
+        plainMode();
+        e_.sop2(SOP2_AND_B32, "s_and_b32", sreg(kSTemp), sreg(kSSample), imm32(kInputBurst - 1));
+        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp), imm32(0));
+        // (one sample in eight: behind the loop)
+        defer(e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1"), [this, storesPerSample, channels]() {
+            const StageInfo& g = prog_.stage;
+            e_.cold(true);
+            e_.waitVmcnt(std::min(63, kInputBurst * storesPerSample));   // younger than that burst: eight samples' PCM stores
+            int n = 0;
+            for (int c = 0; c < channels; ++c) {
+                if (prog_.inRows[(size_t)c] < 0) continue;
+                for (int j = 0; j < kInputBurst; ++j)
+                    e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(g.inRing + 2 * kInputBurst * n + j), vreg(g.inRing + 2 * kInputBurst * n + kInputBurst + j));
+                ++n;
+            }
+            if (!isLast_) inputBurst(kInputBurst, false);
+            e_.sop2(SOP2_AND_B32, "s_and_b32", sreg(kSTemp), sreg(kSSample), imm32(kInputBurst - 1));  // (the burst code used the scratch register)
+            e_.cold(false);
+        });
+        e_.setGprIdxOn(kSTemp, 1u);
+        int used = 0;
+        for (int c = 0; c < channels; ++c) {
+            int v;
+            if (prog_.inRows[(size_t)c] < 0) continue;
+            if (!row((uint32_t)prog_.inRows[(size_t)c], &v)) return false;
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(v), vreg(G.inRing + 2 * kInputBurst * used));
+            ++used;
+        }
+        e_.sopp(SOPP_IDX_OFF, "s_set_gpr_idx_off", 0, false);
+        if (fast_)
+            for (int c = 0; c < channels; ++c)
+                if (prog_.inRows[(size_t)c] >= 0) taintIfNonFinite(vrow((uint32_t)prog_.inRows[(size_t)c]));
+        return true;
     }
 
     // ---- control tracks (fx_xlate.hpp TrackHeader): scalar bookkeeping, one vector move / load per change
@@ -2303,10 +2487,26 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
             for (uint32_t c : {kLutGuess.scale, kLutGuess.bias, kLutGuess.magic, kLutGuess.mask}) pooledProgram.vconst.emplace_back(c, --v);
         }
     }
+    // ... a staged program's spare registers for the next sample's packet and for its PCM input bursts (StageInfo)
+    int stageTop = tmpl.vgprs - (int)pooledProgram.vconst.size();
+    if (program.stage.count > 1) {
+        const int firstFree = kRegFileBase + (int)program.wildRow.size();
+        const int need = (int)program.stage.recvRows.size();
+        if (stageTop - need < firstFree) { if (err) *err = "no spare VGPRs for the stage's packets in this build"; return false; }
+        stageTop -= need;
+        pooledProgram.stage.recvTmp = stageTop;
+        if (program.stage.inRing == -2) {
+            int used = 0;
+            for (int r : program.inRows) used += r >= 0;
+            const int ringRegs = 2 * kInputBurst * used;
+            pooledProgram.stage.inRing = -1;
+            if (used > 0 && stageTop - ringRegs >= firstFree) { stageTop -= ringRegs; pooledProgram.stage.inRing = stageTop; }
+        }
+    }
     // ... and the product cache of the fast streams (Translator::product): per entry an even-aligned pair and a single
     {
         const char* knob = std::getenv("FX_XLATE_CSE");  // diagnostics: number of entries (0 = none)
-        const int top = tmpl.vgprs - (int)pooledProgram.vconst.size();
+        const int top = stageTop;
         const int base = (kRegFileBase + (int)program.wildRow.size() + 1) & ~1;
         int entries = std::min(kProductCacheEntries, knob ? std::atoi(knob) : kProductCacheEntries);
         while (entries > 0 && base + 3 * entries > top) --entries;
@@ -2369,6 +2569,344 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
         if (err) *err = "translated program larger than the code hole of the template";
         return false;
     }
+    return true;
+}
+
+// ---- stage pipelining (fx_xlate.hpp StageInfo) ---------------------------------------------------------------------
+namespace {
+// register-file rows a record reads and writes (uniform operands are not rows; the X word of LOG / EXP is a table)
+struct Access { uint32_t reads[3]; int nReads = 0; int write = -1; bool ccr = false, tram = false, noise = false; };
+Access accessOf(const MicroOp& r) {
+    Access a;
+    const uint32_t slot = r.w[0];
+    if (slot == AS_ENDSAMPLE || slot == AS_NOP || slot == AS_PRED || slot == AS_UNPRED) return a;
+    const bool hot = slot >= AS_MACS && slot < (uint32_t)kAsmSlots;
+    const uint32_t kind = hot ? ((slot - AS_MACS) % 16) / 2 : (r.w[6] & 7u);
+    auto read = [&](uint32_t word, bool uniform) { if (!uniform) a.reads[a.nReads++] = word; };
+    if (slot == AS_SKIP) {
+        a.reads[a.nReads++] = 0;  // the CCR row
+        read(r.w[3], kind & 2u);
+        read(r.w[4], kind & 4u);
+        return a;
+    }
+    if (slot == AS_NOISE) { a.noise = true; a.write = (int)r.w[5]; return a; }
+    if (slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
+        a.tram = true;
+        read(r.w[4], kind & 4u);
+        if (slot == AS_TRAM_IR || slot == AS_TRAM_XR) a.write = (int)r.w[5];
+        else read(r.w[2], kind & 1u);
+        return a;
+    }
+    if (hot && kind == 7u) { a.write = (int)r.w[5]; a.ccr = (slot - AS_MACS) & 1u; return a; }  // folded on the host
+    read(r.w[2], kind & 1u);
+    if (slot != AS_LUT && slot != AS_MOV) {
+        read(r.w[3], kind & 2u);
+        read(r.w[4], kind & 4u);
+    }
+    a.write = (int)r.w[5];
+    a.ccr = hot ? ((slot - AS_MACS) & 1u) != 0 : ((r.w[6] >> 3) & 1u) != 0;
+    return a;
+}
+// a rough count of the vector instructions a record costs (for balancing the stages only)
+int costOf(const MicroOp& r) {
+    const uint32_t slot = r.w[0];
+    if (slot == AS_ENDSAMPLE || slot == AS_NOP || slot == AS_UNPRED) return 0;
+    if (slot == AS_PRED) return 6;
+    if (slot == AS_SKIP) return 3;
+    if (slot == AS_MOV) return 1;
+    if (slot == AS_LUT) return 16;
+    if (slot == AS_NOISE || slot == AS_LIMIT || slot == AS_LIMITN) return 4;
+    if (slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) return 2;
+    if (slot < AS_MACS) return 12;  // wrap-around family, logic, TSTNEG
+    const uint32_t rel = slot - AS_MACS, family = rel / 16;
+    return (family == 3 ? 7 : 3) + ((rel & 1u) ? 12 : 0);
+}
+}  // namespace
+
+StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& prog, int nRows, int wanted) {
+    StagePlan P;
+    auto no = [&](const char* why) { P.why = why; P.cuts.clear(); P.live.clear(); return P; };
+    if (wanted < 2) return no("one stage asked for");
+    if (!prog.trackRows.empty()) return no("control tracks");
+    if (prog.tramDane) return no("DANE delay-line model");
+    if (steadyRecords.size() != lastRecords.size()) return no("streams of different length");
+    size_t n = 0;
+    while (n < steadyRecords.size() && steadyRecords[n].w[0] != AS_ENDSAMPLE) ++n;
+    if (n < 4 || n >= steadyRecords.size() || lastRecords[n].w[0] != AS_ENDSAMPLE) return no("too short");
+    auto shape = [](const MicroOp& r) { return r.w[0] >= AS_MACS && r.w[0] < (uint32_t)kAsmSlots ? (r.w[0] & ~1u) : r.w[0]; };  // (hot slots: without the CCR bit)
+    for (size_t i = 0; i < n; ++i)
+        if (shape(steadyRecords[i]) != shape(lastRecords[i]) || steadyRecords[i].w[5] != lastRecords[i].w[5]) return no("streams differ in structure");
+    const int rows = std::max(nRows, 1);
+    // boundary b (1 .. n-1) = a cut between record b-1 and record b
+    std::vector<uint8_t> allowed(n + 1, 1);
+    allowed[0] = 0;
+    allowed[n] = 0;
+    std::vector<std::vector<int>> liveAt(n + 1);
+    auto forbid = [&](size_t lo, size_t hi) {  // no cut b with lo < b <= hi
+        for (size_t b = lo + 1; b <= hi && b <= n; ++b) allowed[b] = 0;
+    };
+    auto addLive = [&](size_t lo, size_t hi, int row) {  // row is live at every cut b with lo < b <= hi
+        for (size_t b = lo + 1; b <= hi && b <= n; ++b)
+            if (std::find(liveAt[b].begin(), liveAt[b].end(), row) == liveAt[b].end()) liveAt[b].push_back(row);
+    };
+    // structure: a SKIP, the instruction in front of it (fused predicate) and its shadow up to the UNPRED stay together;
+    // delay-line and noise instructions belong to stage 0
+    {
+        bool open = false;
+        size_t from = 0, lastOwned = 0;
+        bool anyOwned = false;
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t slot = steadyRecords[i].w[0];
+            if (slot == AS_SKIP && !open) { open = true; from = i > 0 ? i - 1 : 0; }
+            if (slot == AS_PRED && !open) { open = true; from = i > 0 ? i - 1 : 0; }
+            if (slot == AS_UNPRED && open) { forbid(from, i); open = false; }
+            const Access a = accessOf(steadyRecords[i]);
+            if (a.tram || a.noise) { lastOwned = i; anyOwned = true; }
+        }
+        if (open) forbid(from, n);
+        if (anyOwned) forbid(0, lastOwned + 1 > n ? n : lastOwned + 1);
+    }
+    std::vector<uint8_t> isInput((size_t)rows, 0);
+    for (int r : prog.inRows)
+        if (r >= 0 && r < rows) isInput[(size_t)r] = 1;
+    for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords}) {
+        // per row: its writes (position, conditional?) in program order
+        std::vector<std::vector<std::pair<size_t, bool>>> writes((size_t)rows);
+        bool shadow = false;
+        std::vector<uint8_t> shadowed(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t slot = (*recs)[i].w[0];
+            if (slot == AS_PRED) shadow = true;
+            else if (slot == AS_UNPRED) shadow = false;
+            shadowed[i] = shadow;
+            const Access a = accessOf((*recs)[i]);
+            if (a.write >= 0 && a.write < rows) writes[(size_t)a.write].emplace_back(i, shadow);
+            if (a.ccr) writes[0].emplace_back(i, shadow);
+        }
+        for (size_t i = 0; i < n; ++i) {
+            const Access a = accessOf((*recs)[i]);
+            for (int k = 0; k < a.nReads; ++k) {
+                const uint32_t R = a.reads[k];
+                if (R >= (uint32_t)rows) return no("operand row out of range");
+                if (isInput[R]) { addLive(0, i, (int)R); continue; }  // stage 0 loads the PCM input; it travels with the packets
+                const auto& W = writes[R];
+                // walk back from the read: conditional writes, down to the nearest unconditional one
+                size_t lowest = i;  // the earliest position the value can come from (same sample)
+                bool found = false;
+                for (size_t q = W.size(); q-- > 0;) {
+                    if (W[q].first >= i) continue;
+                    lowest = W[q].first;
+                    if (!W[q].second) { found = true; break; }
+                }
+                if (found) { addLive(lowest, i, (int)R); continue; }
+                // ... the value (also) comes from the previous sample: every candidate definition - the conditional ones of
+                // this sample, and the previous sample's from the end of the program back to its last unconditional one -
+                // must be in the reader's stage
+                size_t highest = i;
+                for (size_t q = W.size(); q-- > 0;) {
+                    if (W[q].first < i) break;
+                    highest = std::max(highest, W[q].first);
+                    if (!W[q].second) break;
+                }
+                if (!W.empty()) {
+                    size_t top = i;
+                    for (const auto& w : W)
+                        if (w.first >= i) top = std::max(top, w.first);
+                    highest = top;  // (conservative: up to the last write of the row)
+                }
+                forbid(lowest, i);
+                forbid(i, highest);
+            }
+        }
+        // the stage of a row's LAST write stores it (state rows at the end of a block, PCM latch rows every sample): if that
+        // write is conditional the stage needs the value it replaces - from the nearest unconditional write in front of it, or,
+        // when there is none in the sample, from the previous sample: then all writes of the row stay in one stage
+        for (int R = 0; R < rows; ++R) {
+            const auto& W = writes[(size_t)R];
+            if (W.size() < 2 || !W.back().second) continue;
+            size_t q = W.size() - 1;
+            while (q > 0 && W[q].second) --q;
+            if (W[q].second) forbid(W.front().first, W.back().first);
+            else addLive(W[q].first, W.back().first, R);
+        }
+    }
+    // balance: cumulative cost, cuts at allowed boundaries nearest to the ideal positions
+    std::vector<int> cum(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) cum[i + 1] = cum[i] + costOf(steadyRecords[i]);
+    const int total = cum[n];
+    if (total < 16 * wanted) wanted = std::max(1, total / 16);
+    if (wanted < 2) return no("too little work per stage");
+    std::vector<int> cuts;
+    for (int k = 1; k < wanted; ++k) {
+        const double ideal = (double)total * k / wanted;
+        int best = -1;
+        double bestDist = 1e30;
+        for (size_t b = (cuts.empty() ? 1 : (size_t)cuts.back() + 1); b < n; ++b) {
+            if (!allowed[b]) continue;
+            const double d = std::fabs((double)cum[b] - ideal);
+            if (d < bestDist) { bestDist = d; best = (int)b; }
+        }
+        if (best < 0) break;
+        // (a cut that leaves less than a quarter of a stage's share on either side is not worth a barrier)
+        const int before = cum[(size_t)best] - (cuts.empty() ? 0 : cum[(size_t)cuts.back()]);
+        if (before * 4 * wanted < total) continue;
+        cuts.push_back(best);
+    }
+    while (!cuts.empty() && (total - cum[(size_t)cuts.back()]) * 4 * wanted < total) cuts.pop_back();
+    if (std::getenv("FX_STAGES_DEBUG")) {
+        std::string line;
+        for (size_t b = 0; b <= n; ++b) line += allowed[b] ? '+' : '.';
+        std::fprintf(stderr, "planStages: %zu records, total cost %d, boundaries %s\n", n, total, line.c_str());
+    }
+    if (cuts.empty()) return no("no legal cut");
+    P.cuts = cuts;
+    for (int b : cuts) {
+        std::vector<int> l = liveAt[(size_t)b];
+        std::sort(l.begin(), l.end());
+        P.live.push_back(l);
+    }
+    const int K = (int)cuts.size() + 1;
+    auto stageOf = [&](size_t pos) { int st = 0; for (int b : cuts) if ((int)pos >= b) ++st; return st; };
+    // who stores what at the end of a block: the stage of the row's last write (the last stream decides: it makes every CCR
+    // write live); rows no record writes - PCM input rows, untouched state - stay with stage 0, which loads every input channel
+    P.storeStage.assign((size_t)rows, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const Access a = accessOf(lastRecords[i]);
+        if (a.write >= 0 && a.write < rows) P.storeStage[(size_t)a.write] = stageOf(i);
+        if (a.ccr) P.storeStage[0] = stageOf(i);
+    }
+    P.pcmStage.assign(prog.latchRows.size(), 0);
+    for (size_t c = 0; c < prog.latchRows.size(); ++c)
+        if (prog.latchRows[c] >= 0 && prog.latchRows[c] < rows) P.pcmStage[c] = P.storeStage[(size_t)prog.latchRows[c]];
+    P.inMask.assign((size_t)K, 0);
+    for (size_t c = 0; c < prog.inRows.size(); ++c)
+        if (prog.inRows[c] >= 0) P.inMask[0] |= 1u << c;
+    return P;
+}
+
+namespace {
+// the records of one stage as a stream of its own (ENDSAMPLE and the fetch pad behind it)
+std::vector<MicroOp> stageRecords(const std::vector<MicroOp>& all, size_t from, size_t to) {
+    std::vector<MicroOp> out(all.begin() + (long)from, all.begin() + (long)to);
+    MicroOp end{};
+    end.w[0] = AS_ENDSAMPLE;
+    out.push_back(end);
+    MicroOp nop{};
+    nop.w[0] = AS_NOP;
+    for (int k = 0; k < 4; ++k) out.push_back(nop);
+    return out;
+}
+}  // namespace
+
+bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
+                      const XlateProgram& program, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* codeOut,
+                      std::vector<std::string>* listingOut, std::string* err, uint32_t ldsBudget) {
+    const int K = (int)plan.cuts.size() + 1;
+    if (K < 2) { if (err) *err = "not a staged plan"; return false; }
+    size_t n = 0;
+    while (n < steadyRecords.size() && steadyRecords[n].w[0] != AS_ENDSAMPLE) ++n;
+    // LDS: the LOG/EXP tables (shared by all stages: every wavefront stages the same bytes), then two buffers of packets
+    const uint32_t tableBytes = program.lutTables.empty() ? 0u : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
+    std::vector<uint32_t> cutOff;
+    uint32_t bufStride = 0;
+    for (const auto& l : plan.live) { cutOff.push_back(bufStride); bufStride += 256u * (uint32_t)l.size(); }
+    // kStageBuffers buffers; the generated code steps through them with an add and an AND: the stride is a power of two
+    {
+        uint32_t pow2 = 256u;
+        while (pow2 < bufStride) pow2 <<= 1;
+        bufStride = pow2;
+    }
+    const uint32_t bufBase = (std::max(tableBytes, (uint32_t)K * 512u) + 255u) & ~255u;  // (the template's epilogue uses the first K * 512 bytes once the loop is over)
+    int group = kStageGroupMax;
+    while (group > 1 && bufBase + 4u * (uint32_t)group * bufStride > ldsBudget) group /= 2;
+    if (bufBase + bufStride > 0xff00u || bufBase + 4u * (uint32_t)group * bufStride > std::min(ldsBudget, 160u * 1024u)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
+    std::vector<std::vector<uint32_t>> code((size_t)K * 4 + 1);
+    std::vector<std::string> listing((size_t)K * 4 + 1);
+    uint32_t at = tmpl.holeOff;
+    out->stages = K;
+    out->stageDesc.assign((size_t)K, StageDescriptor{});
+    out->stageStoreRows.assign((size_t)K, {});
+    out->plan = plan;
+    out->wildRow = program.wildRow;
+    out->steady = XlateStats();
+    out->last = XlateStats();
+    for (size_t r = 0; r < plan.storeStage.size(); ++r) out->stageStoreRows[(size_t)plan.storeStage[r]].push_back((int)r);
+    int worstValu = -1;
+    for (int k = 0; k < K; ++k) {
+        const size_t from = k == 0 ? 0 : (size_t)plan.cuts[(size_t)k - 1], to = k + 1 == K ? n : (size_t)plan.cuts[(size_t)k];
+        const std::vector<MicroOp> steady = stageRecords(steadyRecords, from, to), last = stageRecords(lastRecords, from, to);
+        // the stage as a program of its own: its delay-line reads may lead (stage 0 owns all of them), its PCM channels; tables,
+        // row classes and the LDS layout are the whole program's
+        std::vector<int> inRows = program.inRows;
+        for (size_t c = 0; c < inRows.size(); ++c)
+            if (!((plan.inMask[(size_t)k] >> c) & 1u)) inRows[c] = -1;
+        XlateProgram p = xlateProgramOf(steady, last, program.iSize, program.xSize, (int)program.wildRow.size(), inRows, program.latchRows);
+        p.lutTables = program.lutTables;
+        p.wildRow = program.wildRow;
+        p.tramStreaming = program.tramStreaming;
+        p.stage.index = k;
+        p.stage.count = K;
+        p.stage.bufBase = bufBase;
+        p.stage.bufStride = bufStride;
+        p.stage.group = group;
+        if (k > 0) { p.stage.recvRows = plan.live[(size_t)k - 1]; p.stage.recvOff = cutOff[(size_t)k - 1]; }
+        if (k + 1 < K) { p.stage.sendRows = plan.live[(size_t)k]; p.stage.sendOff = cutOff[(size_t)k]; }
+        p.stage.storeMask = 0;
+        for (size_t c = 0; c < plan.pcmStage.size(); ++c)
+            if (plan.pcmStage[c] == k) p.stage.storeMask |= 1u << c;
+        // steps far shorter than a trip to memory: PCM input in bursts (a stage with delay lines keeps the loop's own prefetch)
+        p.stage.inRing = (p.tramOpsInline == 0 && p.hoist.leadCount == 0 && !std::getenv("FX_STAGES_NO_RING")) ? -2 : -1;
+        XlateImage one;
+        std::vector<uint32_t> c5[5];
+        std::string t5[5];
+        // planXlate lays its streams out from the hole's start; here they follow the previous stage's
+        XlateTemplate shifted = tmpl;
+        shifted.holeOff = at;
+        shifted.holeBytes = tmpl.holeBytes - (at - tmpl.holeOff);
+        if (!planXlate(steady, last, shifted, p, &one, c5, listingOut ? t5 : nullptr, err)) return false;
+        // (its run-once code is dropped: one copy for the whole program follows the last stage)
+        uint32_t end = at;
+        for (int q = 0; q < 4; ++q) {
+            code[(size_t)k * 4 + (size_t)q] = c5[q];
+            listing[(size_t)k * 4 + (size_t)q] = t5[q];
+            if (!c5[q].empty()) end = std::max(end, one.base[q] + align64((uint32_t)c5[q].size() * 4));
+        }
+        StageDescriptor& d = out->stageDesc[(size_t)k];
+        d.steadyFast = one.steadyFastOff;
+        d.steadyExact = one.steadyOff;
+        d.lastFast = one.lastFastOff;
+        d.lastExact = one.lastOff;
+        for (int q = 0; q < 4; ++q) out->base[q] = one.base[q];  // (of the last stage: diagnostics only)
+        out->stageBases.push_back({one.base[0], one.base[1], one.base[2], one.base[3]});
+        if (one.steady.valu > worstValu) { worstValu = one.steady.valu; out->steady = one.steady; out->last = one.last; }
+        out->vgprConstants = one.vgprConstants;
+        at = end;
+    }
+    // the run-once code: tables of the whole program, the hoist decision of stage 0
+    out->initOff = 0;
+    out->ldsBytes = bufBase + 4u * (uint32_t)group * bufStride;
+    {
+        XlateProgram initProg = program;
+        const std::vector<MicroOp> s0 = stageRecords(steadyRecords, 0, (size_t)plan.cuts[0]), l0 = stageRecords(lastRecords, 0, (size_t)plan.cuts[0]);
+        std::vector<int> inRows0 = program.inRows;
+        initProg.hoist = xlateProgramOf(s0, l0, program.iSize, program.xSize, (int)program.wildRow.size(), inRows0, program.latchRows).hoist;
+        if (!initProg.lutTables.empty() || initProg.hoist.leadCount > 0) {
+            emitInit(initProg, &code[(size_t)K * 4], listingOut ? &listing[(size_t)K * 4] : nullptr);
+            out->initOff = at;
+            at += align64((uint32_t)code[(size_t)K * 4].size() * 4);
+        }
+    }
+    out->codeBytes = at - tmpl.holeOff;
+    if (out->codeBytes + 4 > tmpl.holeBytes) { if (err) *err = "translated program larger than the code hole of the template"; return false; }
+    out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
+    for (int k = 0; k < K; ++k)
+        for (int q = 0; q < 4; ++q) {
+            const std::vector<uint32_t>& c = code[(size_t)k * 4 + (size_t)q];
+            if (!c.empty()) std::memcpy(out->elf.data() + tmpl.holeFileOff + (out->stageBases[(size_t)k][(size_t)q] - tmpl.holeOff), c.data(), c.size() * 4);
+        }
+    if (out->initOff) std::memcpy(out->elf.data() + tmpl.holeFileOff + (out->initOff - tmpl.holeOff), code[(size_t)K * 4].data(), code[(size_t)K * 4].size() * 4);
+    if (codeOut) *codeOut = code;
+    if (listingOut) *listingOut = listing;
     return true;
 }
 

@@ -14,6 +14,7 @@
 // by hand and nothing is executed that did not go through the code-object loader.
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -68,8 +69,48 @@ struct TrackHeader {
     uint32_t strideBytes;  // 4: one value for all instances (scalar load); else bytes between steps of a per-instance schedule
 };
 
+// A program pipelined over the wavefronts of a workgroup ("stages", SURVEY.md section 8d: small batches leave the machine
+// empty - 4096 instances are 64 wavefronts on 1024 SIMDs - and a lone wavefront issues one instruction every ~4.5 clocks
+// whatever it is).  The instances offer no more lanes, but a program whose state registers are each read and written by one
+// stretch of it can be CUT into K contiguous stages: wavefront k of a K-wavefront workgroup runs stage k, all K on the same 64
+// instances, stage k working on sample T - k at step T; the values that are live across a cut travel through double-buffered
+// LDS rows, one s_barrier per step.  Every wavefront keeps a full private copy of the register file in its VGPRs; a row is
+// stored at the end of the block by the stage that writes it last.  planStages() decides where cuts are legal:
+//   * a read whose reaching definition is the PREVIOUS sample's must sit in the stage of that definition (a later stage's
+//     result of sample t-1 does not exist yet when an earlier stage starts sample t);
+//   * a SKIP, its shadow and the instruction it is fused with stay in one stage; so do all delay-line and noise instructions
+//     (stage 0: cursors and LFSR words are per-wavefront state), and programs with control tracks or the DANE model are not cut.
+struct StageInfo {
+    int index = 0, count = 1;             // this stream is stage `index` of `count`; count == 1: the whole program, no pipeline
+    std::vector<int> recvRows, sendRows;  // rows received from stage index-1 at the head / handed to stage index+1 at the tail
+    uint32_t recvOff = 0, sendOff = 0;    // LDS byte offset of those packets inside a buffer (row i at +256 i)
+    uint32_t bufBase = 0, bufStride = 0;  // the 4 * group buffers: bufBase + (sample mod (4 * group)) * bufStride (stride a power of two)
+    uint32_t storeMask = ~0u;             // channels whose PCM output this stage stores
+    int group = 1;                        // samples between two barriers (a power of two); the ring has 4 * group buffers
+    // Latencies stay off the step (a step = the `group` samples between two barriers): stage k runs 3k steps behind stage 0.
+    // A packet written during step T is waited for at the end of step T+1 (s_waitcnt in front of that step's barrier: long
+    // complete by then) and may be READ from step T+2 on; the consumer works on it in step T+3 and requests every packet one
+    // SAMPLE ahead, into spare VGPRs (recvTmp ..), from where the next sample's head moves it into the rows.
+    int recvTmp = -1;                     // first of recvRows.size() spare VGPRs
+    // PCM input of a stage whose steps are shorter than a trip to memory: 8 samples per burst, two bursts in VGPRs (per used
+    // channel inRing .. +7 = the samples being consumed, +8 .. +15 = the next eight, in flight), selected by VGPR index mode
+    int inRing = -1;                      // first VGPR of the ring, -1 = the one-sample-ahead prefetch of the unstaged loop
+};
+// `group` samples between two barriers: a wavefront meets the others only every fourth sample (a barrier costs a lone
+// wavefront ~200 clocks, arrival skew included); a packet is consumed at most three barrier intervals after it was written
+constexpr int kStageDepth = 3, kStageGroupMax = 8, kInputBurst = 8;   // (group: StageInfo::group, the largest of 8, 4, 2, 1 whose ring fits the LDS)
+struct StagePlan {
+    std::vector<int> cuts;                    // record index at which stage k+1 begins (size K-1, ascending); empty: not cut
+    std::vector<std::vector<int>> live;       // live[c]: rows handed over at cut c
+    std::vector<int> storeStage;              // per register-file row: the stage that stores it at the end of a block
+    std::vector<int> pcmStage;                // per channel: the stage that stores its PCM output
+    std::vector<uint32_t> inMask;             // per stage: channels whose PCM input it reads
+    std::string why;                          // why the program is not cut (diagnostics)
+};
+
 // What the translator needs to know about the program beyond its records.
 struct XlateProgram {
+    StageInfo stage;
     int iSize = 0, xSize = 0;     // itramsize / xtramsize (the cursors' modulus)
     bool uniformCursors = false;  // all lanes' TRAM cursors move together: kept in SGPRs, TRAM instructions inline
     bool tramDane = false;        // opt-in DANE delay-line model: s80 / s82 are per-sample address counters, taps at (counter + position) mod size
@@ -138,8 +179,24 @@ bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& t
                      bool isLast, uint32_t nextBase, const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code,
                      std::string* listing, XlateStats* stats, std::vector<uint32_t>* returns, uint32_t* coldEntry, std::string* err);
 
+// where cuts are legal and which rows cross them; `wanted` stages at most (>= 2), balanced by an estimate of each record's
+// vector instructions.  cuts empty = the program runs as one stage (why says why).
+StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& prog, int nRows, int wanted);
+
+// what the template needs per stage (fx_interp_gfx950.S, KA_STAGES): 32 bytes each
+struct StageDescriptor {
+    uint32_t steadyFast, steadyExact, lastFast, lastExact;  // cold entries, byte offsets from the kernel entry
+    uint32_t storeFirst, storeCount;                        // this stage's slice of the store-row table (entries behind the load rows)
+    uint32_t reserved0, reserved1;
+};
+
 // A loadable code object: the template with the four streams in its hole.
 struct XlateImage {
+    int stages = 1;                            // > 1: launch with 64 * stages threads per workgroup
+    std::vector<StageDescriptor> stageDesc;    // stages > 1
+    std::vector<std::vector<int>> stageStoreRows;  // stages > 1: register-file rows stage k stores at the end of a block
+    std::vector<std::array<uint32_t, 4>> stageBases;  // stages > 1: where stage k's four streams start
+    StagePlan plan;
     std::vector<unsigned char> elf;
     // COLD entry offsets from the kernel entry; AsmArgs.steady = steadyFastOff | steadyOff << 32, .last likewise
     uint32_t steadyFastOff = 0, steadyOff = 0, lastFastOff = 0, lastOff = 0;
@@ -158,5 +215,10 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
                const XlateProgram& prog, XlateImage* out, std::vector<uint32_t> code[5], std::string listing[5], std::string* err);
 bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
                      const XlateTemplate& tmpl, const XlateProgram& prog, XlateImage* out, std::string* err);
+// The same for a program cut into plan.cuts.size() + 1 stages: per stage the four streams ([fast][last fast][exact][last exact]),
+// then the shared run-once code.  code / listing (optional): [stage * 4 + stream], the run-once code last.
+bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
+                      const XlateProgram& prog, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* code,
+                      std::vector<std::string>* listing, std::string* err, uint32_t ldsBudget = 144u * 1024u);  // LDS a workgroup may take (several per CU: less)
 
 }  // namespace fx

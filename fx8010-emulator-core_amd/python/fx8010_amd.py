@@ -38,7 +38,7 @@ SYMBOLS = [
     "fxp_create", "fxp_destroy", "fxp_load_file", "fxp_load_text", "fxp_num_registers", "fxp_register_name",
     "fxp_register_type", "fxp_register_ioindex", "fxp_register_value", "fxp_num_instructions", "fxp_instruction",
     "fxp_itram_size", "fxp_xtram_size", "fxp_error_count", "fxp_error_desc", "fxp_error_row", "fxp_control_count",
-    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_translate", "fxp_last_error",
+    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_translate", "fxp_translate_staged", "fxp_last_error",
 ]
 
 
@@ -95,6 +95,7 @@ def load():
     sig("fxp_lut", C.POINTER(C.c_double), i32, i32); sig("fxp_lower", i32, vp); sig("fxp_lower_info", i64, vp, i32)
     sig("fxp_last_error", cp, vp)
     sig("fxp_translate", i64, vp, i32, i32, vp, i64, C.c_char_p, i64)
+    sig("fxp_translate_staged", i64, vp, i32, i32, i32, i32, vp, i64, C.c_char_p, i64, C.POINTER(C.c_int), C.POINTER(C.c_int), i32)
     _lib = lib
     return lib
 
@@ -188,6 +189,20 @@ class FrontEnd(_Reports):
         if n < 0:
             raise RuntimeError("fxp_translate: %d %s" % (n, self.last_error()))
         return code.raw[:n], text.value.decode("ascii")
+
+    def translate_staged(self, stages, stage=0, stream=0, vgprs=0):
+        """the program cut into at most `stages` pipeline stages (fx_xlate.hpp StageInfo): (code, listing, actual stages, info)
+        of one stream of one stage; info = [cut record, rows handed over] per cut + [LDS bytes]"""
+        cap, tcap = 1 << 20, 1 << 23
+        code = C.create_string_buffer(cap)
+        text = C.create_string_buffer(tcap)
+        actual = C.c_int(0)
+        info = (C.c_int * 64)()
+        n = int(self._lib.fxp_translate_staged(self._h, int(vgprs), int(stages), int(stage), int(stream), code, cap, text, tcap, C.byref(actual), info, 64))
+        if n < 0:
+            raise RuntimeError("fxp_translate_staged: %d %s" % (n, self.last_error()))
+        k = actual.value
+        return code.raw[:n], text.value.decode("ascii"), k, [int(v) for v in info[: 2 * max(k - 1, 0) + (1 if k > 1 else 0)]]
 
     def last_error(self):
         return self._lib.fxp_last_error(self._h).decode("latin-1")

@@ -261,6 +261,13 @@ int64_t fxp_lower_info(fxp_handle* h, int what);
  * cannot be translated, see fxp_last_error) and copies at most `cap` bytes of code and at most listing_cap-1
  * characters of the assembler listing (one instruction per line). */
 int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap);
+/* The same for the program cut into (at most) `stages` stages run by the wavefronts of one workgroup - what the batch path
+ * generates for small batches (fx_xlate.hpp StageInfo): the code of stream `stream` of stage `stage` (stream 4: the shared
+ * run-once code).  *stages_out = the number of stages the program was cut into (1: not cut - the call then returns the
+ * unstaged code and fxp_last_error says why); info (optional, info_cap ints): per cut {first record of the next stage, rows
+ * handed over}, then the LDS bytes of a workgroup. */
+int64_t fxp_translate_staged(fxp_handle* h, int vgprs, int stages, int stage, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap,
+                             int* stages_out, int* info, int info_cap);
 const char* fxp_last_error(fxp_handle* h);
 
 /* library / device probe: number of HIP devices visible (0 if none), never throws */

@@ -1,0 +1,124 @@
+"""Programs pipelined over the wavefronts of a workgroup (fx_xlate.hpp StageInfo) on the device: bit for bit against the oracle
+whatever the number of stages - outputs, registers, instruction counters, state carried over block boundaries, blocks shorter
+than the pipeline, non-finite values crossing a cut."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import fx8010_programs as progs
+from pyoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.fixture
+def stages(monkeypatch):
+    def pin(k):
+        monkeypatch.delenv("FX_KERNEL", raising=False)
+        monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+        if k is None:
+            monkeypatch.delenv("FX_STAGES", raising=False)
+        else:
+            monkeypatch.setenv("FX_STAGES", str(k))
+    return pin
+
+
+def run_and_compare(gpu, text, x, blocks, regs, pre=None):
+    N = x.shape[1]
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    if pre:
+        pre(b, None)
+    ys = [b.process_block(x[lo:hi]) for lo, hi in blocks]
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(text)
+        if pre:
+            pre(None, (o, n))
+        for (lo, hi), y in zip(blocks, ys):
+            r = o.process_block(x[lo:hi, n].copy())
+            assert np.array_equal(r.view(np.uint32), np.ascontiguousarray(y[:, n]).view(np.uint32)), "instance %d block %d:%d" % (n, lo, hi)
+        assert b.instruction_counter_i(n) == o.instruction_counter(), n
+        for reg in regs:
+            assert b.get_register_bits_i(reg, n) == o.get_register_bits(reg), (reg, n)
+    assert b.ood_flags() == 0
+    return b
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 8, 16])
+def test_config2_in_stages(gpu, stages, k):
+    stages(k)
+    N, S = 200, 83   # four workgroups, the last one ragged (8 instances); blocks of 83, 1, 2, 5 and 30 samples
+    x = progs.stimulus(N, S + 38)
+    blocks = [(0, S), (S, S + 1), (S + 1, S + 3), (S + 3, S + 8), (S + 8, S + 38)]
+    b = run_and_compare(gpu, progs.config2(), x, blocks, ["t", "s0", "s7", "s15", "s30", "out", "ccr", "in"])
+    assert b.info("waves_per_wg") == k and b.info("kernel") >= 9
+
+
+def test_small_batches_are_staged_by_default(gpu, stages):
+    stages(None)
+    b = gpu.Batch(300, 1, 0)
+    assert b.load_text(progs.config2())
+    b.process_block(progs.stimulus(300, 8))
+    assert b.info("waves_per_wg") == 8          # 5 wavefronts of instances: eight stages each
+    big = gpu.Batch(262144, 1, 0)
+    assert big.load_text(progs.config2())
+    big.process_block(progs.stimulus(262144, 2))
+    assert big.info("waves_per_wg") == 1        # 4096 wavefronts fill the machine as they are
+    for name in ("config3", "config4", "config5"):
+        c = gpu.Batch(300, 1, 0)
+        assert c.load_text(progs.CONFIGS[name]())
+        c.process_block(progs.stimulus(300, 4))
+        assert c.info("waves_per_wg") == 1, name  # one recurrence from end to end: no legal cut (tests/test_stages.py)
+
+
+def test_non_finite_values_cross_the_cuts(gpu, stages):
+    """a NaN / Inf that enters stage 0 reaches the later stages through the packets: each stage leaves its fast stream on its
+    own (the rows it receives are checked like values from memory)"""
+    stages(4)
+    N, S = 130, 40
+    x = progs.stimulus(N, S).copy()
+    x[5, 3] = np.nan
+    x[9, 64] = -np.inf
+    x[17, 129] = np.float32(np.nan)
+    x.view(np.uint32)[22, 70] = 0xFFA00123   # a signalling NaN with a payload
+    run_and_compare(gpu, progs.config2(), x, [(0, S)], ["t", "s0", "s12", "s30", "out", "ccr"])
+
+
+def test_delay_lines_noise_skip_and_tables_in_stages(gpu, stages):
+    stages(4)
+    text = ("itramsize 11 \ninput in 0\noutput out 0\ncontrol k = 0.25\nstatic noise\nstatic rd\nstatic a\nstatic t\nstatic u\nstatic w\n"
+            + "".join("static s%d\n" % i for i in range(10))
+            + "idelay read, rd, at, 0\nmacs a, in, rd, 0.5\nmacs a, a, noise, 0.125\nidelay write, a, at, 0\n"
+            + "".join("interp s%d, s%d, k, %s\nmacs t, s%d, a, 0.05\n" % (i, i, "a" if i == 0 else "t", i) for i in range(4))
+            + "macs u, t, 0, 0\nskip ccr, ccr, 6, 2\nmacs t, t, 0.5, 0.5\nmacs out, out, t, 0.1\nlog w, u, 3, 0\nexp u, w, 5, 0\n"
+            + "".join("interp s%d, s%d, k, %s\nmacs t, s%d, u, 0.05\n" % (i, i, "t", i) for i in range(4, 10))
+            + "macs out, out, t, 0.5\nend")
+    N, S = 150, 61
+    x = progs.stimulus(N, S)
+
+    def pre(b, on):
+        if b is not None:
+            for n in range(N):
+                b.seed_noise_i(n, 1234 + n, -77 * n)
+        else:
+            o, n = on
+            o.seed_noise(1234 + n, -77 * n)
+
+    b = run_and_compare(gpu, text, x, [(0, 20), (20, 21), (21, S)], ["rd", "a", "t", "u", "w", "s0", "s5", "s9", "out", "ccr"], pre=pre)
+    assert b.info("waves_per_wg") >= 2
+
+
+def test_stage_fuzz_slice(gpu, stages):
+    stages(None)
+    import fuzz_stages
+    argv = sys.argv
+    try:
+        sys.argv = ["fuzz_stages.py", "900000", "60"]
+        assert fuzz_stages.main() == 0
+    finally:
+        sys.argv = argv
+        os.environ.pop("FX_STAGES", None)

@@ -409,7 +409,7 @@ def _mode_of(i):
     return "other:" + ",".join(names)
 
 
-def lint_index_mode(ins, entry_state=UNKNOWN, entries=None, kernel_labels=()):
+def lint_index_mode(ins, entry_state=UNKNOWN, entries=None, kernel_labels=(), any_base=False):
     """Checks the interpreter's index-mode convention over a disassembly.  Returns a list of (Ins, message).
     Labels in kernel_labels are kernel entries (the hardware starts a wave with index mode off); every other label is a
     handler entered by s_setpc_b64 with whatever mode the previous handler left (entry_state)."""
@@ -482,11 +482,11 @@ def lint_index_mode(ins, entry_state=UNKNOWN, entries=None, kernel_labels=()):
                 v = vregs_of(o)
                 if not v:
                     continue
-                if q == p and min(v) != RF_BASE:
+                if q == p and (min(v) < RF_BASE if any_base else min(v) != RF_BASE):   # (any_base: generated code also indexes its PCM input ring)
                     problems.append((i, "%s index mode: source %d is the plain register %s (would address v(n + M0))" % (st.upper(), q, o)))
-                if q != p and min(v) >= RF_BASE:
+                if q != p and min(v) >= RF_BASE and not any_base:
                     problems.append((i, "%s index mode: source %d names the register file (%s) but is not M0-relative" % (st.upper(), q, o)))
-            if has_vdst and min(vregs_of(dst)) >= RF_BASE:
+            if has_vdst and min(vregs_of(dst)) >= RF_BASE and not any_base:
                 problems.append((i, "%s index mode: destination %s is inside the register file" % (st.upper(), dst)))
             continue
         problems.append((i, "index mode %s is not one the handlers use" % st))
@@ -528,3 +528,74 @@ def stream_entries(ins):
         elif k not in has_pred:
             out[i.addr] = OFF
     return out
+
+
+def staged_image_listing(fe, stages, vgprs=0):
+    """The hole image of a program cut into pipeline stages (fx_xlate.cpp buildStagedImage): per stage
+    [steady fast][last fast][steady exact][last exact], then the shared run-once code.  Returns (listing, bytes, stages,
+    info, heads): heads[k] = byte offsets of stage k's four stream heads in the image (in the order fast, last fast, exact, last exact)."""
+    parts, at, heads = [], 0, []
+    code, listing, k, info = fe.translate_staged(stages, 0, 0, vgprs)
+    if k < 2:
+        return None
+    for st in range(k):
+        mine = []
+        for s in (0, 2, 1, 3):
+            code, listing, _, _ = fe.translate_staged(stages, st, s, vgprs)
+            if not code:
+                continue
+            mine.append(at)
+            parts.append(listing.strip())
+            at += len(code)
+            pad = (-at) % 64
+            parts += ["s_nop 0"] * (pad // 4)
+            at += pad
+        heads.append(mine)
+    code, listing, _, _ = fe.translate_staged(stages, 0, 4, vgprs)
+    if code:
+        parts.append(listing.strip())
+        at += len(code)
+        pad = (-at) % 64
+        parts += ["s_nop 0"] * (pad // 4)
+        at += pad
+    return "\n".join(parts), at, k, info, heads
+
+
+def barrier_counts(ins, head, heads, exits=("s[34:35]",)):
+    """Barriers a wavefront executes on every path from the stream head `head` to the next head of its stage (the loop
+    branch, the hand-over to the last-sample stream, a change to the exact stream and on to ITS loop branch) or to the way
+    out (s_setpc_b64 s[34:35]).  Returns (set of counts at the next head, set of counts at the way out)."""
+    by_addr = {i.addr: i for i in ins}
+    start = by_addr[head].index
+    seen, work = set(), [(start, 0, True)]
+    at_head, at_exit = set(), set()
+    while work:
+        k, n, first = work.pop()
+        i = ins[k]
+        if i.addr in heads and not first:
+            at_head.add(n)
+            continue
+        if (k, n) in seen:
+            continue
+        seen.add((k, n))
+        if n > 64:
+            raise RuntimeError("barrier count runs away")
+        n2 = n + (1 if i.mnem == "s_barrier" else 0)
+        if i.mnem == "s_setpc_b64":
+            if i.ops and i.ops[0] in exits:
+                at_exit.add(n2)
+                continue
+            if k + 1 < len(ins):
+                work.append((k + 1, n2, False))   # a handler call: comes back behind it (handlers hold no barrier)
+            continue
+        if i.mnem == "s_endpgm":
+            continue
+        if is_branch(i):
+            t = branch_target(i)
+            if t in by_addr:
+                work.append((by_addr[t].index, n2, False))
+            if i.mnem == "s_branch":
+                continue
+        if k + 1 < len(ins):
+            work.append((k + 1, n2, False))
+    return at_head, at_exit
