@@ -374,6 +374,7 @@ int Batch::ensureLowered() {
             xlateValuSlow_ = image.steady.valuSlow;
             xlateValuClocks_ = image.steady.valuClocks;
             xlateVgprConstants_ = image.vgprConstants;
+            ++xlateBuilds_;
             xlateStages_ = image.stages;
             xlateStageDesc_ = image.stageDesc;
             xlateStageStoreRows_ = image.stageStoreRows;
@@ -442,13 +443,33 @@ int Batch::ensureLowered() {
     return 0;
 }
 
+// A register whose value is compiled into the instruction stream (a literal of the generated code, an immediate of a record)
+// and that the caller changes AFTER the program has run is a moving control - the reference's setRegisterValue is a store
+// (source/FX8010.cpp:236-253), called every 8 samples by its harness (source/main.cpp:107-114).  Such a register is given a
+// row of the register file, once: the code then reads it as a VGPR operand, and every later change is a fill of that row -
+// no re-lowering, no re-translation.  Not for the few operand positions that shape the code itself: a LOG / EXP table
+// number, a SKIP's condition or count, a delay-line offset (those keep being compiled in).
+bool Batch::movableControl(int r) const {
+    for (const Instr& in : prog_.instrs) {
+        if ((in.op == LOG || in.op == EXP) && in.x == r) return false;
+        if (in.op == SKIP && (in.x == r || in.y == r)) return false;
+        if ((in.op == IDELAY || in.op == XDELAY) && in.y == r) return false;
+    }
+    return true;
+}
+
 int Batch::setRegister(const std::string& key, float v) {
     (void)hipSetDevice(device_);
     const int r = prog_.findRegister(key);
     if (r < 0) return 1;
     hostValue_[r] = v;
-    forcedLane_[r] = 0;  // every instance holds the same value again
-    if (!tracked(r)) {   // (a trackable register lives in its row whatever happens: nothing to re-lower)
+    if (tracked(r) || forcedLane_[r] || intrinsicLane(r)) {
+        // the register lives in a row (a schedule, an earlier per-instance or moving-control write, or the program writes it):
+        // the fill below is all there is to do
+    } else if (loaded_ && everLowered_ && movableControl(r)) {
+        forcedLane_[r] = 1;  // a moving control: a row from now on (one re-lowering, this one)
+        lowDirty_ = true;
+    } else {
         lowDirty_ = true;    // immediates (and possibly the classification) change
         if (loaded_ && everLowered_) controlHeat_ = kHeatPerChange;
     }
@@ -643,8 +664,10 @@ int Batch::processWithTrackFallback(const float* dIn, float* dOut, int nSamples,
 int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
     (void)hipSetDevice(device_);
     if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
-    pendingSamples_ = nSamples;
-    if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;  // quiet again: translate
+    if (!piecewise_) {   // (a piece of a pipelined host block: done once for the whole block)
+        pendingSamples_ = nSamples;
+        if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;  // quiet again: translate
+    }
     int rc = ensureLowered();
     if (rc != 0) return rc;
     everLowered_ = true;
@@ -853,9 +876,17 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
         (void)hipStreamSynchronize(copyOut_);
     };
     waitLastLaunch();
+    // the block is ONE call to the bookkeeping of control changes and to the lowering (with its real length), not kHostPieces:
+    // a translation must not fire between two pieces
+    pendingSamples_ = nSamples;
+    if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;
+    int rc = ensureLowered();
+    if (rc != 0) return rc;
+    piecewise_ = true;
+    struct Reset { bool& f; ~Reset() { f = false; } } reset{piecewise_};
     hipError_t e = copyIn(0);
     if (e != hipSuccess) { drain(); return hipFail(e, "H2D"); }
-    int rc = launch(0);
+    rc = launch(0);
     if (rc != 0) { drain(); return rc; }
     for (int p = 0; p < kHostPieces; ++p) {
         if (p + 1 < kHostPieces) {
@@ -938,6 +969,7 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_CODE_BYTES: return useXlate_ ? (int64_t)xlateCodeBytes_ : 0;
         case FXB_INFO_XLATE_INLINED: return useXlate_ ? xlateInlined_ : 0;
         case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;
+        case FXB_INFO_XLATE_BUILDS: return xlateBuilds_;
         case FXB_INFO_XLATE_UNSATURATED: return useXlate_ ? xlateUnsaturated_ : 0;
         case FXB_INFO_XLATE_VALU: return useXlate_ ? xlateValu_ : 0;
         case FXB_INFO_XLATE_VALU_SLOW: return useXlate_ ? xlateValuSlow_ : 0;

@@ -116,6 +116,9 @@ private:
     uint64_t xlateSteady_ = 0, xlateLast_ = 0;  // {fast, exact} stream offsets as the kernel takes them
     uint32_t xlateCodeBytes_ = 0, xlateInitOff_ = 0, xlateLdsBytes_ = 0;
     int stagesWanted(int variant) const;
+    bool movableControl(int reg) const;
+    bool piecewise_ = false;   // processDevice is being called for the pieces of one pipelined host block
+    int xlateBuilds_ = 0;      // translations since the handle was created
     int xlateStages_ = 1;                        // wavefronts per workgroup of the translated program (fx_xlate.hpp StageInfo)
     std::vector<StageDescriptor> xlateStageDesc_;
     std::vector<std::vector<int>> xlateStageStoreRows_;

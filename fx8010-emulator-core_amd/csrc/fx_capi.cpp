@@ -326,6 +326,9 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
             int q = 0;
             for (size_t c = 0; c < sp.cuts.size() && info && q + 2 <= infoCap; ++c) { info[q++] = sp.cuts[c]; info[q++] = (int)sp.live[c].size(); }
             if (info && q < infoCap) info[q++] = (int)plan.ldsBytes;
+            // ... then the number of register-file rows and the stage that stores each of them
+            if (info && q < infoCap) info[q++] = (int)sp.storeStage.size();
+            for (size_t r = 0; r < sp.storeStage.size() && info && q < infoCap; ++r) info[q++] = sp.storeStage[r];
         } else {
             h->err = "not cut into stages: " + sp.why;
         }

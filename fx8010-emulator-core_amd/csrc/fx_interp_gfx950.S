@@ -198,7 +198,7 @@ KNAME:
 	s_mov_b32 s95, 0                                      // early TRAM reads: allowed only if the run-once code says so
 #endif
 #ifdef XLATE
-	s_load_dwordx4  s[48:51], s[0:1], KA_INOFF            // inOff[4] (s52..s55: stage, stages, first entry of its store table, -)
+	s_load_dwordx4  s[48:51], s[0:1], KA_INOFF            // inOff[4] (s52..s55: stage, stages, first entry of its store table, LDS scratch of the epilogue)
 	s_load_dwordx2  s[62:63], s[0:1], KA_STAGES
 	s_load_dword    s53, s[0:1], KA_NSTAGES
 	s_mov_b32 s54, 0
@@ -218,12 +218,13 @@ KNAME:
 	s_cmp_lt_u32 s53, 2
 	s_cbranch_scc1 .Lone_stage
 	s_lshl_b32 s64, s52, 5
-	s_load_dwordx8 s[80:87], s[62:63], s64                // steady {fast, exact}, last {fast, exact}, store first, store count
+	s_load_dwordx8 s[80:87], s[62:63], s64                // steady {fast, exact}, last {fast, exact}, store first, store count, LDS scratch
 	s_waitcnt lgkmcnt(0)
 	s_mov_b64 s[6:7], s[80:81]
 	s_mov_b64 s[42:43], s[82:83]
 	s_mov_b32 s54, s84
 	s_mov_b32 s75, s85
+	s_mov_b32 s55, s86                                    // LDS offset of the epilogue's scratch area
 .Lone_stage:
 #endif
 	// TRAM base of this wave: base + wave * slots * 256
@@ -658,10 +659,12 @@ h_endsample_d:
 #ifdef XLATE
 	// staged: every wavefront has stored the rows it owns; the delay-line cursors, the LFSR words, the out-of-domain flags
 	// and the instruction counter are stage 0's - with the other stages' shadowed-instruction counts and flags, which
-	// come through LDS ([stage][2][lane] from offset 0: the loop is over, tables and packets are dead)
+	// come through LDS ([stage][2][lane] from s55 on: an area of its own - an early stage gets here while the later ones
+	// still read tables and packets)
 	s_cmp_lt_u32 s53, 2
 	s_cbranch_scc1 .Lsolo
 	s_lshl_b32 s62, s52, 9
+	s_add_u32 s62, s62, s55
 	v_add_u32 v5, s62, v1
 	ds_write_b32 v5, v15
 	ds_write_b32 v5, v22 offset:256
@@ -672,6 +675,7 @@ h_endsample_d:
 	s_mov_b32 s62, 1
 .Lgather:
 	s_lshl_b32 s63, s62, 9
+	s_add_u32 s63, s63, s55
 	v_add_u32 v5, s63, v1
 	ds_read_b32 v6, v5
 	ds_read_b32 v7, v5 offset:256

@@ -2623,9 +2623,13 @@ int costOf(const MicroOp& r) {
 }
 }  // namespace
 
+namespace {
+bool verifyStagePlan(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, size_t n, const XlateProgram& prog, int rows, const StagePlan& P, std::string* why);
+}
+
 StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& prog, int nRows, int wanted) {
     StagePlan P;
-    auto no = [&](const char* why) { P.why = why; P.cuts.clear(); P.live.clear(); return P; };
+    auto no = [&](const std::string& why) { P.why = why; P.cuts.clear(); P.live.clear(); return P; };
     if (wanted < 2) return no("one stage asked for");
     if (!prog.trackRows.empty()) return no("control tracks");
     if (prog.tramDane) return no("DANE delay-line model");
@@ -2781,10 +2785,89 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
     P.inMask.assign((size_t)K, 0);
     for (size_t c = 0; c < prog.inRows.size(); ++c)
         if (prog.inRows[c] >= 0) P.inMask[0] |= 1u << c;
+    {
+        std::string why;
+        if (!verifyStagePlan(steadyRecords, lastRecords, n, prog, rows, P, &why)) return no(why);
+    }
     return P;
 }
 
 namespace {
+// A plan is checked before it is used, by running the program's DATA FLOW twice over a few samples and two launches - as the
+// reference runs it (one register file, records in order) and as the stages would (one file per stage, the rows of `live`
+// copied at each cut, inputs loaded by stage 0, rows stored at the end of a launch by their owners) - on symbolic values: every
+// write makes a value that is a hash of the record, the sample and the values it read (a conditional write: also of the value
+// it may leave in place).  Every read, every PCM output and every stored row must see the same value in both runs.
+uint64_t mix64(uint64_t h, uint64_t v) {
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+    return h ^ (h >> 33);
+}
+bool verifyStagePlan(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, size_t n, const XlateProgram& prog, int rows, const StagePlan& P, std::string* why) {
+    const int K = (int)P.cuts.size() + 1;
+    const std::vector<MicroOp>* current = &steady;   // (the last sample of a launch runs the last-sample stream: every CCR write live)
+    auto stageOf = [&](size_t pos) { int st = 0; for (int b : P.cuts) if ((int)pos >= b) ++st; return st; };
+    std::vector<uint64_t> state((size_t)rows);
+    for (int r = 0; r < rows; ++r) state[(size_t)r] = mix64(0x1234, (uint64_t)r);
+    std::vector<uint8_t> shadowed(n, 0);
+    {
+        bool sh = false;
+        for (size_t i = 0; i < n; ++i) {
+            if (steady[i].w[0] == AS_PRED) sh = true;
+            else if (steady[i].w[0] == AS_UNPRED) sh = false;
+            shadowed[i] = sh;
+        }
+    }
+    auto step = [&](std::vector<uint64_t>& file, size_t i, int launch, int t, std::vector<uint64_t>* trace) {
+        const Access a = accessOf((*current)[i]);
+        uint64_t h = mix64(mix64((uint64_t)i * 977 + 13, (uint64_t)t), (uint64_t)launch);
+        for (int k = 0; k < a.nReads; ++k) {
+            const uint64_t v = file[a.reads[k]];
+            if (trace) trace->push_back(v);
+            h = mix64(h, v);
+        }
+        auto write = [&](int R) {
+            uint64_t v = mix64(h, (uint64_t)R);
+            if (shadowed[i]) v = mix64(v, file[(size_t)R]);  // (may leave the old value in place)
+            file[(size_t)R] = v;
+        };
+        if (a.write >= 0 && a.write < rows) write(a.write);
+        if (a.ccr) write(0);
+    };
+    for (int launch = 0; launch < 2; ++launch) {
+        std::vector<uint64_t> seq = state;
+        std::vector<std::vector<uint64_t>> file((size_t)K, state);
+        for (int t = 0; t < 3; ++t) {
+            current = t == 2 ? &last : &steady;
+            std::vector<uint64_t> want, got;
+            for (size_t c = 0; c < prog.inRows.size(); ++c)
+                if (prog.inRows[c] >= 0 && prog.inRows[c] < rows) {
+                    seq[(size_t)prog.inRows[c]] = mix64(mix64(0x77, c), (uint64_t)(launch * 16 + t));
+                    file[0][(size_t)prog.inRows[c]] = seq[(size_t)prog.inRows[c]];
+                }
+            for (size_t i = 0; i < n; ++i) step(seq, i, launch, t, &want);
+            for (int k = 0; k < K; ++k) {
+                if (k > 0)
+                    for (int R : P.live[(size_t)k - 1]) file[(size_t)k][(size_t)R] = file[(size_t)k - 1][(size_t)R];
+                const size_t from = k == 0 ? 0 : (size_t)P.cuts[(size_t)k - 1], to = k + 1 == K ? n : (size_t)P.cuts[(size_t)k];
+                for (size_t i = from; i < to; ++i) step(file[(size_t)k], i, launch, t, &got);
+            }
+            if (want != got) { if (why) *why = "plan check: a read would see another value"; return false; }
+            for (size_t c = 0; c < prog.latchRows.size(); ++c) {
+                const int R = prog.latchRows[c];
+                if (R < 0 || R >= rows) continue;
+                if (file[(size_t)P.pcmStage[c]][(size_t)R] != seq[(size_t)R]) { if (why) *why = "plan check: PCM output of another stage's copy"; return false; }
+            }
+        }
+        for (int R = 0; R < rows; ++R) {
+            if (file[(size_t)P.storeStage[(size_t)R]][(size_t)R] != seq[(size_t)R]) { if (why) *why = "plan check: a row would be stored by the wrong stage"; return false; }
+            state[(size_t)R] = seq[(size_t)R];
+        }
+        (void)stageOf;
+    }
+    return true;
+}
+
 // the records of one stage as a stream of its own (ENDSAMPLE and the fetch pad behind it)
 std::vector<MicroOp> stageRecords(const std::vector<MicroOp>& all, size_t from, size_t to) {
     std::vector<MicroOp> out(all.begin() + (long)from, all.begin() + (long)to);
@@ -2816,10 +2899,11 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
         while (pow2 < bufStride) pow2 <<= 1;
         bufStride = pow2;
     }
-    const uint32_t bufBase = (std::max(tableBytes, (uint32_t)K * 512u) + 255u) & ~255u;  // (the template's epilogue uses the first K * 512 bytes once the loop is over)
+    const uint32_t bufBase = (tableBytes + 255u) & ~255u;
+    const uint32_t scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0), behind the ring
     int group = kStageGroupMax;
-    while (group > 1 && bufBase + 4u * (uint32_t)group * bufStride > ldsBudget) group /= 2;
-    if (bufBase + bufStride > 0xff00u || bufBase + 4u * (uint32_t)group * bufStride > std::min(ldsBudget, 160u * 1024u)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
+    while (group > 1 && bufBase + 4u * (uint32_t)group * bufStride + scratchBytes > ldsBudget) group /= 2;
+    if (bufBase + bufStride > 0xff00u || bufBase + 4u * (uint32_t)group * bufStride + scratchBytes > std::min(ldsBudget, 160u * 1024u)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
     std::vector<std::vector<uint32_t>> code((size_t)K * 4 + 1);
     std::vector<std::string> listing((size_t)K * 4 + 1);
     uint32_t at = tmpl.holeOff;
@@ -2832,6 +2916,7 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     out->last = XlateStats();
     for (size_t r = 0; r < plan.storeStage.size(); ++r) out->stageStoreRows[(size_t)plan.storeStage[r]].push_back((int)r);
     int worstValu = -1;
+    HoistPlan stage0Hoist;
     for (int k = 0; k < K; ++k) {
         const size_t from = k == 0 ? 0 : (size_t)plan.cuts[(size_t)k - 1], to = k + 1 == K ? n : (size_t)plan.cuts[(size_t)k];
         const std::vector<MicroOp> steady = stageRecords(steadyRecords, from, to), last = stageRecords(lastRecords, from, to);
@@ -2854,8 +2939,16 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
         p.stage.storeMask = 0;
         for (size_t c = 0; c < plan.pcmStage.size(); ++c)
             if (plan.pcmStage[c] == k) p.stage.storeMask |= 1u << c;
+        // a leading delay-line read issued a sample ahead lands in its row while this sample's tail is still to come: a row the
+        // tail hands to the next stage must not be one of those (the hoist point only knows the stage's own records)
+        for (int q = 0; q < p.hoist.leadCount; ++q)
+            if (std::find(p.stage.sendRows.begin(), p.stage.sendRows.end(), (int)steady[(size_t)q].w[5]) != p.stage.sendRows.end()) {
+                p.hoist = HoistPlan();
+                break;
+            }
         // steps far shorter than a trip to memory: PCM input in bursts (a stage with delay lines keeps the loop's own prefetch)
         p.stage.inRing = (p.tramOpsInline == 0 && p.hoist.leadCount == 0 && !std::getenv("FX_STAGES_NO_RING")) ? -2 : -1;
+        if (k == 0) stage0Hoist = p.hoist;
         XlateImage one;
         std::vector<uint32_t> c5[5];
         std::string t5[5];
@@ -2884,12 +2977,11 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     }
     // the run-once code: tables of the whole program, the hoist decision of stage 0
     out->initOff = 0;
-    out->ldsBytes = bufBase + 4u * (uint32_t)group * bufStride;
+    out->ldsBytes = bufBase + 4u * (uint32_t)group * bufStride + scratchBytes;
+    for (StageDescriptor& d : out->stageDesc) d.scratchOff = bufBase + 4u * (uint32_t)group * bufStride;
     {
         XlateProgram initProg = program;
-        const std::vector<MicroOp> s0 = stageRecords(steadyRecords, 0, (size_t)plan.cuts[0]), l0 = stageRecords(lastRecords, 0, (size_t)plan.cuts[0]);
-        std::vector<int> inRows0 = program.inRows;
-        initProg.hoist = xlateProgramOf(s0, l0, program.iSize, program.xSize, (int)program.wildRow.size(), inRows0, program.latchRows).hoist;
+        initProg.hoist = stage0Hoist;
         if (!initProg.lutTables.empty() || initProg.hoist.leadCount > 0) {
             emitInit(initProg, &code[(size_t)K * 4], listingOut ? &listing[(size_t)K * 4] : nullptr);
             out->initOff = at;

@@ -187,7 +187,9 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
 struct StageDescriptor {
     uint32_t steadyFast, steadyExact, lastFast, lastExact;  // cold entries, byte offsets from the kernel entry
     uint32_t storeFirst, storeCount;                        // this stage's slice of the store-row table (entries behind the load rows)
-    uint32_t reserved0, reserved1;
+    uint32_t scratchOff;                                    // LDS bytes [scratchOff, scratchOff + 512 * stages): the epilogue's, nothing else's (a stage
+                                                            // that is done reaches its epilogue while later stages still read tables and packets)
+    uint32_t reserved1;
 };
 
 // A loadable code object: the template with the four streams in its hole.

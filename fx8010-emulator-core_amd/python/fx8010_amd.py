@@ -22,7 +22,7 @@ INFO = {
     "num_instructions": 0, "num_registers": 1, "num_lane_regs": 2, "num_uniform_regs": 3, "lds_bytes_per_wg": 4,
     "waves_per_wg": 5, "num_microops": 6, "itram_slots": 7, "xtram_slots": 8, "tram_ops": 9, "multipass": 10,
     "num_shadowed": 11, "num_ccr_live": 12, "device": 13, "grid": 14, "inst_per_lane": 15, "kernel": 16, "num_rows": 17,
-    "xlate_code_bytes": 18, "xlate_inlined": 19, "xlate_called": 20, "xlate_unsaturated": 21, "xlate_valu": 22, "xlate_valu_slow": 23, "xlate_valu_clocks": 24, "xlate_vgpr_constants": 25,
+    "xlate_code_bytes": 18, "xlate_inlined": 19, "xlate_called": 20, "xlate_unsaturated": 21, "xlate_valu": 22, "xlate_valu_slow": 23, "xlate_valu_clocks": 24, "xlate_vgpr_constants": 25, "xlate_builds": 26,
 }
 
 # every symbol include/fx8010_amd.h declares (tests check that the library exports them all)
@@ -197,12 +197,14 @@ class FrontEnd(_Reports):
         code = C.create_string_buffer(cap)
         text = C.create_string_buffer(tcap)
         actual = C.c_int(0)
-        info = (C.c_int * 64)()
-        n = int(self._lib.fxp_translate_staged(self._h, int(vgprs), int(stages), int(stage), int(stream), code, cap, text, tcap, C.byref(actual), info, 64))
+        info = (C.c_int * 512)()
+        n = int(self._lib.fxp_translate_staged(self._h, int(vgprs), int(stages), int(stage), int(stream), code, cap, text, tcap, C.byref(actual), info, 512))
         if n < 0:
             raise RuntimeError("fxp_translate_staged: %d %s" % (n, self.last_error()))
         k = actual.value
-        return code.raw[:n], text.value.decode("ascii"), k, [int(v) for v in info[: 2 * max(k - 1, 0) + (1 if k > 1 else 0)]]
+        head = 2 * max(k - 1, 0) + (1 if k > 1 else 0)
+        self.stage_store = [int(v) for v in info[head + 1: head + 1 + int(info[head])]] if k > 1 else []   # per row: the stage that stores it
+        return code.raw[:n], text.value.decode("ascii"), k, [int(v) for v in info[:head]]
 
     def last_error(self):
         return self._lib.fxp_last_error(self._h).decode("latin-1")

@@ -216,7 +216,8 @@ enum {
     FXB_INFO_XLATE_VALU = 22,       /* translated program: vector-ALU instructions per wavefront and sample period (steady fast stream) */
     FXB_INFO_XLATE_VALU_SLOW = 23,  /* ... those of the ~4-clock issue class (conversions, min/max/med3, compares, fp64, SGPR sources) */
     FXB_INFO_XLATE_VALU_CLOCKS = 24,/* ... modelled SIMD issue clocks of all of them per wavefront and sample period */
-    FXB_INFO_XLATE_VGPR_CONSTANTS = 25 /* uniform constants the translated code keeps in spare VGPRs */
+    FXB_INFO_XLATE_VGPR_CONSTANTS = 25, /* uniform constants the translated code keeps in spare VGPRs */
+    FXB_INFO_XLATE_BUILDS = 26     /* translations (code generation + module load) since the handle was created */
 };
 int64_t fxb_info(fxb_handle* h, int what);
 
@@ -265,7 +266,7 @@ int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t 
  * generates for small batches (fx_xlate.hpp StageInfo): the code of stream `stream` of stage `stage` (stream 4: the shared
  * run-once code).  *stages_out = the number of stages the program was cut into (1: not cut - the call then returns the
  * unstaged code and fxp_last_error says why); info (optional, info_cap ints): per cut {first record of the next stage, rows
- * handed over}, then the LDS bytes of a workgroup. */
+ * handed over}, then the LDS bytes of a workgroup, the number of register-file rows and, per row, the stage that stores it. */
 int64_t fxp_translate_staged(fxp_handle* h, int vgprs, int stages, int stage, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap,
                              int* stages_out, int* info, int info_cap);
 const char* fxp_last_error(fxp_handle* h);

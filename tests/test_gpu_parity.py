@@ -548,42 +548,73 @@ def test_set_register_broadcast_and_per_instance(gpu, k):
     assert b.get_register_i("nonexistent", 0) == 1.0
 
 
-def test_control_changes_defer_the_translation(gpu, monkeypatch):
-    """A control change re-lowers the program.  Translating costs a module load, so while changes keep coming the
-    interpreter runs the blocks; once the controls have been quiet for a few blocks the program is translated
-    again.  Results are the reference's throughout (the main.cpp slider schedule: a change every 8 samples)."""
+def test_moving_controls_become_rows_once(gpu, monkeypatch):
+    """The reference's setRegisterValue is a store (source/FX8010.cpp:236-253), called every 8 samples by its harness
+    (source/main.cpp:107-114).  Here a control starts out compiled into the generated code; the first change after the program
+    has run gives it a row of the register file (ONE re-translation), every later change is a fill of that row: the translated
+    tier runs every block of a slider sweep.  Results are the reference's throughout."""
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
-    text = HDR + "macs a, a, vol, in\ninterp b, b, vol, a\nmacs out, b, a, 0.5\nend"
+    text = HDR + "control mix = 0.25\nmacs a, a, vol, in\ninterp b, b, vol, a\nmacs out, b, a, mix\nend"
     N = 70
     b = gpu.Batch(N, 1, 0)
     assert b.load_text(text), b.errors()
     o = Oracle(1)
     assert o.load_text(text)
     x = progs.stimulus(N, 8 * 40)
-    tiers = []
+    tiers, builds = [], []
     for blk in range(40):
-        if 3 <= blk < 12:
-            v = 0.1 + 0.05 * blk
+        if 3 <= blk < 30:
+            v = float(np.float32(0.1 + 0.03 * blk))
             b.set_register("vol", v)
             o.set_register("vol", v)
+        if blk in (10, 11, 25):
+            b.set_register("mix", 0.5 - 0.01 * blk)
+            o.set_register("mix", 0.5 - 0.01 * blk)
+        if blk == 20:   # non-finite values through a moving control: the row is checked like any state row
+            b.set_register("vol", float("inf"))
+            o.set_register("vol", float("inf"))
         xs = x[8 * blk:8 * blk + 8]
         y = b.process_block(xs)
         ref = o.process_block(xs[:, 5].copy())
         assert np.array_equal(bits(ref), bits(y[:, 5])), "block %d" % blk
         tiers.append(b.info("kernel"))
-    assert tiers[0] >= 9 and tiers[2] >= 9          # translated before the first change
-    assert all(2 <= t <= 8 for t in tiers[3:12])    # interpreter while the slider moves
-    assert tiers[-1] >= 9                           # translated again after the quiet period
+        builds.append(b.info("xlate_builds"))
+    assert all(t >= 9 for t in tiers), tiers                 # the translated tier on every block
+    assert builds[2] == 1 and builds[3] == 2 and builds[9] == 2   # the first change of vol: one more translation, then none
+    assert builds[10] == 3 and builds[-1] == 3                    # ... likewise for mix
     assert b.instruction_counter_i(5) == o.instruction_counter()
-    # a long block is worth a translation even while the slider moves
-    big = gpu.Batch(70000, 1, 0)
-    assert big.load_text(progs.config5())
-    xb = progs.stimulus(70000, 256)
-    big.process_block(xb)
-    big.set_register(big.controls()[0], 0.3)
-    big.process_block(xb)
-    assert big.info("kernel") >= 9
+    for n in (0, 63, 69):
+        assert b.get_register_bits_i("vol", n) == o.get_register_bits("vol") and b.get_register_bits_i("b", n) is not None
+
+
+def test_controls_that_shape_the_code_are_compiled_in(gpu, monkeypatch):
+    """a SKIP's count, a LOG / EXP table number, a delay-line offset given as a control: changing them re-lowers (the
+    interpreter tier runs the blocks while such a control keeps moving, the translation comes back when it rests)"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    text = HDR + "control n = 1\ncontrol e = 3\nmacs a, in, 0, 0\nskip ccr, ccr, 6, n\nmacs out, 0, in, 1.0\nmacs b, out, 0.5, 0.5\nlog out, b, e, 0\nend"
+    N = 70
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    o = Oracle(1)
+    assert o.load_text(text)
+    x = progs.stimulus(N, 8 * 24)
+    tiers = []
+    for blk in range(24):
+        if blk in (3, 4, 5):
+            b.set_register("n", float(blk % 3))
+            o.set_register("n", float(blk % 3))
+        if blk == 6:
+            b.set_register("e", 7.0)
+            o.set_register("e", 7.0)
+        xs = x[8 * blk:8 * blk + 8]
+        y = b.process_block(xs)
+        ref = o.process_block(xs[:, 5].copy())
+        assert np.array_equal(bits(ref), bits(y[:, 5])), "block %d" % blk
+        tiers.append(b.info("kernel"))
+    assert tiers[0] >= 9 and tiers[-1] >= 9 and all(t >= 2 for t in tiers)
+    assert b.instruction_counter_i(5) == o.instruction_counter()
 
 
 def test_register_arrays_per_instance_automation(gpu, k):

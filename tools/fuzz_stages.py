@@ -98,7 +98,16 @@ def main():
             ok = ok and b.instruction_counter_i(n) == o.instruction_counter()
             ok = ok and all(b.get_register_bits_i(reg, n) == o.get_register_bits(reg) for reg in names + ["ccr", "out", "in"])
             if not ok:
-                print("MISMATCH seed %d instance %d stages %d (kernel %d, waves/wg %d)\n%s" % (seed, n, K, b.info("kernel"), b.info("waves_per_wg"), text), flush=True)
+                what = []
+                for q, (a, g) in enumerate(zip(r, y)):
+                    bad = np.nonzero(a.view(np.uint32) != np.ascontiguousarray(g[:, n]).view(np.uint32))[0]
+                    if bad.size:
+                        what.append("block %d: %d samples differ, first %d (ref %08x got %08x)" % (q, bad.size, bad[0], a.view(np.uint32)[bad[0]], np.ascontiguousarray(g[:, n]).view(np.uint32)[bad[0]]))
+                if b.instruction_counter_i(n) != o.instruction_counter():
+                    what.append("counter %d vs %d" % (b.instruction_counter_i(n), o.instruction_counter()))
+                what += ["%s %08x vs %08x" % (reg, b.get_register_bits_i(reg, n), o.get_register_bits(reg)) for reg in names + ["ccr", "out", "in"]
+                         if b.get_register_bits_i(reg, n) != o.get_register_bits(reg)]
+                print("MISMATCH seed %d instance %d stages %d (kernel %d, waves/wg %d): %s\n%s" % (seed, n, K, b.info("kernel"), b.info("waves_per_wg"), "; ".join(what), text if os.environ.get("FX_FUZZ_TEXT") else ""), flush=True)
                 failures.append(seed)
                 break
     print("stage fuzz: %d programs, waves per workgroup %s, failures %s" % (count, dict(sorted(cut.items())), failures))
