@@ -332,7 +332,8 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
         algo_bytes = float(n_inst) * (S * bytes_per_inst_sample + 2 * 4 * (rows + 9))
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_source = measured_traffic(config, n_inst, S)
-        valu_per_wave_sample = batch.info("xlate_valu")
+        valu_per_wave_sample = batch.info("xlate_valu")   # (a program cut into stages: the sum over its stages = one sample of one group of 64 instances)
+        stages = batch.info("waves_per_wg")
         waves = (n_inst + 63) // 64
         valu = None
         if valu_per_wave_sample > 0:
@@ -344,7 +345,8 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
             hz = (clock_mhz * 1e6) if clock_mhz else MAX_CLOCK_HZ
             busy = clocks * (waves / float(SIMDS)) * S / (kernel_ms * 1e-3 * hz)
             valu = {"bound": "valu issue", "achieved": round(per_s / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
-                    "frac": round(per_s / peak, 4), "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves / float(SIMDS), 3),
+                    "frac": round(per_s / peak, 4), "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves * stages / float(SIMDS), 3),
+                    "stages": stages,
                     "valu_per_emulated_instr": round(valu_per_wave_sample / max(executed / float(steps * S * n_inst * n_dev), 1e-9), 3),
                     "valu_4clock_class_per_wave_sample": batch.info("xlate_valu_slow"),
                     "issue_clocks_per_wave_sample": clocks, "clock_mhz": clock_mhz, "power_w": power_w,
@@ -464,6 +466,7 @@ def main():
                                    "instr_per_sample_executed": r["config"]["instr_per_sample_executed"],
                                    "kernel_ms": r["roofline"]["kernel_ms"], "hbm_frac": r["roofline"]["frac"],
                                    "valu_frac": (r["roofline"]["valu"] or {}).get("frac"), "waves_per_simd": (r["roofline"]["valu"] or {}).get("waves_per_simd"),
+                                   "stages": (r["roofline"]["valu"] or {}).get("stages"),
                                    "valu_per_emulated_instr": (r["roofline"]["valu"] or {}).get("valu_per_emulated_instr"),
                                    "simd_issue_busy": (r["roofline"]["valu"] or {}).get("simd_issue_busy"), "clock_mhz": (r["roofline"]["valu"] or {}).get("clock_mhz"),
                                    "power_w": (r["roofline"]["valu"] or {}).get("power_w"),

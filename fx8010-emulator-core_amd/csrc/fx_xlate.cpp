@@ -503,7 +503,8 @@ constexpr int kSTrackNext[kMaxTracks] = {28, 29, 69};   // sample index at which
 constexpr int kSTrackPtr[kMaxTracks] = {26, 30, 70};    // s[26:27] / s[30:31] / s[70:71]: address of that value
 constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
-constexpr int kVSend = 30, kVRecv = 31;             // staged programs: lane * 4 + the LDS buffer this step's packets go to / come from
+constexpr int kVRing = 30;                          // staged programs: lane * 4 + the LDS buffer of this sample's packets (sent and requested, see stageRequest)
+constexpr int kSLastSample = 8;                     // staged programs: nSamples - 1 (s8 is the interpreter's fetch offset: free in generated code)
 
 int32_t danePosition(uint32_t bits, bool shifted, int32_t size);  // (defined with the hoist planning below)
 
@@ -648,7 +649,7 @@ class Translator {
 
         // ---- PCM out, next sample
         plainMode();
-        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+        if (!staged || usesSkipCounter) e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
         if (staged) {
             // hand this sample's live rows to the next stage; ONE barrier per step on every path through a sample (all
             // wavefronts of the workgroup execute the same number of them).  The wait in front of it covers LAST step's writes
@@ -656,9 +657,9 @@ class Translator {
             for (size_t i = 0; i < G.sendRows.size(); ++i) {
                 int v;
                 if (!row((uint32_t)G.sendRows[i], &v)) { if (err) *err = err_; return false; }
-                e_.dsWriteB32(kVSend, v, G.bufBase + G.sendOff + 256u * (uint32_t)i);
+                e_.dsWriteB32(kVRing, v, G.bufBase + G.sendOff + 256u * (uint32_t)i);
             }
-            if (!G.sendRows.empty()) ringStep(kVSend);
+            ringStep(kVRing);
             // ... every group-th sample (the same samples in every wavefront: they all count from 0)
             if (G.group > 1) {
                 e_.sop2(SOP2_AND_B32, "s_and_b32", sreg(kSTemp), sreg(kSSample), imm32((uint32_t)G.group - 1u));
@@ -684,8 +685,12 @@ class Translator {
         if (prog_.tramDane && prog_.uniformCursors) daneStep();
         if (!isLast_) {
             // loop while the sample after this one is not the block's last, then on to the last-sample stream
-            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSSample), imm32(1));
-            e_.sopc(SOPC_CMP_LT_U32, "s_cmp_lt_u32", sreg(kSTemp), sreg(kSNumSamples));
+            if (staged) {
+                e_.sopc(SOPC_CMP_LT_U32, "s_cmp_lt_u32", sreg(kSSample), sreg(kSLastSample));
+            } else {
+                e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSSample), imm32(1));
+                e_.sopc(SOPC_CMP_LT_U32, "s_cmp_lt_u32", sreg(kSTemp), sreg(kSNumSamples));
+            }
             if (!e_.branchBack(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
             const int64_t delta = ((int64_t)nextBase_ - ((int64_t)base_ + (int64_t)e_.bytes() + 4)) / 4;
             if (delta < -32768 || delta > 32767) { if (err) *err = "last-sample stream out of branch range"; return false; }
@@ -714,13 +719,16 @@ class Translator {
         if (staged) {
             // stage k starts 3k steps late; packet s lives in buffer s & 3.  The step in front of its first sample requests
             // that sample's rows.
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVSend), vreg(kVLane4));
-            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVRecv), vreg(kVLane4));
+            // (the request in front of the first sample: packet 0 of the cut in front of this stage, buffer `index`; then the
+            // pointer stands at index + 1 for sample 0)
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVRing, imm32((uint32_t)G.index * G.bufStride), kVLane4);
             for (int k = 0; k + 1 < kStageDepth * G.index; ++k) e_.barrier();
             if (G.index > 0) {
                 if (!G.recvRows.empty()) stageRequest();
                 e_.barrier();
             }
+            ringStep(kVRing);
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLastSample), sreg(kSNumSamples), imm32(0xffffffffu));
             if (ring) inputBurst(0, true);
         }
         for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
@@ -802,11 +810,12 @@ class Translator {
         e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", v, imm32(G.bufStride), v);
         e_.vop2(VOP2_AND_B32, "v_and_b32_e32", v, imm32(4u * (uint32_t)G.group * G.bufStride - 1u), v);
     }
-    // request the rows of the NEXT sample this stage will work on (the previous stage wrote them two steps ago)
+    // request the rows of the NEXT sample this stage will work on (the previous stage wrote them two steps ago).  Packet s of
+    // the cut behind stage c lives in buffer (s + c + 1) mod ring: what stage k sends for its sample s and what it requests for
+    // its sample s + 1 (from the cut in front of it) share one buffer index, s + k + 1 - one pointer, stepped once per sample.
     void stageRequest() {
         const StageInfo& G = prog_.stage;
-        for (size_t i = 0; i < G.recvRows.size(); ++i) e_.dsReadB32(G.recvTmp + (int)i, kVRecv, G.bufBase + G.recvOff + 256u * (uint32_t)i);
-        ringStep(kVRecv);
+        for (size_t i = 0; i < G.recvRows.size(); ++i) e_.dsReadB32(G.recvTmp + (int)i, kVRing, G.bufBase + G.recvOff + 256u * (uint32_t)i);
     }
     // PCM input in bursts of eight samples (StageInfo::inRing).  inputBurst(first, initial): loads of samples s + first ..
     // s + first + 7 (s = the current sample, s3) into the "next" half, each only if it exists; the initial one is waited for.
@@ -2971,7 +2980,16 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
         d.lastExact = one.lastOff;
         for (int q = 0; q < 4; ++q) out->base[q] = one.base[q];  // (of the last stage: diagnostics only)
         out->stageBases.push_back({one.base[0], one.base[1], one.base[2], one.base[3]});
-        if (one.steady.valu > worstValu) { worstValu = one.steady.valu; out->steady = one.steady; out->last = one.last; }
+        // statistics: the stages' vector instructions ADD UP to the work of one sample of one instance group (the slowest
+        // stage sets the pace: worstValu)
+        worstValu = std::max(worstValu, one.steady.valu);
+        for (auto pr : {std::make_pair(&out->steady, &one.steady), std::make_pair(&out->last, &one.last)}) {
+            XlateStats& a = *pr.first;
+            const XlateStats& b = *pr.second;
+            a.inlined += b.inlined; a.called += b.called; a.instructions += b.instructions; a.valu += b.valu; a.valuSlow += b.valuSlow;
+            a.valuClocks += b.valuClocks; a.fusedSkips += b.fusedSkips; a.regions += b.regions; a.unitMultipliers += b.unitMultipliers;
+            a.reusedProducts += b.reusedProducts; a.fusedZeroAdds += b.fusedZeroAdds; a.unsaturated += b.unsaturated;
+        }
         out->vgprConstants = one.vgprConstants;
         at = end;
     }
@@ -2989,6 +3007,7 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
         }
     }
     out->codeBytes = at - tmpl.holeOff;
+    out->slowestStageValu = worstValu;
     if (out->codeBytes + 4 > tmpl.holeBytes) { if (err) *err = "translated program larger than the code hole of the template"; return false; }
     out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
     for (int k = 0; k < K; ++k)

@@ -195,6 +195,7 @@ struct StageDescriptor {
 // A loadable code object: the template with the four streams in its hole.
 struct XlateImage {
     int stages = 1;                            // > 1: launch with 64 * stages threads per workgroup
+    int slowestStageValu = 0;                  // stages > 1: vector instructions per sample of the stage that sets the pace (steady / last: sums over the stages)
     std::vector<StageDescriptor> stageDesc;    // stages > 1
     std::vector<std::vector<int>> stageStoreRows;  // stages > 1: register-file rows stage k stores at the end of a block
     std::vector<std::array<uint32_t, 4>> stageBases;  // stages > 1: where stage k's four streams start
