@@ -60,7 +60,7 @@ public:
     void noteError(const std::string& what) { lastError_ = what; }
     // behaviour beyond the reference (fx_model.hpp kOpt*): takes effect for programs loaded afterwards
     int setOption(unsigned option, bool on) {
-        if (option & ~(kOptTramDane | kOptTramAddrShift)) return -3;
+        if (option & ~kOptAll) return -3;
         prog_.options = on ? (prog_.options | option) : (prog_.options & ~option);
         lowDirty_ = true;
         return 0;

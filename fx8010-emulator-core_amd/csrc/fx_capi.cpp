@@ -203,7 +203,7 @@ int64_t fxb_info(fxb_handle* h, int what) { return h ? guard(&h->batch.front(), 
 fxp_handle* fxp_create(int ch) { return create<fxp_handle>(ch); }
 void fxp_destroy(fxp_handle* h) { delete h; }
 int fxp_set_option(fxp_handle* h, unsigned option, int on) {
-    if (!h || (option & ~(fx::kOptTramDane | fx::kOptTramAddrShift))) return FX_E_ARG;
+    if (!h || (option & ~fx::kOptAll)) return FX_E_ARG;
     h->prog.options = on ? (h->prog.options | option) : (h->prog.options & ~option);
     return 0;
 }

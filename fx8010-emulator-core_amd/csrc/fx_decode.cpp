@@ -289,7 +289,10 @@ Lowered lowerProgram(const Program& prog, const std::vector<float>& hostValue, c
             }
             uint32_t flags = sh | F_COUNT;
             if (setsCcr(I.op) && (pass == 1 || ccrLive[k])) flags |= F_CCR;
-            if (h >= H_TRAM_IR && h <= H_TRAM_XW && out.tramDane) flags |= F_TRAM_DANE | ((prog.options & kOptTramAddrShift) ? F_TRAM_SHIFT : 0u);
+            if (h >= H_TRAM_IR && h <= H_TRAM_XW && out.tramDane) {
+                flags |= F_TRAM_DANE | ((prog.options & kOptTramAddrShift) ? F_TRAM_SHIFT : 0u);
+                if ((h == H_TRAM_IR || h == H_TRAM_XR) && (prog.options & kOptTramAddrShift) && (prog.options & kOptTramInterp)) flags |= F_TRAM_INTERP;
+            }
 
             // operand slots: LDS byte offset of a per-instance row, or the immediate of a uniform register;
             // slots an opcode does not read are immediates too, so the kernel issues no LDS read for them

@@ -54,7 +54,8 @@ enum : uint32_t {
     F_STATIC_OOD = 1u << 16,  // decoder already knows this op leaves the parity domain
     F_WRITE_R = 1u << 17,     // the handler's result is stored to row R (and CCR derived from it if F_CCR)
     F_TRAM_DANE = 1u << 18,   // opt-in delay-line model (fx_model.hpp kOptTramDane): slot = (per-sample counter + position) mod size
-    F_TRAM_SHIFT = 1u << 19   // ... positions are DANE addresses: >> 11
+    F_TRAM_SHIFT = 1u << 19,  // ... positions are DANE addresses: >> 11
+    F_TRAM_INTERP = 1u << 20  // ... and a READ tap interpolates between position and position + 1 with the address's low 11 bits
 };
 
 // state rows (32-bit words per instance) in the device state block, after the register rows

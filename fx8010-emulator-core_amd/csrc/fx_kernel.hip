@@ -250,6 +250,18 @@ __device__ __forceinline__ void daneTap(const Ctx<K>& c, float* __restrict__ bas
         float* cell = base + (size_t)idx * (64 * K) + k;
         if (idx < slots) { if (isRead) av.v[k] = *cell; else *cell = av.v[k]; }
         else if (isRead) av.v[k] = 0.0f;
+        if (isRead && (flags & F_TRAM_INTERP)) {
+            // opt-in: x0 + f * (x1 - x0) with the address's low 11 bits (oracle dane_read: four fp32 operations, x1 - x0 as
+            // x1 + (-1.0 * x0) so that a NaN keeps its sign, sources ordered like the oracle's operands)
+            const int frac = cvtt_f32(yv.v[k] * 2147483648.0f) & 0x7ff;
+            if (frac != 0) {
+                long long i1 = ((long long)(int)asU(cur.v[k]) + position + 1) % size;
+                if (i1 < 0) i1 += size;
+                const float x0 = av.v[k], x1 = i1 < slots ? base[(size_t)i1 * (64 * K) + k] : 0.0f;
+                const float d = addFirst(x1, mulFirst(-1.0f, x0));
+                av.v[k] = addFirst(x0, mulFirst((float)frac * 0.00048828125f, d));
+            }
+        }
     }
     orOod<K>(c, ood);
 }

@@ -28,6 +28,8 @@ enum RegType : int {
 // options (same values as FX_OPT_* in include/fx8010_amd.h and FXO_OPT_* in the oracle)
 constexpr unsigned kOptTramDane = 1u << 0;       // DANE delay-line model: per-sample address counter, ring taps, &name tap registers
 constexpr unsigned kOptTramAddrShift = 1u << 1;  // tap positions are DANE addresses (0x800 per sample)
+constexpr unsigned kOptTramInterp = 1u << 2;     // (with the address shift) READ taps interpolate linearly with the address's low 11 bits
+constexpr unsigned kOptAll = kOptTramDane | kOptTramAddrShift | kOptTramInterp;
 
 constexpr int kMaxITram = 8192;     // reference MAX_IDELAY_SIZE, include/FX8010.h:41
 constexpr int kMaxXTram = 1048576;  // reference MAX_XDELAY_SIZE, include/FX8010.h:42

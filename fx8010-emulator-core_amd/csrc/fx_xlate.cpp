@@ -468,6 +468,7 @@ enum : uint32_t {
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
     SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
+    VOP2_ASHRREV_I32 = 0x11, VOP1_FLOOR_F32 = 0x1f, VOP1_CVT_F32_I32 = 5, VOPC_CMP_EQ_U32_ = 0xca,
 };
 
 // register conventions shared with fx_interp_gfx950.S
@@ -1254,6 +1255,129 @@ class Translator {
         }
     }
 
+    // the low 11 bits of a uniform DANE address (FX_OPT_TRAM_INTERP: the weight of the next sample)
+    static int32_t daneFraction(uint32_t bits) {
+        float f;
+        std::memcpy(&f, &bits, 4);
+        const float scaled = f * 2147483648.0f;
+        uint32_t sb;
+        std::memcpy(&sb, &scaled, 4);
+        return x86Trunc(sb) & 0x7ff;
+    }
+    // Opt-in DANE taps that are not one scalar slot: the position is a per-instance DANE address (FX_OPT_TRAM_ADDR_SHIFT: a
+    // fixed-point fraction, |position| < 2^20 samples), and / or the read interpolates between two slots (FX_OPT_TRAM_INTERP).
+    // Per lane: a = cvttss2si(value * 2^31); p = a >> 11; slot = (counter + p) mod size - the modulo in fp32, where every
+    // quantity is an integer below 2^23 and therefore exact: q = floor(x / size) by the reciprocal is off by at most one, two
+    // selects repair it; the lanes then gather / scatter with their own byte offsets.  Reads wait for their data at once.
+    bool daneGather(const MicroOp& r, int t, int32_t size, bool isRead, int vData) {
+        const bool perLane = !(r.w[6] & 4u), interp = isRead && (r.w[6] & 64u) != 0;
+        if (perLane && !(r.w[6] & 32u)) return fail("DANE tap with a per-instance position in whole samples (HIP C++ kernel)");
+        const Src vcc = named(106, "vcc");
+        const int counter = kSCursor + 2 * t;
+        if (isRead && !flush()) return false;   // (the wait below drains everything: earlier reads are checked first)
+        // v6 = the DANE address a
+        if (perLane) {
+            int vY;
+            if (!row(r.w[4], &vY)) return false;
+            e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 7, imm32(0x4f000000u), vY);                     // value * 2^31
+            e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(6), vreg(7));
+            e_.vopc(VOPC_CMP_NGT_F32, "v_cmp_ngt_f32_e32", imm32(0x4f000000u), 7);                 // cvttss2si: NaN and >= 2^31 give 0x80000000 (v_cvt saturates upwards)
+            e_.sopp(SOPP_NOP, "s_nop", 1, true);
+            e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", 6, vreg(6), 28, ", vcc");                    // v28 = 0x80000000
+        } else {
+            float f;
+            std::memcpy(&f, &r.w[4], 4);
+            const float scaled = f * 2147483648.0f;
+            uint32_t sb;
+            std::memcpy(&sb, &scaled, 4);
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(6), imm32((uint32_t)x86Trunc(sb)));
+        }
+        // slot = (counter + (a >> 11)) mod size, as a float in v8; v10 = size
+        e_.vop2(VOP2_ASHRREV_I32, "v_ashrrev_i32_e32", 7, imm32(11), 6);
+        e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 7, sreg(counter), 7);
+        e_.vop1(VOP1_CVT_F32_I32, "v_cvt_f32_i32_e32", vreg(8), vreg(7));
+        const float sizef = (float)size, rcp = 1.0f / (float)size;
+        uint32_t sizeBits, rcpBits;
+        std::memcpy(&sizeBits, &sizef, 4);
+        std::memcpy(&rcpBits, &rcp, 4);
+        e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(10), imm32(sizeBits));
+        e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 9, imm32(rcpBits), 8);
+        e_.vop1(VOP1_FLOOR_F32, "v_floor_f32_e32", vreg(9), vreg(9));
+        {
+            Src addend = vreg(8);
+            e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(8), vreg(9), vreg(10), &addend, 1);           // x - q * size
+        }
+        auto wrap = [&](int v) {   // v in [-size, 2 size) -> [0, size)
+            e_.vopc(VOPC_CMP_GT_F32, "v_cmp_gt_f32_e32", imm32(0), v);
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 11, vreg(10), v);
+            e_.sopp(SOPP_NOP, "s_nop", 0, true);
+            e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", v, vreg(v), 11, ", vcc");
+            e_.vopc(VOPC_CMP_LE_F32, "v_cmp_le_f32_e32", vreg(10), v);
+            e_.vop2(VOP2_SUB_F32, "v_sub_f32_e32", 11, vreg(v), 10);
+            e_.sopp(SOPP_NOP, "s_nop", 0, true);
+            e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", v, vreg(v), 11, ", vcc");
+        };
+        wrap(8);
+        auto address = [&](int vSlotF, int vAddr) {   // byte offset of the lane's slot: slot * 256 + lane * 4
+            e_.vop1(VOP1_CVT_I32_F32, "v_cvt_i32_f32_e32", vreg(vAddr), vreg(vSlotF));
+            e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", vAddr, imm32(8), vAddr);
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", vAddr, vreg(vAddr), kVLane4);
+        };
+        // the ring is allocated whole (slots >= size: fx_batch ensureTram) - checked once per tap, scalar
+        e_.sopc(SOPC_CMP_GE_I32, "s_cmp_ge_i32", sreg(kSTramSlots[t]), imm32((uint32_t)size));
+        Emitter::Fixup outside = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+        address(8, 7);
+        if (!isRead) {
+            e_.global(GLOBAL_STORE_DWORD, false, vData, 7, kSTramBase[t], streaming(2));
+            defer(outside, [this]() {
+                e_.waitVmcnt(0);
+                e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(2));
+            });
+            return true;
+        }
+        const int vR = vData;
+        e_.global(GLOBAL_LOAD_DWORD, true, vR, 7, kSTramBase[t], streaming(1));
+        if (interp) {
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 12, imm32(0x3f800000u), 8);                      // the next slot
+            e_.vopc(VOPC_CMP_LE_F32, "v_cmp_le_f32_e32", vreg(10), 12);
+            e_.vop2(VOP2_SUB_F32, "v_sub_f32_e32", 11, vreg(12), 10);
+            e_.sopp(SOPP_NOP, "s_nop", 0, true);
+            e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", 12, vreg(12), 11, ", vcc");
+            address(12, 7);
+            e_.global(GLOBAL_LOAD_DWORD, true, 4, 7, kSTramBase[t], streaming(1));
+        }
+        e_.waitVmcnt(0);
+        defer(outside, [this, vR, interp]() {
+            e_.waitVmcnt(0);
+            e_.cold(true);
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
+            if (interp) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(4), imm32(0));
+            e_.cold(false);
+        });
+        if (interp) {
+            // x0 + f * (x1 - x0), f = (a & 0x7ff) / 2048; x1 - x0 as x1 + (-1.0 * x0); lanes with f == 0 keep x0 itself
+            e_.vop2(VOP2_AND_B32, "v_and_b32_e32", 13, imm32(0x7ffu), 6);
+            e_.vop1(VOP1_CVT_F32_I32, "v_cvt_f32_i32_e32", vreg(9), vreg(13));
+            e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 9, imm32(0x3a000000u), 9);                       // * 2^-11
+            e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 3, imm32(0xbf800000u), vR);
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 3, vreg(4), 3);                                   // x1 first
+            e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 3, vreg(9), 3);                                   // f first
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 3, vreg(vR), 3);                                  // x0 first
+            e_.vopc(VOPC_CMP_EQ_U32_, "v_cmp_eq_u32_e32", imm32(0), 13);
+            e_.sopp(SOPP_NOP, "s_nop", 1, true);
+            e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", vR, vreg(3), vR, ", vcc");
+        }
+        // what arrived (and what the interpolation made of it) is checked like any value from memory; both streams define the
+        // sync point
+        returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+        if (fast_) {
+            taintCheckRow(vR);
+            if (!leaveIfTainted((*exactReturns_)[syncIndex(1)])) return false;
+        }
+        (void)vcc;
+        return true;
+    }
+
     bool tramRead(const MicroOp& r, uint32_t slot, bool deferred, bool ahead = false) {
         const int t = tramOf(slot);
         const int cursor = kSCursor + 2 * t + 1;
@@ -1268,6 +1392,11 @@ class Translator {
             e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vR), imm32(0));
             e_.sop2(SOP2_OR_B32, "s_or_b32", sreg(kSOod), sreg(kSOod), imm32(4));
             return true;
+        }
+        if (prog_.tramDane && (!(r.w[6] & 4u) || ((r.w[6] & 64u) && daneFraction(r.w[4]) != 0))) {
+            // a tap whose position is a per-instance value (a modulated delay), or an interpolated read between two slots
+            if (!deferred) return fail("internal: a leading read must be a plain tap");
+            return daneGather(r, t, size, true, vR);
         }
         const int32_t p = prog_.tramDane ? 1 : tramOffset(r, size);
         const Src pos = p == 0 ? sreg(cursor) : sreg(kSPos);
@@ -1310,6 +1439,7 @@ class Translator {
         int vA = 2;
         if (r.w[6] & 1u) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), value(r.w[2]));
         else if (!row(r.w[2], &vA)) return false;
+        if (prog_.tramDane && !(r.w[6] & 4u)) return daneGather(r, t, size, false, vA);
         if (prog_.tramDane) daneSlot(r, t, size, false);
         else if (p != 0) e_.sop2(SOP2_ADD_I32, "s_add_i32", sreg(kSPos), sreg(cursor), imm32((uint32_t)p));
         e_.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSAddr), sreg(kSTramSlots[t]), imm32(t == 0 ? 8192u : 1048576u, true));
@@ -2298,6 +2428,15 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
     while ((size_t)lead < steady.size() && (size_t)lead < last.size() && lead < 32) {
         const MicroOp& r = steady[(size_t)lead];
         if (!isRead(r.w[0]) || last[(size_t)lead].w[0] != r.w[0] || last[(size_t)lead].w[5] != r.w[5] || last[(size_t)lead].w[4] != r.w[4]) break;
+        if (!(r.w[6] & 4u)) break;   // a per-instance position: gathered where it stands
+        if (p.tramDane && (r.w[6] & 64u)) {   // an interpolated read between two slots: likewise
+            float f;
+            std::memcpy(&f, &r.w[4], 4);
+            const float scaled = f * 2147483648.0f;
+            uint32_t sb;
+            std::memcpy(&sb, &scaled, 4);
+            if (truncX86(sb) & 0x7ff) break;
+        }
         if (sizeOf(tramOf(r.w[0])) < 1 || (!p.tramDane && offsetOf(r) != 0) || std::find(rows.begin(), rows.end(), r.w[5]) != rows.end()) break;
         // a register with a control track takes its scheduled value at the head of the sample, BEFORE the program's first
         // instruction: a read into it must stay an ordinary instruction behind the head (api fuzz seed 50788)
@@ -2306,6 +2445,8 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
         ++lead;
     }
     if (lead == 0) return H;
+    for (const MicroOp& r : steady)   // a write whose slot is not known here may be the one an early read must not overtake
+        if (isWrite(r.w[0]) && !(r.w[6] & 4u)) return H;
     // per TRAM: reads and writes per sample, leading reads
     int nRead[2] = {0, 0}, nWrite[2] = {0, 0}, nLead[2] = {0, 0};
     for (size_t i = 0; i < steady.size(); ++i) {
@@ -2412,7 +2553,8 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
                 if (r.w[6] & 16u) p.tramDane = true;  // (all TRAM records of a program carry the flag, or none)
                 // reference model: a shadowed TRAM instruction makes the lanes' cursors diverge; DANE model: the counter
                 // steps per sample whatever executes, so only the position has to be uniform
-                if ((shadow && !(r.w[6] & 16u)) || !(r.w[6] & 4u)) ok = false;
+                // ... a per-instance position is gathered per lane (generated for DANE addresses, daneGather)
+                if ((shadow && !(r.w[6] & 16u)) || (!(r.w[6] & 4u) && (r.w[6] & 48u) != 48u)) ok = false;
             }
         }
     }

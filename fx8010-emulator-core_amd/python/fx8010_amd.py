@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "..", "libfx8010_amd.so")
 _f32p = C.POINTER(C.c_float)
 _lib = None
 
-OPT_TRAM_DANE, OPT_TRAM_ADDR_SHIFT = 1, 2  # FX_OPT_* of include/fx8010_amd.h
+OPT_TRAM_DANE, OPT_TRAM_ADDR_SHIFT, OPT_TRAM_INTERP = 1, 2, 4  # FX_OPT_* of include/fx8010_amd.h
 
 # selectors of fxb_info / fxp_lower_info
 INFO = {
@@ -112,7 +112,7 @@ class _Reports:
         return getattr(self._lib, self._pfx + name)(self._h, *a)
 
     def set_option(self, option, on=True):
-        """FX_OPT_* (OPT_TRAM_DANE, OPT_TRAM_ADDR_SHIFT): behaviour beyond the reference; before loading"""
+        """FX_OPT_* (OPT_TRAM_DANE, OPT_TRAM_ADDR_SHIFT, OPT_TRAM_INTERP): behaviour beyond the reference; before loading"""
         rc = self._call("set_option", option, 1 if on else 0)
         if rc != 0:
             raise RuntimeError("set_option(%d) failed: %d" % (option, rc))

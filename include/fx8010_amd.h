@@ -59,6 +59,12 @@ extern "C" {
  * kernel tier (FXB_INFO_KERNEL 0; also taps with a per-instance position) and, as the checker, by oracle/ (FXO_OPT_*). */
 #define FX_OPT_TRAM_DANE (1u << 0)
 #define FX_OPT_TRAM_ADDR_SHIFT (1u << 1)
+/* FX_OPT_TRAM_INTERP  (with FX_OPT_TRAM_ADDR_SHIFT) the interpolated read the reference's comment asks for ("To do linear
+ *   Interpolation, you need to find the fractional part of the read position and interpolate between the two adjacent
+ *   samples", source/FX8010.cpp:929-932; ":1192 (Y-2048) mit 11 Bit Shift"): a READ tap at DANE address a = floatToInt(value)
+ *   returns x0 + f * (x1 - x0), x0 at position a >> 11, x1 at the position after it, f = (a & 0x7ff) / 2048 - four fp32
+ *   operations in that order; f == 0 returns x0 itself.  Writes ignore the fraction. */
+#define FX_OPT_TRAM_INTERP (1u << 2)
 
 typedef struct fx_handle fx_handle;   /* one emulated DSP  */
 typedef struct fxb_handle fxb_handle; /* a batch of N DSPs */

@@ -527,6 +527,23 @@ static int dane_slot(fxo_t* f, int size, int base, float value) {
     long idx = ((long)base + position) % size;
     return (int)(idx < 0 ? idx + size : idx);
 }
+/* opt-in FXO_OPT_TRAM_INTERP (with ADDR_SHIFT; the reference only says what it wants: "To do linear Interpolation, you need to
+ * find the fractional part of the read position and interpolate between the two adjacent samples", source/FX8010.cpp:929-932):
+ * a READ tap at DANE address a = floatToInt(value) takes x0 from position a >> 11 and x1 from the position after it and
+ * returns x0 + f * (x1 - x0), f = (a & 0x7ff) / 2048 - four fp32 operations in this order, nothing fused; f == 0: x0 itself. */
+static float dane_read(fxo_t* f, const float* ring, int size, int base, float value) {
+    if (!((f->opts & FXO_OPT_TRAM_INTERP) && (f->opts & FXO_OPT_TRAM_ADDR_SHIFT))) return ring[dane_slot(f, size, base, value)];
+    const int32_t a = cvtt_f32(value * 2147483648.0f);
+    const int32_t p = a >> 11, frac = a & 0x7ff;
+    long i0 = ((long)base + p) % size, i1 = ((long)base + p + 1) % size;
+    if (i0 < 0) i0 += size;
+    if (i1 < 0) i1 += size;
+    const float x0 = ring[i0];
+    if (frac == 0) return x0;
+    const float x1 = ring[i1], fr = (float)frac * 0.00048828125f;
+    const float d = addss(x1, mulss(-1.0f, x0));      /* x1 - x0 without negating a NaN (the device cannot subtract one unchanged) */
+    return addss(x0, mulss(fr, d));
+}
 static void tram_write(fxo_t* f, float* buf, int cap, int size, int* wpos, float sample, int position) {
     if (size <= 0) { f->ood |= FXO_OOD_TRAM_SIZE0; return; }
     position = position > size - 1 ? size - 1 : position; position = position < 0 ? 0 : position; /* max(0,min(p,size-1)) */
@@ -622,8 +639,8 @@ void fxo_process(fxo_t* f, const float* in, float* out) {
                 case OP_IDELAY:                                              /* :1188-1199 */
                     if ((f->opts & FXO_OPT_TRAM_DANE) && (R->type == RT_READ || R->type == RT_WRITE)) {
                         if (f->itram_size <= 0) { f->ood |= FXO_OOD_TRAM_SIZE0; if (R->type == RT_READ) A->value = 0.0f; break; }
-                        const int slot = dane_slot(f, f->itram_size, f->iw, Y->value);
-                        if (R->type == RT_READ) A->value = f->itram[slot]; else f->itram[slot] = A->value;
+                        if (R->type == RT_READ) A->value = dane_read(f, f->itram, f->itram_size, f->iw, Y->value);
+                        else f->itram[dane_slot(f, f->itram_size, f->iw, Y->value)] = A->value;
                         break;
                     }
                     if (R->type == RT_READ) A->value = tram_read(f, f->itram, MAX_IDELAY_SIZE, f->itram_size, &f->ir, cvtt_f32(Y->value));
@@ -634,8 +651,8 @@ void fxo_process(fxo_t* f, const float* in, float* out) {
                         if (!f->xtram) f->xtram = (float*)calloc(MAX_XDELAY_SIZE, sizeof(float));
                         if (f->opts & FXO_OPT_TRAM_DANE) {
                             if (f->xtram_size <= 0) { f->ood |= FXO_OOD_TRAM_SIZE0; if (R->type == RT_READ) A->value = 0.0f; break; }
-                            const int slot = dane_slot(f, f->xtram_size, f->xw, Y->value);
-                            if (R->type == RT_READ) A->value = f->xtram[slot]; else f->xtram[slot] = A->value;
+                            if (R->type == RT_READ) A->value = dane_read(f, f->xtram, f->xtram_size, f->xw, Y->value);
+                            else f->xtram[dane_slot(f, f->xtram_size, f->xw, Y->value)] = A->value;
                             break;
                         }
                         if (R->type == RT_READ) A->value = tram_read(f, f->xtram, MAX_XDELAY_SIZE, f->xtram_size, &f->xr, cvtt_f32(Y->value));

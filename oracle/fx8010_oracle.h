@@ -31,7 +31,8 @@ enum {
 /* behaviour beyond the reference, off by default: the same switches as the product's FX_OPT_* (include/fx8010_amd.h) */
 enum {
     FXO_OPT_TRAM_DANE = 1 << 0,       /* DANE delay-line model: per-sample address counter, ring taps, &name tap registers */
-    FXO_OPT_TRAM_ADDR_SHIFT = 1 << 1  /* tap positions are DANE addresses (0x800 per sample) */
+    FXO_OPT_TRAM_ADDR_SHIFT = 1 << 1, /* tap positions are DANE addresses (0x800 per sample) */
+    FXO_OPT_TRAM_INTERP = 1 << 2      /* (with ADDR_SHIFT) a READ tap interpolates linearly with the address's low 11 bits */
 };
 
 fxo_t* fxo_create(int channels);

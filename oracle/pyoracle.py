@@ -208,7 +208,7 @@ class Oracle(_Base):
         return int(self._lib.fxo_ood_flags(self._h))
 
     def set_option(self, option, on=True):
-        """FXO_OPT_* (1 = DANE delay-line model, 2 = DANE address shift): behaviour beyond the reference; before loading"""
+        """FXO_OPT_* (1 = DANE delay-line model, 2 = DANE address shift, 4 = interpolated reads): behaviour beyond the reference; before loading"""
         self._lib.fxo_set_option(self._h, C.c_uint(option), 1 if on else 0)
 
     def seed_noise(self, x1, x2):

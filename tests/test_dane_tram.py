@@ -9,7 +9,7 @@ import pytest
 import fx8010_programs as progs
 from pyoracle import Oracle
 
-OPT_DANE, OPT_SHIFT = 1, 2
+OPT_DANE, OPT_SHIFT, OPT_INTERP = 1, 2, 4
 
 TWO_TAPS = """itramsize 64 
 xtramsize 500 
@@ -104,6 +104,93 @@ def test_address_shift_positions_are_fixed_point_fractions():
     assert y[100] == 0.25
 
 
+def test_interpolated_reads_weigh_the_two_neighbours_with_the_address_fraction():
+    """FX_OPT_TRAM_INTERP: a READ tap at DANE address a returns x0 + f * (x1 - x0), x0 at position a >> 11, x1 one position
+    further (one sample older), f = (a & 0x7ff) / 2048; f == 0 is x0 itself; writes ignore the fraction"""
+    text = ("itramsize 64 \ninput in 0\noutput out 0\nstatic rd\nidelay write, in, at, 0\nidelay read, rd, at, 10\nmacs out, 0, rd, 1.0\nend")
+    x = (np.arange(200, dtype=np.float32) * np.float32(2.0 ** -10)).astype(np.float32)   # a ramp: interpolation is exact on it
+    for frac in (0, 1024, 512, 1, 2047):
+        o = Oracle(1)
+        for opt in (OPT_DANE, OPT_SHIFT, OPT_INTERP):
+            o.set_option(opt)
+        assert o.load_text(text), o.errors()
+        o.set_register("&rd", float(np.float32((10 * 2048 + frac) * 2.0 ** -31)))
+        y = o.process_block(x)
+        n = np.arange(20, 200)
+        want = (x[n - 10].astype(np.float64) + (frac / 2048.0) * (x[n - 11].astype(np.float64) - x[n - 10].astype(np.float64))).astype(np.float32)
+        assert np.array_equal(bits(y[20:]), bits(want)), frac
+    # without the option the fraction is dropped (FX_OPT_TRAM_ADDR_SHIFT alone)
+    o = Oracle(1)
+    o.set_option(OPT_DANE)
+    o.set_option(OPT_SHIFT)
+    assert o.load_text(text)
+    o.set_register("&rd", float(np.float32((10 * 2048 + 1024) * 2.0 ** -31)))
+    y = o.process_block(x)
+    assert np.array_equal(bits(y[20:]), bits(x[10:190]))
+
+
+FRACTIONAL_TAPS = """itramsize 97 
+xtramsize 300 
+input in 0
+output out 0
+static w
+static r1
+static r2
+static xr
+idelay write, w, at, 0
+idelay read, r1, at, 7
+idelay read, r2, at, 19
+xdelay write, in, at, 3
+xdelay read, xr, at, 203
+macs w, in, 0, 0
+macs r1, r1, r2, 0.5
+macs out, r1, xr, 0.25
+end"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["default", "hip"])
+def test_gpu_interpolated_and_modulated_taps(gpu, kernel, monkeypatch):
+    """FX_OPT_TRAM_INTERP on the device: taps with a fixed fractional position (two scalar slots per tap) and the chorus, whose
+    tap position is computed per instance and per sample - generated code gathers it per lane (fp32 modulo, exact below 2^23) -
+    against the oracle, on the translated tier and on the HIP C++ kernel"""
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    if kernel != "default":
+        monkeypatch.setenv("FX_KERNEL", kernel)
+    n, s = 150, 3100
+    x = progs.stimulus(n, s)
+    for text, regs in ((FRACTIONAL_TAPS, ("&r1", "&r2", "&xr")), (CHORUS, ())):
+        b = gpu.Batch(n, 1, 0)
+        for opt in (gpu.OPT_TRAM_DANE, gpu.OPT_TRAM_ADDR_SHIFT, gpu.OPT_TRAM_INTERP):
+            b.set_option(opt)
+        assert b.load_text(text), b.errors()
+        pos = {"&r1": (7 * 2048 + 1024), "&r2": (19 * 2048 + 1), "&xr": (203 * 2048 + 2047)}
+        for reg in regs:
+            b.set_register(reg, float(np.float32(pos[reg] * 2.0 ** -31)))
+        depth = np.linspace(0.0, 0.0012, n).astype(np.float32)
+        speed = np.linspace(0.05, 0.6, n).astype(np.float32)
+        if text is CHORUS:
+            b.set_register_array("depth", depth)
+            b.set_register_array("speed", speed)
+        y = np.concatenate([b.process_block(x[:1000]), b.process_block(x[1000:1001]), b.process_block(x[1001:])], axis=0)
+        assert (b.info("kernel") >= 9) == (kernel == "default"), (kernel, b.info("kernel"))
+        assert b.ood_flags() == 0
+        for inst in (0, 63, 64, 99, n - 1):
+            o = Oracle(1)
+            for opt in (OPT_DANE, OPT_SHIFT, OPT_INTERP):
+                o.set_option(opt)
+            assert o.load_text(text)
+            for reg in regs:
+                o.set_register(reg, float(np.float32(pos[reg] * 2.0 ** -31)))
+            if text is CHORUS:
+                o.set_register("depth", float(depth[inst]))
+                o.set_register("speed", float(speed[inst]))
+            ref = o.process_block(x[:, inst].copy())
+            assert np.array_equal(bits(ref), bits(y[:, inst])), (kernel, inst)
+            assert b.instruction_counter_i(inst) == o.instruction_counter()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shift", [False, True], ids=["sample_positions", "dane_addresses"])
 @pytest.mark.parametrize("text", [TWO_TAPS, CHORUS], ids=["two_taps", "modulated_chorus"])
@@ -124,8 +211,9 @@ def test_gpu_matches_the_oracle_in_the_dane_model(gpu, text, shift, monkeypatch)
         b.set_register_array("speed", np.linspace(0.05, 0.6, n).astype(np.float32))
     ys = [b.process_block(x[:1000]), b.process_block(x[1000:])]
     y = np.concatenate(ys, axis=0)
-    # static taps are generated inline by the translator; per-instance positions (the modulated chorus) run on the HIP C++ kernel
-    assert (b.info("kernel") >= 9) == (text is TWO_TAPS)
+    # static taps are generated inline by the translator, and so are per-instance positions given as DANE addresses (the modulated
+    # chorus with the address shift: gathered per lane); per-instance positions in whole samples run on the HIP C++ kernel
+    assert (b.info("kernel") >= 9) == (text is TWO_TAPS or shift)
     assert b.ood_flags() == 0
     for inst in (0, 63, 64, 99, n - 1):
         o = Oracle(1)

@@ -128,6 +128,11 @@ def test_generated_code_of_the_benchmark_programs(name):
 def test_generated_code_of_the_dane_model():
     n, findings, problems = lint_program(P.CONFIGS["config5_dane"](), options=A.OPT_TRAM_DANE)
     assert n > 1000 and not findings and not problems, (findings[:5], problems[:5])
+    # taps gathered per lane (a modulated position) and interpolated reads between two slots
+    from test_dane_tram import CHORUS, FRACTIONAL_TAPS
+    for text in (CHORUS, FRACTIONAL_TAPS):
+        n, findings, problems = lint_program(text, options=A.OPT_TRAM_DANE | A.OPT_TRAM_ADDR_SHIFT | A.OPT_TRAM_INTERP)
+        assert n > 300 and not findings and not problems, (findings[:5], problems[:5])
 
 
 def test_generated_code_of_random_programs():

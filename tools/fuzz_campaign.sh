@@ -35,4 +35,6 @@ run "product cache x3"         FX_FUZZ_SCALE=3 timeout -k 10 900 python3 tools/f
 run "at scale 65553 x3"        FX_FUZZ_SCALE=3 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/stress_fuzz.py $((400*K)) 65553
 run "at scale 262144"          timeout -k 10 900 python3 tools/stress_fuzz.py $((400*K)) 262144
 run "benchmark programs"       timeout -k 10 900 python3 tools/stress_scale.py 3
+run "stages"                 timeout -k 10 900 python3 tools/fuzz_stages.py 2000000 $((1500*K))
+run "stages, interpreter off" FX_STAGES=4 timeout -k 10 900 python3 tools/fuzz_sweep.py 2700000 $((1500*K))
 echo done
