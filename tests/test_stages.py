@@ -125,3 +125,36 @@ def test_unstaged_code_is_unchanged_by_the_option():
     again, _, k, _ = fe.translate_staged(4, 0, 0, 0)
     assert k == 1 and again == plain
     assert "s_barrier" not in fe.translate(0, 0)[1]
+
+
+@needs_llvm
+def test_random_feed_forward_programs_plan_verify_lint_and_balance():
+    """the corpus of tools/fuzz_stages.py (sections with private state, SKIPs, LOG / EXP, delay lines and noise in the first
+    section): every plan that is made passes its symbolic check (a failing one is refused with a 'plan check' message - none
+    may occur), every generated stage re-assembles, lints clean and keeps its barriers balanced"""
+    import fuzz_stages
+    cut = 0
+    for seed in range(0, 120):
+        rng = np.random.default_rng(seed)
+        text = fuzz_stages.random_program(rng, int(rng.integers(2, 9)), int(rng.integers(2, 9)))
+        K = int(rng.choice([2, 3, 4, 8]))
+        fe = A.FrontEnd(1)
+        assert fe.load_text(text), (seed, fe.errors())
+        _, _, k, info = fe.translate_staged(K, 0, 0, 128)
+        if k < 2:
+            assert "plan check" not in fe.last_error(), (seed, fe.last_error())
+            continue
+        cut += 1
+        if seed % 4:
+            continue   # (the full check on a quarter of them: it assembles every stream)
+        listing, size, k, info, heads = L.staged_image_listing(fe, K, 128)
+        ins = L.disassemble_listing(listing)
+        assert ins[-1].addr + ins[-1].size == size, seed
+        assert not L.lint_hazards(ins, assume_entry_defs={"vcc", "s62", "s63", "s64", "s65", "s66", "s67"}), seed
+        assert not L.lint_index_mode(ins, entries=L.stream_entries(ins), any_base=True), seed
+        for st in range(k):
+            hs = set(heads[st])
+            for h in heads[st]:
+                at_head, at_exit = L.barrier_counts(ins, h, hs)
+                assert at_head <= {0, 1} and at_exit <= {3 * (k - 1 - st), 1 + 3 * (k - 1 - st)}, (seed, st)
+    assert cut > 40
