@@ -226,13 +226,17 @@ bool Batch::laneResident(int reg) const {
     return !lowDirty_ ? low_.rowOfReg[reg] >= 0 : (reg < (int)low_.rowOfReg.size() && low_.rowOfReg[reg] >= 0);
 }
 
-// how many pipeline stages to ask the translator for: until ~4 wavefronts per SIMD are in flight (256 CUs x 4 SIMDs);
-// FX_STAGES pins the number (1 = never)
+// How many pipeline stages to ask the translator for; FX_STAGES pins the number (1 = never).  Measured with config2's filter
+// chain at S = 2048 (tools/stage_probe.py, profiles/r03_stage_policy.txt): 8 stages are worth x 2.5 / 2.3 / 1.6 at 16 / 256 / 512
+// wavefronts of instances (up to two groups per CU), 4 stages + 4 % at 1 024 (one wavefront per SIMD becomes four, but every
+// stage adds ~26 instructions per sample), and from 2 048 wavefronts on the plain program is faster.
 int Batch::stagesWanted(int variant) const {
     if (const char* knob = std::getenv("FX_STAGES")) return std::max(1, std::min(16, std::atoi(knob)));
+    (void)variant;
     const int64_t waves = (n_ + 63) / 64;
-    const int64_t room = std::min<int64_t>(4096, (int64_t)1024 * kAsmWavesPerSimd[variant]);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(8, room / std::max<int64_t>(waves, 1)));
+    if (waves <= 512) return 8;
+    if (waves <= 1024) return 4;
+    return 1;
 }
 
 int Batch::ensureLowered() {
