@@ -466,7 +466,7 @@ enum : uint32_t {
     VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOP2_AND_B32 = 0x13, VOP2_XOR_B32 = 0x15, VOP2_LSHRREV_B32 = 0x10, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F32 = 0x1cb, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
-    SOP2_ADD_U32 = 0, SOP2_ADDC_U32 = 4,
+    SOP2_ADD_U32 = 0, SOP2_SUB_U32 = 1, SOP2_ADDC_U32 = 4,
     SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
     VOP2_ASHRREV_I32 = 0x11, VOP1_FLOOR_F32 = 0x1f, VOP1_CVT_F32_I32 = 5, VOPC_CMP_EQ_U32_ = 0xca,
 };
@@ -505,7 +505,9 @@ constexpr int kSTrackPtr[kMaxTracks] = {26, 30, 70};    // s[26:27] / s[30:31] /
 constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
 constexpr int kVRing = 30;                          // staged programs: lane * 4 + the LDS buffer of this sample's packets (sent and requested, see stageRequest)
-constexpr int kSLastSample = 8;                     // staged programs: nSamples - 1 (s8 is the interpreter's fetch offset: free in generated code)
+// staged programs (s4..s8 are the template's dispatch scratch and the interpreter's fetch offset: free in generated code)
+constexpr int kSGroupLeft = 7;                      // samples left until the group's barrier (counts down from group - 1)
+constexpr int kSSteadyLeft = 6;                     // samples the steady stream still has to run after this one (counts down from nSamples - 2)
 
 int32_t danePosition(uint32_t bits, bool shifted, int32_t size);  // (defined with the hoist planning below)
 
@@ -546,6 +548,37 @@ class Translator {
             anyLut = anyLut || r.w[0] == AS_LUT;
         }
         buildConstantPool(records, anyLut);
+        // staged programs: when the record words s22:s23 are only ever one value - the (1 - X) of the stage's INTERPs with one
+        // uniform X - and nothing calls a handler, the pair is loaded by the cold entry instead of in every sample
+        bool hoistOmx = false;
+        uint32_t omxLo = 0, omxHi = 0;
+        if (prog_.stage.count > 1) {
+            bool simple = true, any = false;
+            for (const MicroOp& r : records) {
+                const uint32_t slot = r.w[0];
+                if (slot == AS_ENDSAMPLE) break;
+                if (slot == AS_NOP || slot == AS_PRED || slot == AS_UNPRED || slot == AS_MOV || slot == AS_LIMIT || slot == AS_LIMITN) continue;
+                if (slot == AS_SKIP) { float w; int32_t c; if (!uniformSkip(r, &w, &c)) simple = false; continue; }
+                if (slot == AS_LUT) { if (r.w[6] & 1u) simple = false; continue; }
+                if (slot < AS_MACS || slot >= (uint32_t)kAsmSlots) { simple = false; continue; }
+                const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2;
+                if (family != 3 || !(kind & 2u) || kind == 7u) continue;
+                bool inlineConst = false;
+                const uint64_t omx = (uint64_t)r.w[6] | ((uint64_t)r.w[7] << 32);
+                for (const InlineD& k : kInlineF64) inlineConst = inlineConst || k.bits == omx;
+                if (inlineConst) continue;
+                if (any && (r.w[6] != omxLo || r.w[7] != omxHi)) simple = false;
+                any = true;
+                omxLo = r.w[6];
+                omxHi = r.w[7];
+            }
+            hoistOmx = simple && any;
+            if (hoistOmx) {
+                known_[6] = known_[7] = true;
+                value_[6] = omxLo;
+                value_[7] = omxHi;
+            }
+        }
         // ---- head: this sample's operands that come from memory
         const size_t headWord = e_.words();
         const StageInfo& G = prog_.stage;
@@ -663,11 +696,11 @@ class Translator {
             ringStep(kVRing);
             // ... every group-th sample (the same samples in every wavefront: they all count from 0)
             if (G.group > 1) {
-                e_.sop2(SOP2_AND_B32, "s_and_b32", sreg(kSTemp), sreg(kSSample), imm32((uint32_t)G.group - 1u));
-                e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp), imm32((uint32_t)G.group - 1u));
+                e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupLeft), sreg(kSGroupLeft), imm32(1));   // SCC = borrow: this was the group's last sample
                 Emitter::Fixup within = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
                 if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
                 e_.barrier();
+                e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupLeft), imm32((uint32_t)G.group - 1u));
                 e_.bind(within);
             } else {
                 if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
@@ -682,17 +715,18 @@ class Translator {
             e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(q), sreg(q), sreg(kSSampleBytes));
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(q + 1), sreg(q + 1), imm32(0));
         }
-        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSample), sreg(kSSample), imm32(1));
+        if (!staged || ring) e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSample), sreg(kSSample), imm32(1));   // (a later stage counts down instead)
         if (prog_.tramDane && prog_.uniformCursors) daneStep();
         if (!isLast_) {
             // loop while the sample after this one is not the block's last, then on to the last-sample stream
             if (staged) {
-                e_.sopc(SOPC_CMP_LT_U32, "s_cmp_lt_u32", sreg(kSSample), sreg(kSLastSample));
+                e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSSteadyLeft), sreg(kSSteadyLeft), imm32(1));   // SCC = borrow: the next sample is the last
+                if (!e_.branchBack(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
             } else {
                 e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSSample), imm32(1));
                 e_.sopc(SOPC_CMP_LT_U32, "s_cmp_lt_u32", sreg(kSTemp), sreg(kSNumSamples));
+                if (!e_.branchBack(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
             }
-            if (!e_.branchBack(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
             const int64_t delta = ((int64_t)nextBase_ - ((int64_t)base_ + (int64_t)e_.bytes() + 4)) / 4;
             if (delta < -32768 || delta > 32767) { if (err) *err = "last-sample stream out of branch range"; return false; }
             e_.sopp(SOPP_BRANCH, "s_branch", (uint32_t)delta & 0xffffu, true);
@@ -729,7 +763,12 @@ class Translator {
                 e_.barrier();
             }
             ringStep(kVRing);
-            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSLastSample), sreg(kSNumSamples), imm32(0xffffffffu));
+            e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupLeft), imm32((uint32_t)G.group - 1u));
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSteadyLeft), sreg(kSNumSamples), imm32(0xfffffffeu));
+            if (hoistOmx) {   // the one (1 - X) of the stage's INTERPs: set once, not once per sample
+                e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSRecord + 6), imm32(omxLo));
+                e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSRecord + 7), imm32(omxHi));
+            }
             if (ring) inputBurst(0, true);
         }
         for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
