@@ -25,11 +25,14 @@ def f32(hexstr, shape=None):
     return a.reshape(shape) if shape else a
 
 
-@pytest.fixture(params=["default", "asm", "asm_lds", "asm_v256", "hip"], ids=["xlate", "asm", "asm_lds", "asm_v256", "hip"])
+@pytest.fixture(params=["default", "unstaged", "asm", "asm_lds", "asm_v256", "hip"], ids=["xlate", "xlate_unstaged", "asm", "asm_lds", "asm_v256", "hip"])
 def tier(request, monkeypatch):
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
-    if request.param != "default":
+    monkeypatch.delenv("FX_STAGES", raising=False)
+    if request.param == "unstaged":   # (the fixtures' batches are small: by default their programs run as pipelines of stages where they can be cut)
+        monkeypatch.setenv("FX_STAGES", "1")
+    elif request.param != "default":
         monkeypatch.setenv("FX_KERNEL", request.param)
     return request.param
 

@@ -13,17 +13,21 @@ from pyoracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["default", "xlate_v256", "asm", "asm_v256", "asm_lds", 1, 2, 4],
-                ids=["xlate", "xlate_v256", "asm", "asm_v256", "asm_lds", "k1", "k2", "k4"])
+@pytest.fixture(params=["default", "unstaged", "xlate_v256", "asm", "asm_v256", "asm_lds", 1, 2, 4],
+                ids=["xlate", "xlate_unstaged", "xlate_v256", "asm", "asm_v256", "asm_lds", "k1", "k2", "k4"])
 def k(request, monkeypatch):
-    """kernel variant: the default choice (program translated to gfx950 code in the smallest VGPR build that
-    fits), the translation forced into the 256-VGPR build, the hand-written interpreter (smallest VGPR build,
+    """kernel variant: the default choice (program translated to gfx950 code; the small batches of these tests run it as a
+    pipeline of stages wherever the program can be cut), the same with FX_STAGES=1 (one wavefront runs the whole program: what
+    large batches get), the translation forced into the 256-VGPR build, the hand-written interpreter (smallest VGPR build,
     forced 256-VGPR build, forced LDS build), or the HIP C++ kernel with 1/2/4 instances per lane
     (FX_INST_PER_LANE pins it)"""
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_STAGES", raising=False)
     if request.param == "default":
         pass
+    elif request.param == "unstaged":
+        monkeypatch.setenv("FX_STAGES", "1")
     elif isinstance(request.param, str):
         monkeypatch.setenv("FX_KERNEL", request.param)
     else:
@@ -86,7 +90,7 @@ def test_config_programs_bit_exact(gpu, name, k):
             "config5": ("m", "u", "v", "w3", "ccr")}.get(name, ("ccr",))
     b, _ = check_batch(gpu, text, x, regs=regs)
     if isinstance(k, str):
-        want = {"default": tuple(range(9, 16)), "xlate_v256": (15,), "asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
+        want = {"default": tuple(range(9, 16)), "unstaged": tuple(range(9, 16)), "xlate_v256": (15,), "asm": (2, 3, 4, 5, 6, 7, 8), "asm_v256": (8,), "asm_lds": (1,)}[k]
         assert b.info("kernel") in want and b.info("inst_per_lane") == 1
     else:
         assert b.info("kernel") == 0 and b.info("inst_per_lane") == k
@@ -376,7 +380,7 @@ def test_saturation_elision_is_sound(gpu, k):
         assert np.array_equal(bits(ref), bits(y[:, n])), "instance %d" % n
         for r in ("a", "b", "t", "u", "w", "rd", "out"):
             assert b.get_register_bits_i(r, n) == o.get_register_bits(r), "instance %d register %s" % (n, r)
-    if k == "default":
+    if k in ("default", "unstaged"):
         assert b.info("xlate_unsaturated") >= 3
 
 
@@ -487,7 +491,7 @@ def test_delay_inside_skip_shadow(gpu, k):
             "macs out, rd, b, 0.5\nend")
     x = progs.stimulus(130, 200)
     b, _ = check_batch(gpu, text, x, regs=("rd", "b", "t", "ccr"))
-    if k == "default":
+    if k in ("default", "unstaged"):
         assert b.info("xlate_called") >= 4  # the four TRAM instructions run in the interpreter's per-lane handlers
 
 
