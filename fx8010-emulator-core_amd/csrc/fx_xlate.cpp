@@ -454,9 +454,9 @@ class Emitter {
 enum : uint32_t {
     VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
-    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_LE_F32 = 0x43, VOPC_CMP_GT_U32 = 0xcc,
+    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_NE_U32 = 0xcd, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_LE_F32 = 0x43, VOPC_CMP_GT_U32 = 0xcc,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6, SOPP_CBRANCH_VCCNZ = 7,
-    SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
+    SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_MIN_U32 = 7, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
     SOPC_CMP_GT_I32 = 2, SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
@@ -506,8 +506,12 @@ constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_as
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
 constexpr int kVRing = 30;                          // staged programs: lane * 4 + the LDS buffer of this sample's packets (sent and requested, see stageRequest)
 // staged programs (s4..s8 are the template's dispatch scratch and the interpreter's fetch offset: free in generated code)
-constexpr int kSGroupLeft = 7;                      // samples left until the group's barrier (counts down from group - 1)
-constexpr int kSSteadyLeft = 6;                     // samples the steady stream still has to run after this one (counts down from nSamples - 2)
+// A steady stream: s7 counts down to the next event - the group's barrier or the end of the steady stream - from s5 - 1; when it
+// borrows, s8 (samples left in the group) and s6 (steady samples left) both go down by s5 and whichever reached 0 is served.
+// A last-sample stream: s7 = samples of the group still to come after this one (the barrier follows when it borrows).
+constexpr int kSGroupLeft = 7;
+constexpr int kSSteadyLeft = 6;
+constexpr int kSLoaded = 5, kSGroupSamples = 8;
 
 int32_t danePosition(uint32_t bits, bool shifted, int32_t size);  // (defined with the hoist planning below)
 
@@ -621,8 +625,8 @@ class Translator {
                 if (!row((uint32_t)G.recvRows[i], &v)) { if (err) *err = err_; return false; }
                 e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(v), vreg(G.recvTmp + (int)i));
             }
-            if (fast_)
-                for (int r : G.recvRows) taintCheckRow(vrow((uint32_t)r));
+            // (what arrives is not checked row by row: a stage whose packets may hold anything but clean values - it runs its
+            // exact stream - says so in its flag row, which the receiver reads behind every barrier: stageFlagCheck)
             if (!isLast_) stageRequest();
         }
         if (ring) {
@@ -646,7 +650,9 @@ class Translator {
         if (usesSkipCounter) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVNumSkip), imm32(0));  // numSkip is local to process() (FX8010.cpp:1030)
         index_ = records.size();
         returns_[syncIndex(0)] = base_ + (uint32_t)e_.bytes();
-        if (fast_ && !leaveIfTainted((*exactReturns_)[syncIndex(0)])) { if (err) *err = err_; return false; }
+        // (a later stage of a pipelined program has nothing at its head that could taint it: its flag check sits behind the barriers)
+        const bool cleanHead = staged && G.index > 0 && H.leadCount == 0 && !ring && prog_.trackRows.empty();
+        if (fast_ && !cleanHead && !leaveIfTainted((*exactReturns_)[syncIndex(0)])) { if (err) *err = err_; return false; }
 
         // ---- the program
         products_.assign((size_t)(fast_ ? prog_.cseEntries : 0), Product());
@@ -688,12 +694,18 @@ class Translator {
             // hand this sample's live rows to the next stage; ONE barrier per step on every path through a sample (all
             // wavefronts of the workgroup execute the same number of them).  The wait in front of it covers LAST step's writes
             // and this step's request - everything but the writes just issued.
+            // (an exact stream's packets may hold non-finite values: its flag row tells the next stage, before the packets do)
+            if (!fast_ && G.index + 1 < G.count) e_.dsWriteB32(kVLane4, kVClassMask, G.flagBase + 256u * (uint32_t)G.index);
             for (size_t i = 0; i < G.sendRows.size(); ++i) {
                 int v;
                 if (!row((uint32_t)G.sendRows[i], &v)) { if (err) *err = err_; return false; }
                 e_.dsWriteB32(kVRing, v, G.bufBase + G.sendOff + 256u * (uint32_t)i);
             }
             ringStep(kVRing);
+        }
+        // (a steady stream of a staged program: barrier and loop control by ONE down-counter, behind the PCM store - below)
+        const bool oneCounter = staged && !isLast_;
+        if (staged && !oneCounter) {
             // ... every group-th sample (the same samples in every wavefront: they all count from 0)
             if (G.group > 1) {
                 e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupLeft), sreg(kSGroupLeft), imm32(1));   // SCC = borrow: this was the group's last sample
@@ -701,10 +713,12 @@ class Translator {
                 if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
                 e_.barrier();
                 e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupLeft), imm32((uint32_t)G.group - 1u));
+                if (!isLast_ && !stageFlagCheck(1)) { if (err) *err = err_; return false; }
                 e_.bind(within);
             } else {
                 if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
                 e_.barrier();
+                if (!isLast_ && !stageFlagCheck(1)) { if (err) *err = err_; return false; }
             }
         }
         if (storesPerSample > 0) pcmAccess(false, kSPcmOut, false);
@@ -717,7 +731,37 @@ class Translator {
         }
         if (!staged || ring) e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSample), sreg(kSSample), imm32(1));   // (a later stage counts down instead)
         if (prog_.tramDane && prog_.uniformCursors) daneStep();
-        if (!isLast_) {
+        if (oneCounter) {
+            // s7 counts the samples up to the next event - the group's barrier or the end of the steady stream, whichever
+            // comes first (s5 = what it was loaded with, s8 = samples of the group, s6 = steady samples still to run when it
+            // was loaded): one subtract and one branch per sample; the bookkeeping runs once per group
+            e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupLeft), sreg(kSGroupLeft), imm32(1));   // SCC = borrow: an event is due
+            if (!e_.branchBack(SOPP_CBRANCH_SCC0, "s_cbranch_scc0", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
+            e_.cold(true);
+            e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupSamples), sreg(kSGroupSamples), sreg(kSLoaded));
+            e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSSteadyLeft), sreg(kSSteadyLeft), sreg(kSLoaded));
+            e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSGroupSamples), imm32(0));
+            Emitter::Fixup within = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+            // the group's barrier: ONE per `group` samples in every wavefront of the workgroup (they all count from 0).  The
+            // wait in front of it covers the packets of the previous samples - everything but the writes just issued
+            if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
+            e_.barrier();
+            e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupSamples), imm32((uint32_t)G.group));
+            if (!stageFlagCheck(1)) { if (err) *err = err_; return false; }
+            e_.bind(within);
+            e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSSteadyLeft), imm32(0));
+            Emitter::Fixup done = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
+            e_.sop2(SOP2_MIN_U32, "s_min_u32", sreg(kSLoaded), sreg(kSSteadyLeft), sreg(kSGroupSamples));
+            e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupLeft), sreg(kSLoaded), imm32(1));
+            if (!e_.branchBack(SOPP_BRANCH, "s_branch", headWord)) { if (err) *err = "translated loop too long for a branch"; return false; }
+            e_.bind(done);
+            // (the last-sample stream counts the rest of the group down from its length - 1)
+            e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupLeft), sreg(kSGroupSamples), imm32(1));
+            e_.cold(false);
+            const int64_t delta = ((int64_t)nextBase_ - ((int64_t)base_ + (int64_t)e_.bytes() + 4)) / 4;
+            if (delta < -32768 || delta > 32767) { if (err) *err = "last-sample stream out of branch range"; return false; }
+            e_.sopp(SOPP_BRANCH, "s_branch", (uint32_t)delta & 0xffffu, true);
+        } else if (!isLast_) {
             // loop while the sample after this one is not the block's last, then on to the last-sample stream
             if (staged) {
                 e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSSteadyLeft), sreg(kSSteadyLeft), imm32(1));   // SCC = borrow: the next sample is the last
@@ -756,15 +800,30 @@ class Translator {
             // that sample's rows.
             // (the request in front of the first sample: packet 0 of the cut in front of this stage, buffer `index`; then the
             // pointer stands at index + 1 for sample 0)
+            if (G.index + 1 < G.count) {
+                // this stage's flag row: clean so far (the next stage first reads it behind its last barrier in front of its first
+                // sample - behind this wavefront's first barrier, whichever that is)
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), imm32(0));
+                e_.dsWriteB32(kVLane4, 2, G.flagBase + 256u * (uint32_t)G.index);
+                e_.waitLgkm0();
+            }
             e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVRing, imm32((uint32_t)G.index * G.bufStride), kVLane4);
             for (int k = 0; k + 1 < kStageDepth * G.index; ++k) e_.barrier();
             if (G.index > 0) {
                 if (!G.recvRows.empty()) stageRequest();
                 e_.barrier();
+                index_ = records.size();
+                if (!stageFlagCheck(2)) { if (err) *err = err_; return false; }
             }
             ringStep(kVRing);
-            e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupLeft), imm32((uint32_t)G.group - 1u));
-            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSteadyLeft), sreg(kSNumSamples), imm32(0xfffffffeu));
+            if (isLast_) {
+                e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupLeft), imm32((uint32_t)G.group - 1u));
+            } else {
+                e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSteadyLeft), sreg(kSNumSamples), imm32(0xffffffffu));   // nSamples - 1 steady samples (>= 1)
+                e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupSamples), imm32((uint32_t)G.group));
+                e_.sop2(SOP2_MIN_U32, "s_min_u32", sreg(kSLoaded), sreg(kSSteadyLeft), sreg(kSGroupSamples));
+                e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupLeft), sreg(kSLoaded), imm32(1));
+            }
             if (hoistOmx) {   // the one (1 - X) of the stage's INTERPs: set once, not once per sample
                 e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSRecord + 6), imm32(omxLo));
                 e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSRecord + 7), imm32(omxHi));
@@ -849,6 +908,20 @@ class Translator {
         const StageInfo& G = prog_.stage;
         e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", v, imm32(G.bufStride), v);
         e_.vop2(VOP2_AND_B32, "v_and_b32_e32", v, imm32(4u * (uint32_t)G.group * G.bufStride - 1u), v);
+    }
+    // Behind a barrier: has the stage in front of this one left its fast stream?  Its packets of the step that just ended -
+    // consumed three steps from now - may then hold non-finite values, and this wavefront continues in ITS exact stream, at the
+    // same point there (sync point `key` of the end of the stream: 1 = behind the group's barrier, 2 = behind the last barrier
+    // of the cold entry).  The exact stream only notes where that point is.
+    bool stageFlagCheck(int key) {
+        const StageInfo& G = prog_.stage;
+        if (G.index == 0) return true;
+        if (!fast_) { returns_[syncIndex(key)] = base_ + (uint32_t)e_.bytes(); return true; }
+        e_.dsReadB32(2, kVLane4, G.flagBase + 256u * (uint32_t)(G.index - 1));
+        e_.waitLgkm0();
+        e_.vopc(VOPC_CMP_NE_U32, "v_cmp_ne_u32_e32", imm32(0), 2);
+        e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
+        return leaveIfTainted((*exactReturns_)[syncIndex(key)]);
     }
     // request the rows of the NEXT sample this stage will work on (the previous stage wrote them two steps ago).  Packet s of
     // the cut behind stage c lives in buffer (s + c + 1) mod ring: what stage k sends for its sample s and what it requests for
@@ -2930,23 +3003,48 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
     const int total = cum[n];
     if (total < 16 * wanted) wanted = std::max(1, total / 16);
     if (wanted < 2) return no("too little work per stage");
+    // The slowest stage sets the pace of the whole workgroup (everybody meets at the step's barrier), and a stage's time is its
+    // share of the program PLUS what the pipeline costs it: stage 0 fetches the PCM input (ring of bursts, index mode), the last
+    // writer of an output latch stores PCM, every row received costs a move and a request, every row sent a write.  Cuts = the allowed boundaries that minimise the largest such sum (dynamic programme over boundaries; a
+    // stage with less than a quarter of an even share of the program is not worth a barrier: fewer stages then).
+    bool anyInputRow = false;
+    for (int r : prog.inRows) anyInputRow = anyInputRow || r >= 0;
+    static const bool flat = std::getenv("FX_STAGES_BALANCE") && std::atoi(std::getenv("FX_STAGES_BALANCE")) == 0;   // diagnostics: the program's share only
+    const int kInputCost = anyInputRow && !flat ? 14 : 0, kOutputCost = flat ? 0 : 7, kRecvCost = flat ? 0 : 3, kSendCost = flat ? 0 : 1, kFixedCost = 8;
+    std::vector<size_t> bounds{0};
+    for (size_t b = 1; b < n; ++b)
+        if (allowed[b]) bounds.push_back(b);
+    bounds.push_back(n);
+    const size_t nb = bounds.size();
+    auto stageCost = [&](size_t lo, size_t hi) {   // indices into bounds
+        const size_t from = bounds[lo], to = bounds[hi];
+        int c = cum[to] - cum[from] + kFixedCost;
+        if (from == 0) c += kInputCost; else c += kRecvCost * (int)liveAt[from].size();
+        if (to == n) c += kOutputCost; else c += kSendCost * (int)liveAt[to].size();
+        return c;
+    };
     std::vector<int> cuts;
-    for (int k = 1; k < wanted; ++k) {
-        const double ideal = (double)total * k / wanted;
-        int best = -1;
-        double bestDist = 1e30;
-        for (size_t b = (cuts.empty() ? 1 : (size_t)cuts.back() + 1); b < n; ++b) {
-            if (!allowed[b]) continue;
-            const double d = std::fabs((double)cum[b] - ideal);
-            if (d < bestDist) { bestDist = d; best = (int)b; }
+    for (int K = std::min<int>(wanted, (int)nb - 1); K >= 2 && cuts.empty(); --K) {
+        const int kInf = 1 << 30;
+        // best[k][j]: the smallest possible largest-stage cost of records [0, bounds[j]) in k stages
+        std::vector<std::vector<int>> best((size_t)K + 1, std::vector<int>(nb, kInf)), from((size_t)K + 1, std::vector<int>(nb, -1));
+        best[0][0] = 0;
+        for (int k = 1; k <= K; ++k)
+            for (size_t j = 1; j < nb; ++j)
+                for (size_t i = 0; i < j; ++i) {
+                    if (best[(size_t)k - 1][i] == kInf) continue;
+                    if ((cum[bounds[j]] - cum[bounds[i]]) * 4 * wanted < total) continue;
+                    const int c = std::max(best[(size_t)k - 1][i], stageCost(i, j));
+                    if (c < best[(size_t)k][j]) { best[(size_t)k][j] = c; from[(size_t)k][j] = (int)i; }
+                }
+        if (best[(size_t)K][nb - 1] == kInf) continue;
+        size_t j = nb - 1;
+        for (int k = K; k >= 1; --k) {
+            j = (size_t)from[(size_t)k][j];
+            if (k > 1) cuts.push_back((int)bounds[j]);
         }
-        if (best < 0) break;
-        // (a cut that leaves less than a quarter of a stage's share on either side is not worth a barrier)
-        const int before = cum[(size_t)best] - (cuts.empty() ? 0 : cum[(size_t)cuts.back()]);
-        if (before * 4 * wanted < total) continue;
-        cuts.push_back(best);
+        std::reverse(cuts.begin(), cuts.end());
     }
-    while (!cuts.empty() && (total - cum[(size_t)cuts.back()]) * 4 * wanted < total) cuts.pop_back();
     if (std::getenv("FX_STAGES_DEBUG")) {
         std::string line;
         for (size_t b = 0; b <= n; ++b) line += allowed[b] ? '+' : '.';
@@ -3089,7 +3187,9 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
         while (pow2 < bufStride) pow2 <<= 1;
         bufStride = pow2;
     }
-    const uint32_t bufBase = (tableBytes + 255u) & ~255u;
+    // (in front of the ring: one flag row per stage - "my packets may hold non-finite values", Translator::stageFlagCheck)
+    const uint32_t flagBase = (tableBytes + 255u) & ~255u;
+    const uint32_t bufBase = flagBase + 256u * (uint32_t)K;
     const uint32_t scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0), behind the ring
     int group = kStageGroupMax;
     while (group > 1 && bufBase + 4u * (uint32_t)group * bufStride + scratchBytes > ldsBudget) group /= 2;
@@ -3122,6 +3222,7 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
         p.stage.index = k;
         p.stage.count = K;
         p.stage.bufBase = bufBase;
+        p.stage.flagBase = flagBase;
         p.stage.bufStride = bufStride;
         p.stage.group = group;
         if (k > 0) { p.stage.recvRows = plan.live[(size_t)k - 1]; p.stage.recvOff = cutOff[(size_t)k - 1]; }

@@ -85,6 +85,7 @@ struct StageInfo {
     std::vector<int> recvRows, sendRows;  // rows received from stage index-1 at the head / handed to stage index+1 at the tail
     uint32_t recvOff = 0, sendOff = 0;    // LDS byte offset of those packets inside a buffer (row i at +256 i)
     uint32_t bufBase = 0, bufStride = 0;  // the 4 * group buffers: bufBase + (sample mod (4 * group)) * bufStride (stride a power of two)
+    uint32_t flagBase = 0;                // LDS rows [stage][lane]: non-zero = that stage runs its exact stream (its packets may hold non-finite values)
     uint32_t storeMask = ~0u;             // channels whose PCM output this stage stores
     int group = 1;                        // samples between two barriers (a power of two); the ring has 4 * group buffers
     // Latencies stay off the step (a step = the `group` samples between two barriers): stage k runs 3k steps behind stage 0.

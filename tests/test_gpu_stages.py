@@ -75,17 +75,25 @@ def test_small_batches_are_staged_by_default(gpu, stages):
         assert c.info("waves_per_wg") == 1, name  # one recurrence from end to end: no legal cut (tests/test_stages.py)
 
 
-def test_non_finite_values_cross_the_cuts(gpu, stages):
-    """a NaN / Inf that enters stage 0 reaches the later stages through the packets: each stage leaves its fast stream on its
-    own (the rows it receives are checked like values from memory)"""
-    stages(4)
-    N, S = 130, 40
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_non_finite_values_cross_the_cuts(gpu, stages, k):
+    """a NaN / Inf that enters stage 0 reaches the later stages through the packets.  A stage that leaves its fast stream says
+    so in its flag row (LDS), and the next stage reads that row behind every barrier - three barriers before the first such
+    packet is consumed - and continues in its own exact stream: also in blocks shorter than a group of samples (the check
+    behind the cold entry's barriers), in the last sample of a block, and at a block's very first sample"""
+    stages(k)
+    N, S = 130, 64
     x = progs.stimulus(N, S).copy()
     x[5, 3] = np.nan
     x[9, 64] = -np.inf
     x[17, 129] = np.float32(np.nan)
     x.view(np.uint32)[22, 70] = 0xFFA00123   # a signalling NaN with a payload
-    run_and_compare(gpu, progs.config2(), x, [(0, S)], ["t", "s0", "s12", "s30", "out", "ccr"])
+    x[39, 1] = np.inf                         # the last sample of a block
+    x[40, 65] = np.nan                        # a block of one sample
+    x[41, 66] = np.nan                        # the first sample of a block of two
+    x[47, 2] = -np.nan                        # in a block of five, behind the middle
+    x[63, 100] = np.nan                       # the very last sample
+    run_and_compare(gpu, progs.config2(), x, [(0, 40), (40, 41), (41, 43), (43, 48), (48, S)], ["t", "s0", "s12", "s30", "out", "ccr"])
 
 
 def test_delay_lines_noise_skip_and_tables_in_stages(gpu, stages):
