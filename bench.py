@@ -408,7 +408,8 @@ def main():
     # meet over gloo instead of RCCL, which refuses two ranks on one device - same code path otherwise
     rehearsal = os.environ.get("FX_BENCH_REHEARSAL") == "1"
     n_visible = max(torch.cuda.device_count(), 1)
-    if rehearsal:
+    if rehearsal or local >= n_visible:
+        # (a launcher that shows every rank only its own GPU - ROCR_VISIBLE_DEVICES per rank - makes that GPU ordinal 0)
         local = local % n_visible
     if args.sharded:
         if world != 1:
