@@ -227,15 +227,15 @@ bool Batch::laneResident(int reg) const {
 }
 
 // How many pipeline stages to ask the translator for; FX_STAGES pins the number (1 = never).  Measured with config2's filter
-// chain at S = 2048 (tools/stage_probe.py, profiles/r03_stage_policy.txt): 8 stages are worth x 2.5 / 2.3 / 1.6 at 16 / 256 / 512
-// wavefronts of instances (up to two groups per CU), 4 stages + 4 % at 1 024 (one wavefront per SIMD becomes four, but every
-// stage adds ~26 instructions per sample), and from 2 048 wavefronts on the plain program is faster.
+// chain at S = 2048 (tools/stage_probe.py, profiles/r03b_stage_policy.txt): 8 stages are worth x 3.1 / 2.7 / 1.7 at 16 / 256 / 512
+// wavefronts of instances (up to two groups per CU), 4 stages + 30 % / + 8 % / + 7 % at 768 / 1 024 / 1 536 (one wavefront per SIMD
+// becomes four, but every stage adds ~11 instructions per sample), and from 1 792 wavefronts on the plain program is faster.
 int Batch::stagesWanted(int variant) const {
     if (const char* knob = std::getenv("FX_STAGES")) return std::max(1, std::min(16, std::atoi(knob)));
     (void)variant;
     const int64_t waves = (n_ + 63) / 64;
     if (waves <= 512) return 8;
-    if (waves <= 1024) return 4;
+    if (waves <= 1536) return 4;
     return 1;
 }
 

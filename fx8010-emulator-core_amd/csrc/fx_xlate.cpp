@@ -807,7 +807,8 @@ class Translator {
                 e_.dsWriteB32(kVLane4, 2, G.flagBase + 256u * (uint32_t)G.index);
                 e_.waitLgkm0();
             }
-            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVRing, imm32((uint32_t)G.index * G.bufStride), kVLane4);
+            // (the ring has 4 * group buffers: fewer than stages when the LDS budget allows only a group of one or two)
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVRing, imm32(((uint32_t)G.index % (4u * (uint32_t)G.group)) * G.bufStride), kVLane4);
             for (int k = 0; k + 1 < kStageDepth * G.index; ++k) e_.barrier();
             if (G.index > 0) {
                 if (!G.recvRows.empty()) stageRequest();
@@ -3192,6 +3193,10 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     const uint32_t bufBase = flagBase + 256u * (uint32_t)K;
     const uint32_t scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0), behind the ring
     int group = kStageGroupMax;
+    if (const char* knob = std::getenv("FX_STAGES_GROUP")) {   // tests: a shorter ring than the LDS would allow (1, 2, 4)
+        const int g = std::atoi(knob);
+        if (g == 1 || g == 2 || g == 4) group = g;
+    }
     while (group > 1 && bufBase + 4u * (uint32_t)group * bufStride + scratchBytes > ldsBudget) group /= 2;
     if (bufBase + bufStride > 0xff00u || bufBase + 4u * (uint32_t)group * bufStride + scratchBytes > std::min(ldsBudget, 160u * 1024u)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
     std::vector<std::vector<uint32_t>> code((size_t)K * 4 + 1);

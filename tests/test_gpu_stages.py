@@ -58,6 +58,19 @@ def test_config2_in_stages(gpu, stages, k):
     assert b.info("waves_per_wg") == k and b.info("kernel") >= 9
 
 
+@pytest.mark.parametrize("group", [1, 2, 4])
+def test_rings_shorter_than_the_pipeline(gpu, stages, group, monkeypatch):
+    """the packet ring has 4 x group buffers; with little LDS per workgroup (large batches, wide packets) group drops to 2 or 1 and
+    the ring is shorter than the pipeline has stages: the first request of stage k >= ring must wrap like every later one
+    (found at 98 304 instances x 8 stages: stages 4 .. 7 read their first packet from beyond the ring)"""
+    stages(8)
+    monkeypatch.setenv("FX_STAGES_GROUP", str(group))
+    N, S = 200, 50
+    x = progs.stimulus(N, S + 9)
+    b = run_and_compare(gpu, progs.config2(), x, [(0, S), (S, S + 1), (S + 1, S + 9)], ["t", "s0", "s7", "s15", "s30", "out", "ccr", "in"])
+    assert b.info("waves_per_wg") == 8
+
+
 def test_small_batches_are_staged_by_default(gpu, stages):
     stages(None)
     b = gpu.Batch(300, 1, 0)

@@ -75,6 +75,12 @@ def main():
         text = random_program(rng, int(rng.integers(2, 9)), int(rng.integers(2, 9)))
         K = int(rng.choice([2, 3, 4, 8]))
         os.environ["FX_STAGES"] = str(K)
+        # one program in three with a packet ring shorter than the LDS would allow (4, 8 or 16 buffers: rings shorter than the pipeline)
+        ring = int(rng.choice([0, 0, 0, 0, 1, 2, 4]))
+        if ring:
+            os.environ["FX_STAGES_GROUP"] = str(ring)
+        else:
+            os.environ.pop("FX_STAGES_GROUP", None)
         x = P.stimulus(N, S, first_instance=seed)
         if seed % 5 == 0:   # non-finite words: the taint hand-over between stages
             x = x.copy()
@@ -110,6 +116,7 @@ def main():
                 print("MISMATCH seed %d instance %d stages %d (kernel %d, waves/wg %d): %s\n%s" % (seed, n, K, b.info("kernel"), b.info("waves_per_wg"), "; ".join(what), text if os.environ.get("FX_FUZZ_TEXT") else ""), flush=True)
                 failures.append(seed)
                 break
+    os.environ.pop("FX_STAGES_GROUP", None)
     print("stage fuzz: %d programs, waves per workgroup %s, failures %s" % (count, dict(sorted(cut.items())), failures))
     return 1 if failures else 0
 
