@@ -71,6 +71,23 @@ def test_rings_shorter_than_the_pipeline(gpu, stages, group, monkeypatch):
     assert b.info("waves_per_wg") == 8
 
 
+@pytest.mark.parametrize("width", [4, 12])
+def test_wide_packets(gpu, stages, width):
+    """`width` parallel one-pole chains advance side by side: 5 or 13 rows cross every cut.  With 13 rows a buffer takes 32 KB and
+    the LDS holds a ring of four for eight stages (group = 1) - by the default policy, no knob"""
+    stages(None)
+    W = width
+    text = ("input in 0\noutput out 0\ncontrol k = 0.25\n" + "".join("static a%d\n" % i for i in range(W))
+            + "".join("static s%d_%d\n" % (i, j) for i in range(W) for j in range(6))
+            + "".join("macs a%d, in, in, 0.%02d\n" % (i, i + 1) for i in range(W))
+            + "".join("interp s%d_%d, s%d_%d, k, a%d\nmacs a%d, s%d_%d, in, 0.05\n" % (i, j, i, j, i, i, i, j) for j in range(6) for i in range(W))
+            + "macs out, 0, a0, 1.0\n" + "".join("macs out, out, a%d, 0.1\n" % i for i in range(1, W)) + "end")
+    N, S = 130, 45
+    x = progs.stimulus(N, S)
+    b = run_and_compare(gpu, text, x, [(0, 30), (30, 31), (31, S)], ["a0", "a%d" % (W - 1), "s0_0", "s%d_5" % (W - 1), "out", "ccr"])
+    assert b.info("waves_per_wg") == 8
+
+
 def test_small_batches_are_staged_by_default(gpu, stages):
     stages(None)
     b = gpu.Batch(300, 1, 0)
