@@ -71,6 +71,21 @@ def test_rings_shorter_than_the_pipeline(gpu, stages, group, monkeypatch):
     assert b.info("waves_per_wg") == 8
 
 
+@pytest.mark.parametrize("k,group", [(8, None), (8, 1), (3, 2), (16, None)])
+def test_every_block_length(gpu, stages, k, group, monkeypatch):
+    """blocks of 1, 2, 3 .. 18 samples one after the other (state carried): every position of a block's end inside a group of
+    samples, blocks shorter than a group, shorter than the pipeline is deep"""
+    stages(k)
+    if group:
+        monkeypatch.setenv("FX_STAGES_GROUP", str(group))
+    N = 70
+    cuts = [0]
+    for n in range(1, 19):
+        cuts.append(cuts[-1] + n)
+    x = progs.stimulus(N, cuts[-1])
+    run_and_compare(gpu, progs.config2(), x, list(zip(cuts[:-1], cuts[1:])), ["t", "s0", "s9", "s30", "out", "ccr"])
+
+
 @pytest.mark.parametrize("width", [4, 12])
 def test_wide_packets(gpu, stages, width):
     """`width` parallel one-pole chains advance side by side: 5 or 13 rows cross every cut.  With 13 rows a buffer takes 32 KB and
