@@ -35,7 +35,7 @@ struct AsmArgs {
     int oodRow, countLo, countHi, staticCount;
     int lutX1Off;
     int initOff;  // translated programs: byte offset (from the kernel entry) of code to run once before the first sample, 0 = none
-    const uint32_t* tracks;  // translated programs with control tracks: TrackHeader[kMaxTracks] + values (fx_xlate.hpp), else nullptr
+    const uint32_t* tracks;  // translated programs with control tracks: the block's TrackEvent list + values (fx_xlate.hpp), else nullptr
     const uint32_t* stages;  // translated programs cut into stages: StageDescriptor[nStages] (fx_xlate.hpp), else nullptr
     int nStages;             // wavefronts per workgroup (0 / 1: the whole program in one)
     int pad0;

@@ -593,13 +593,24 @@ int Batch::setRegisterTrack(const std::string& key, const float* values, int nSt
     return 0;
 }
 
-// header + values of the armed schedules -> dTracks_ (on the launch stream, ahead of the kernel); the schedules are one-shot
+// the events of the armed schedules, sorted by sample, and their values -> dTracks_ (on the launch stream, ahead of the kernel);
+// the schedules are one-shot
 int Batch::uploadTracks(int nSamples, hipStream_t s) {
-    if (!tracksArmed() && tracksClear_ && dTracks_) return 0;  // nothing armed and the device header already says so
-    const size_t headerWords = (size_t)kMaxTracks * 4;
-    size_t words = headerWords;
-    for (const PendingTrack& t : pendingTracks_)
-        if (t.steps > 0) words += t.perInstance ? (size_t)t.steps * (size_t)nPad_ : (size_t)t.steps;
+    if (!tracksArmed() && tracksClear_ && dTracks_) return 0;  // nothing armed and the device list already says so
+    struct Due { uint32_t sample, slot, step; };
+    std::vector<Due> due;
+    std::vector<int> used(pendingTracks_.size(), 0);
+    size_t valueWords = 0;
+    for (size_t k = 0; k < pendingTracks_.size(); ++k) {
+        const PendingTrack& t = pendingTracks_[k];
+        if (t.steps <= 0) continue;
+        used[k] = std::min(t.steps, (nSamples + t.period - 1) / t.period);  // changes that fall inside this block
+        for (int q = 0; q < used[k]; ++q) due.push_back({(uint32_t)q * (uint32_t)t.period, (uint32_t)k, (uint32_t)q});
+        valueWords += t.perInstance ? (size_t)used[k] * (size_t)nPad_ : (size_t)used[k];
+    }
+    std::stable_sort(due.begin(), due.end(), [](const Due& a, const Due& b) { return a.sample < b.sample; });  // (same sample: by slot, as armed)
+    const size_t listWords = (due.size() + 1) * 4;
+    const size_t words = listWords + valueWords;
     if (words * 4 > tracksCap_) {
         waitLastLaunch();
         (void)hipFree(dTracks_);
@@ -611,28 +622,38 @@ int Batch::uploadTracks(int nSamples, hipStream_t s) {
     }
     waitLastLaunch();  // trackStage_ / dTracks_ of the previous block are free again
     trackStage_.assign(words, 0);
-    size_t at = headerWords;
+    std::vector<size_t> valuesAt(pendingTracks_.size(), 0);
+    size_t at = listWords;
     for (size_t k = 0; k < pendingTracks_.size(); ++k) {
         PendingTrack& t = pendingTracks_[k];
         if (t.steps <= 0) continue;
-        const int used = std::min(t.steps, (nSamples + t.period - 1) / t.period);  // changes that fall inside this block
-        TrackHeader h{(uint32_t)t.period, (uint32_t)used, (uint32_t)(at * 4), t.perInstance ? (uint32_t)(nPad_ * 4) : 4u};
-        std::memcpy(&trackStage_[k * 4], &h, sizeof(h));
+        valuesAt[k] = at;
         const int reg = trackRegs_[k];
         if (t.perInstance) {
-            for (int q = 0; q < used; ++q) std::memcpy(&trackStage_[at + (size_t)q * (size_t)nPad_], &t.values[(size_t)q * (size_t)n_], (size_t)n_ * 4);
-            at += (size_t)t.steps * (size_t)nPad_;
+            for (int q = 0; q < used[k]; ++q) std::memcpy(&trackStage_[at + (size_t)q * (size_t)nPad_], &t.values[(size_t)q * (size_t)n_], (size_t)n_ * 4);
+            at += (size_t)used[k] * (size_t)nPad_;
             forcedLane_[(size_t)reg] = 1;
         } else {
-            std::memcpy(&trackStage_[at], t.values.data(), (size_t)t.steps * 4);
-            at += (size_t)t.steps;
-            hostValue_[(size_t)reg] = t.values[(size_t)used - 1];  // what every instance holds after the block
+            std::memcpy(&trackStage_[at], t.values.data(), (size_t)used[k] * 4);
+            at += (size_t)used[k];
+            hostValue_[(size_t)reg] = t.values[(size_t)used[k] - 1];  // what every instance holds after the block
             forcedLane_[(size_t)reg] = 0;
         }
+    }
+    for (size_t i = 0; i < due.size(); ++i) {
+        const Due& d = due[i];
+        const PendingTrack& t = pendingTracks_[d.slot];
+        const size_t value = valuesAt[d.slot] + (t.perInstance ? (size_t)d.step * (size_t)nPad_ : (size_t)d.step);
+        const TrackEvent ev{d.sample, d.slot, (uint32_t)(value * 4), t.perInstance ? (uint32_t)(nPad_ * 4) : 4u};
+        std::memcpy(&trackStage_[i * 4], &ev, sizeof(ev));
+    }
+    const TrackEvent closing{0xffffffffu, 0, 0, 4};
+    std::memcpy(&trackStage_[due.size() * 4], &closing, sizeof(closing));
+    for (PendingTrack& t : pendingTracks_) {
         t.steps = 0;
         t.values.clear();
     }
-    tracksClear_ = words == headerWords;
+    tracksClear_ = due.empty();
     hipError_t e = hipMemcpyAsync(dTracks_, trackStage_.data(), words * 4, hipMemcpyHostToDevice, s);
     return e == hipSuccess ? 0 : hipFail(e, "tracks upload");
 }

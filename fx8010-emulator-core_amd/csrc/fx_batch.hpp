@@ -135,7 +135,7 @@ private:
     double* dLut_ = nullptr;
     uint32_t* dStream_ = nullptr;
     size_t streamCap_ = 0;
-    // control tracks (fx_xlate.hpp TrackHeader): registers the generated loop can re-load by itself, and what is armed
+    // control tracks (fx_xlate.hpp TrackEvent): registers the generated loop can re-load by itself, and what is armed
     struct PendingTrack { int period = 0, steps = 0; bool perInstance = false; std::vector<float> values; };
     std::vector<int> trackRegs_;           // register of slot t
     std::vector<PendingTrack> pendingTracks_;  // per slot; steps == 0: not armed

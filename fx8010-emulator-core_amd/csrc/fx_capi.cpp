@@ -28,6 +28,7 @@ struct fxp_handle {
     fx::Lowered low;
     bool lowered = false;
     std::string err;
+    std::vector<int> tracked;  // registers fxp_translate treats as trackable (fxp_track_register)
     explicit fxp_handle(int ch) : prog(ch) {}
     void noteError(const std::string& what) { err = what; }
 };
@@ -272,6 +273,15 @@ int64_t fxp_lower_info(fxp_handle* h, int what) {
 }
 static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap, int stages, int stage,
                              int* stagesOut, int* info, int infoCap);
+int fxp_track_register(fxp_handle* h, const char* key) {
+    if (!h || !key) return FX_E_ARG;
+    const int r = h->prog.findRegister(key);
+    if (r < 0) return 1;
+    if (std::find(h->tracked.begin(), h->tracked.end(), r) != h->tracked.end()) return 0;
+    if (h->tracked.size() >= (size_t)fx::kMaxTracks) { h->err = "at most " + std::to_string(fx::kMaxTracks) + " registers can have schedules"; return FX_E_ARG; }
+    h->tracked.push_back(r);
+    return 0;
+}
 int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap) {
     if (!h) return FX_E_ARG;
     try {
@@ -291,7 +301,9 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     std::vector<float> values(h->prog.regs.size());
     for (size_t r = 0; r < values.size(); ++r) values[r] = h->prog.regs[r].value;
     // the lowering of the VGPR builds: one instance per lane, bookkeeping in VGPRs, rows are plain indices
-    fx::Lowered low = fx::lowerProgram(h->prog, values, std::vector<uint8_t>(values.size(), 0), 1, false, 1);
+    std::vector<uint8_t> perLane(values.size(), 0);
+    for (int r : h->tracked) perLane[(size_t)r] = 1;   // (a register with a schedule has a row of its own, as in Batch::laneForced)
+    fx::Lowered low = fx::lowerProgram(h->prog, values, perLane, 1, false, 1);
     if (!low.error.empty()) { h->err = low.error; return FX_E_PROGRAM; }
     std::string why;
     if (!fx::asmEligible(low, &why)) { h->err = "not eligible: " + why; return FX_E_PROGRAM; }
@@ -311,7 +323,9 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     std::string text4[5];
     fx::XlateImage plan;
     const std::vector<fx::MicroOp> steadyRecords = fx::encodeAsmStream(low.steady, nullptr, true), lastRecords = fx::encodeAsmStream(low.last, nullptr, true);
-    fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow);
+    std::vector<int> trackRows;
+    for (int r : h->tracked) trackRows.push_back(low.rowOfReg[(size_t)r]);
+    fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow, trackRows);
     std::vector<std::vector<uint32_t>> stagedCode;
     std::vector<std::string> stagedText;
     if (stagesOut) *stagesOut = 1;

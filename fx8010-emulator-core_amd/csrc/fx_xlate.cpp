@@ -500,8 +500,8 @@ constexpr int kSValidLanes = 58;                    // s[58:59]: lanes that hold
 constexpr int kVInput = 23;                         // v23..v26: PCM input of the current sample, channel 0..3 (requested one sample ahead)
 constexpr int kVInstance4 = 27;                     // v27 = instance * 4: byte offset into a PCM / state row
 constexpr int kSPrefetched = 94;                    // s94 = 1: the leading TRAM reads of this sample are already in flight
-constexpr int kSTrackNext[kMaxTracks] = {28, 29, 69};   // sample index at which track slot t takes its next value (0xFFFFFFFF: never)
-constexpr int kSTrackPtr[kMaxTracks] = {26, 30, 70};    // s[26:27] / s[30:31] / s[70:71]: address of that value
+constexpr int kSEventNext = 28;                         // control tracks: the sample at which the next event of the block's list is due (0xFFFFFFFF: none left)
+constexpr int kSEventPtr = 26;                          // s[26:27]: address of that event's record (fx_xlate.hpp TrackEvent)
 constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
 constexpr int kVRing = 30;                          // staged programs: lane * 4 + the LDS buffer of this sample's packets (sent and requested, see stageRequest)
@@ -613,8 +613,7 @@ class Translator {
             // longer than one of its steps)
             if (anyInput || !staged) e_.waitVmcnt(prog_.tramOpsInline + storesPerSample);
         }
-        for (size_t t = 0; t < prog_.trackRows.size(); ++t)
-            if (!trackStep((int)t)) { if (err) *err = err_; return false; }
+        if (!prog_.trackRows.empty() && !trackStep()) { if (err) *err = err_; return false; }
         if (staged && !G.recvRows.empty()) {
             // the rows the previous stage handed over for this sample were read into spare registers one step ago; the
             // next sample's are requested now and land behind this step's work (StageInfo).  (Younger than that request:
@@ -831,7 +830,7 @@ class Translator {
             }
             if (ring) inputBurst(0, true);
         }
-        for (size_t t = 0; t < prog_.trackRows.size(); ++t) trackInit((int)t);
+        if (!prog_.trackRows.empty()) trackInit();
         // (inline constants where the bit pattern has one, as the assembler would choose: the listing must re-assemble to the same bytes)
         for (const auto& c : pool_) e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(c.second), imm32(c.first));
         for (const auto& c : prog_.vconst) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(c.second), imm32(c.first));
@@ -1009,7 +1008,7 @@ class Translator {
         return true;
     }
 
-    // ---- control tracks (fx_xlate.hpp TrackHeader): scalar bookkeeping, one vector move / load per change
+    // ---- control tracks (fx_xlate.hpp TrackEvent): scalar bookkeeping, one vector move / load per change
     void smemLoad(int dwords, int sdst, int sbase, uint32_t offset) {  // s_load_dword / x2 / x4 with a 20-bit immediate offset
         const uint32_t op = dwords == 1 ? 0u : (dwords == 2 ? 1u : 2u);
         e_.raw2(0xc0020000u | (op << 18) | ((uint32_t)sdst << 6) | ((uint32_t)sbase >> 1), offset,
@@ -1022,51 +1021,63 @@ class Translator {
         std::snprintf(buf, sizeof(buf), "%x", v);
         return buf;
     }
-    // cold entry: slot t's first change is at sample 0 when the track is armed (steps > 0)
-    void trackInit(int t) {
-        const int next = kSTrackNext[t], ptr = kSTrackPtr[t];
+    // cold entry: the first event of the block's list (fx_xlate.hpp TrackEvent)
+    void trackInit() {
         smemLoad(2, kSTemp, 0, kKernargTracks);                       // s[62:63] = tracks buffer
         e_.waitLgkm0();
-        smemLoad(4, kSTemp + 2, kSTemp, (uint32_t)t * 16);             // s[64:67] = period, steps, valuesOffset, strideBytes
+        e_.sop1(SOP1_MOV_B64, "s_mov_b64", sreg64(kSEventPtr), sreg64(kSTemp));
+        smemLoad(1, kSEventNext, kSEventPtr, 0);                       // the sample of the first event (0xFFFFFFFF: none)
         e_.waitLgkm0();
-        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(ptr), sreg(kSTemp), sreg(kSTemp + 4));
-        e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(ptr + 1), sreg(kSTemp + 1), imm32(0));
-        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp + 3), imm32(0));
-        e_.sop2(SOP2_CSELECT_B32, "s_cselect_b32", sreg(next), imm32(0xffffffffu), imm32(0));
     }
-    // head of a sample: if this is the sample at which slot t changes, fetch the value(s) and schedule the next change
-    bool trackStep(int t) {
-        const int next = kSTrackNext[t], ptr = kSTrackPtr[t];
-        int vRow;
-        if (!row((uint32_t)prog_.trackRows[(size_t)t], &vRow)) return false;
-        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSSample), sreg(next));
-        Emitter::Fixup notNow = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
-        e_.cold(true);
-        smemLoad(2, kSTemp, 0, kKernargTracks);
-        e_.waitLgkm0();
-        smemLoad(4, kSTemp + 2, kSTemp, (uint32_t)t * 16);
-        e_.waitLgkm0();
-        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp + 5), imm32(4));
-        Emitter::Fixup perInstance = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
-        smemLoad(1, kSTemp, ptr, 0);                                   // one value for every instance
-        e_.waitLgkm0();
-        e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(vRow), sreg(kSTemp));
-        Emitter::Fixup loaded = e_.branchForward(SOPP_BRANCH, "s_branch");
-        e_.bind(perInstance);
-        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), sreg64(kSValidLanes));
-        e_.global(GLOBAL_LOAD_DWORD, true, vRow, kVInstance4, ptr);
-        e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
-        e_.waitVmcnt(0);
-        e_.bind(loaded);
-        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(ptr), sreg(ptr), sreg(kSTemp + 5));
-        e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(ptr + 1), sreg(ptr + 1), imm32(0));
-        e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(next), sreg(next), sreg(kSTemp + 2));
-        e_.sop2(SOP2_MUL_I32, "s_mul_i32", sreg(kSTemp), sreg(kSTemp + 2), sreg(kSTemp + 3));  // period * steps: past the schedule
-        e_.sopc(SOPC_CMP_GE_U32, "s_cmp_ge_u32", sreg(next), sreg(kSTemp));
-        e_.sop2(SOP2_CSELECT_B32, "s_cselect_b32", sreg(next), imm32(0xffffffffu), sreg(next));
-        if (fast_) taintIfNonFinite(vRow);
-        e_.cold(false);
-        e_.bind(notNow);
+    // head of a sample: ONE compare whatever the number of schedules; the events due at this sample are applied behind the loop
+    bool trackStep() {
+        std::vector<int> rows;
+        for (int r : prog_.trackRows) {
+            int v;
+            if (!row((uint32_t)r, &v)) return false;
+            rows.push_back(v);
+        }
+        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSSample), sreg(kSEventNext));
+        defer(e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1"), [this, rows]() {
+            e_.cold(true);
+            const size_t again = e_.words();
+            smemLoad(4, kSTemp + 2, kSEventPtr, 0);                    // s[64:67] = sample, slot, value offset, stride
+            smemLoad(2, kSTemp, 0, kKernargTracks);
+            e_.waitLgkm0();
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSTemp), sreg(kSTemp + 4));   // s[62:63] = address of the value(s)
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSTemp + 1), sreg(kSTemp + 1), imm32(0));
+            std::vector<Emitter::Fixup> to(rows.size()), done;
+            for (size_t t = 0; t < rows.size(); ++t) {
+                e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp + 3), imm32((uint32_t)t));
+                to[t] = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
+            }
+            done.push_back(e_.branchForward(SOPP_BRANCH, "s_branch"));   // (a slot this code does not know: skipped)
+            for (size_t t = 0; t < rows.size(); ++t) {
+                e_.bind(to[t]);
+                e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp + 5), imm32(4));
+                Emitter::Fixup perInstance = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+                smemLoad(1, kSTemp + 2, kSTemp, 0);                    // one value for every instance
+                e_.waitLgkm0();
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(rows[t]), sreg(kSTemp + 2));
+                Emitter::Fixup loaded = e_.branchForward(SOPP_BRANCH, "s_branch");
+                e_.bind(perInstance);
+                e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), sreg64(kSValidLanes));
+                e_.global(GLOBAL_LOAD_DWORD, true, rows[t], kVInstance4, kSTemp);
+                e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+                e_.waitVmcnt(0);
+                e_.bind(loaded);
+                if (fast_) taintIfNonFinite(rows[t]);
+                if (t + 1 < rows.size()) done.push_back(e_.branchForward(SOPP_BRANCH, "s_branch"));
+            }
+            for (const Emitter::Fixup& f : done) e_.bind(f);
+            e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSEventPtr), sreg(kSEventPtr), imm32(16));
+            e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSEventPtr + 1), sreg(kSEventPtr + 1), imm32(0));
+            smemLoad(1, kSEventNext, kSEventPtr, 0);
+            e_.waitLgkm0();
+            e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSSample), sreg(kSEventNext));
+            if (!e_.branchBack(SOPP_CBRANCH_SCC1, "s_cbranch_scc1", again)) deferredFailed_ = true;
+            e_.cold(false);
+        });
         return true;
     }
 

@@ -55,18 +55,19 @@ struct HoistPlan {
 };
 
 // Control tracks (the reference's caller changes a slider every 8 samples, source/main.cpp:107-114):
-// up to kMaxTracks registers can be given a schedule of values that the generated sample loop applies itself - at
-// sample s of a block, when s is a multiple of the track's period, the register takes the next value - instead of the
-// caller cutting the block.  The generated code only knows WHICH rows are trackable; period, number of steps and the
-// values come from a device buffer (AsmArgs.tracks) at run time, so arming, changing or clearing a schedule needs no
-// re-translation.  Buffer: TrackHeader[kMaxTracks], then the values: one float per step (broadcast) or nPad floats per
-// step (one per instance).
-constexpr int kMaxTracks = 3;
-struct TrackHeader {
-    uint32_t period;       // samples between two values (>= 1)
-    uint32_t steps;        // values in the schedule; 0 = track not armed for this block
-    uint32_t valuesOffset; // byte offset of the first value from the start of the buffer
-    uint32_t strideBytes;  // 4: one value for all instances (scalar load); else bytes between steps of a per-instance schedule
+// registers can be given a schedule of values that the generated sample loop applies itself - at sample s of a block, when s
+// is a multiple of the track's period, the register takes the next value - instead of the caller cutting the block.  The
+// generated code only knows WHICH rows are trackable (at most kMaxTracks: each has its few instructions behind the loop);
+// the schedules of a block come as ONE list of events, sorted by sample, in a device buffer (AsmArgs.tracks), so arming,
+// changing or clearing a schedule needs no re-translation and the loop itself pays one scalar compare per sample whatever
+// the number of schedules.  Buffer: the events of the block in order, a closing record with sample 0xFFFFFFFF, then the
+// values: one float per step (for all instances) or nPad floats per step (one per instance).
+constexpr int kMaxTracks = 16;
+struct TrackEvent {
+    uint32_t sample;       // the sample of the block at which the register changes (0xFFFFFFFF closes the list)
+    uint32_t slot;         // which trackable row (index into XlateProgram::trackRows)
+    uint32_t valueOffset;  // byte offset of the value (or of the row of per-instance values) from the start of the buffer
+    uint32_t strideBytes;  // 4: one value for all instances (scalar load); else the values are a row, one per instance
 };
 
 // A program pipelined over the wavefronts of a workgroup ("stages", SURVEY.md section 8d: small batches leave the machine

@@ -38,7 +38,7 @@ SYMBOLS = [
     "fxp_create", "fxp_destroy", "fxp_load_file", "fxp_load_text", "fxp_num_registers", "fxp_register_name",
     "fxp_register_type", "fxp_register_ioindex", "fxp_register_value", "fxp_num_instructions", "fxp_instruction",
     "fxp_itram_size", "fxp_xtram_size", "fxp_error_count", "fxp_error_desc", "fxp_error_row", "fxp_control_count",
-    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_translate", "fxp_translate_staged", "fxp_last_error",
+    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_translate", "fxp_track_register", "fxp_translate_staged", "fxp_last_error",
 ]
 
 
@@ -95,6 +95,7 @@ def load():
     sig("fxp_lut", C.POINTER(C.c_double), i32, i32); sig("fxp_lower", i32, vp); sig("fxp_lower_info", i64, vp, i32)
     sig("fxp_last_error", cp, vp)
     sig("fxp_translate", i64, vp, i32, i32, vp, i64, C.c_char_p, i64)
+    sig("fxp_track_register", i32, vp, cp)
     sig("fxp_translate_staged", i64, vp, i32, i32, i32, i32, vp, i64, C.c_char_p, i64, C.POINTER(C.c_int), C.POINTER(C.c_int), i32)
     _lib = lib
     return lib
@@ -178,6 +179,13 @@ class FrontEnd(_Reports):
 
     def lower_info(self, what):
         return int(self._lib.fxp_lower_info(self._h, INFO[what]))
+
+    def track_register(self, key):
+        """translate() from now on generates the code of a batch in which `key` can have a control track"""
+        rc = int(self._lib.fxp_track_register(self._h, key.encode()))
+        if rc < 0:
+            raise RuntimeError("fxp_track_register: %d %s" % (rc, self.last_error()))
+        return rc
 
     def translate(self, vgprs=0, stream=0):
         """gfx950 machine code of the program as the batch path generates it: (code bytes, assembler listing).

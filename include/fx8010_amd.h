@@ -154,7 +154,7 @@ int fxb_get_register_array(fxb_handle* h, const char* key, float* values);
  * sample s of that block, whenever s is a multiple of `period`, the register takes values[s / period] (per_instance:
  * values[(s / period) * n_instances + instance]) - exactly what a caller of the reference does with setRegisterValue()
  * between process() calls (the slider every 8 samples of source/main.cpp:107-114), in ONE launch instead of one per
- * change.  At most 3 registers can have tracks; steps beyond the block are dropped; the register keeps its last value.
+ * change.  At most 16 registers can have tracks (one sorted list of events per block: the loop pays one compare per sample whatever their number); steps beyond the block are dropped; the register keeps its last value.
  * The translated program reads the schedule from device memory (no re-translation per schedule); the interpreter and
  * HIP C++ tiers cut the block at the change points.  0 found, 1 not found, <0 FX_E_*. */
 int fxb_set_register_track(fxb_handle* h, const char* key, const float* values, int n_steps, int period, int per_instance);
@@ -268,6 +268,9 @@ int64_t fxp_lower_info(fxp_handle* h, int what);
  * cannot be translated, see fxp_last_error) and copies at most `cap` bytes of code and at most listing_cap-1
  * characters of the assembler listing (one instruction per line). */
 int64_t fxp_translate(fxp_handle* h, int vgprs, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap);
+/* ... with `key` among the registers that can have a control track (fxb_set_register_track): the code fxp_translate then
+ * returns is what a batch runs after a track has been armed for that register.  0 found, 1 not found, FX_E_ARG beyond 16. */
+int fxp_track_register(fxp_handle* h, const char* key);
 /* The same for the program cut into (at most) `stages` stages run by the wavefronts of one workgroup - what the batch path
  * generates for small batches (fx_xlate.hpp StageInfo): the code of stream `stream` of stage `stage` (stream 4: the shared
  * run-once code).  *stages_out = the number of stages the program was cut into (1: not cut - the call then returns the

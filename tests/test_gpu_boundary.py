@@ -273,10 +273,11 @@ def test_track_limits_and_sharded_tracks(gpu):
     n = 300
     b = gpu.Batch(n, 1, devices=[0, 0])
     assert b.load_text(progs.config5())
-    for key in ("damp", "decay", "diff"):
+    names = ["damp", "decay", "diff"] + ["lp%d" % i for i in range(4)] + ["y%d" % i for i in range(9)]
+    for key in names:                          # sixteen registers can have schedules ...
         b.set_register_track(key, [0.3, 0.2], 16)
     with pytest.raises(RuntimeError):
-        b.set_register_track("in", [0.0], 4)  # a fourth register
+        b.set_register_track("in", [0.0], 4)   # ... a seventeenth cannot
     import ctypes as C
     one_value = (C.c_float * 1)(0.5)
     assert b._lib.fxb_set_register_track(b._h, b"nosuch", one_value, 1, 1, 0) == 1  # the reference's "not found"
@@ -291,6 +292,44 @@ def test_track_limits_and_sharded_tracks(gpu):
         bb.set_register_track("decay", [0.45, 0.2], 20)
     assert np.array_equal(bits(b.process_block(x)), bits(one.process_block(x)))
     assert np.array_equal(bits(b.get_register_array("damp")), bits(vals[2]))
+
+
+def test_many_tracks_in_one_block(gpu, track_tier):
+    """seven schedules in one 90-sample block - periods 1 .. 40, per instance and for all, several changes due at the same
+    sample - as ONE list of events the generated loop walks; against the oracle with set_register in between"""
+    n, s = 150, 90
+    text = progs.config5()
+    x = progs.stimulus(n, s + 20)
+    rng = np.random.default_rng(77)
+    plan = [("damp", 8, False), ("decay", 40, False), ("diff", 1, False), ("lp1", 16, True), ("y3", 5, True), ("w2", 8, False), ("y17", 30, True)]
+    sched = {}
+    for name, period, per in plan:
+        steps = (s + period - 1) // period + (1 if name == "decay" else 0)   # (one value more than the block uses)
+        sched[name] = rng.uniform(-0.9, 0.9, size=(steps, n) if per else (steps,)).astype(np.float32)
+    b = gpu.Batch(n, 1, 0)
+    assert b.load_text(text)
+    b.process_block(x[:7])
+    for name, period, per in plan:
+        b.set_register_track(name, sched[name], period)
+    y = b.process_block(x[7:7 + s])
+    y2 = b.process_block(x[7 + s:])
+    assert b.ood_flags() == 0
+    for inst in (0, 63, 64, n - 1):
+        o = Oracle(1)
+        assert o.load_text(text)
+        o.process_block(x[:7, inst].copy())
+        outs = []
+        for lo in range(s):
+            for name, period, per in plan:
+                if lo % period == 0:
+                    v = sched[name][lo // period]
+                    o.set_register(name, float(v[inst] if per else v))
+            outs.append(o.process_block(x[7 + lo:8 + lo, inst].copy()))
+        assert np.array_equal(bits(np.concatenate(outs)), bits(y[:, inst])), inst
+        assert np.array_equal(bits(o.process_block(x[7 + s:, inst].copy())), bits(y2[:, inst])), inst
+        assert b.instruction_counter_i(inst) == o.instruction_counter()
+        for name, _, _ in plan:
+            assert b.get_register_bits_i(name, inst) == o.get_register_bits(name), (name, inst)
 
 
 @pytest.mark.parametrize("channels", [1, 2])

@@ -100,12 +100,14 @@ def test_handwritten_kernels(name):
 
 
 # ------------------------------------------------------------------------------------------------ generated code
-def lint_program(text, vgprs=0, options=0):
+def lint_program(text, vgprs=0, options=0, tracked=()):
     fe = A.FrontEnd(1)
     if options:
         fe.set_option(options)
     if not fe.load_text(text):
         return None
+    for key in tracked:
+        assert fe.track_register(key) == 0, key
     try:
         listing, size = L.image_listing(fe, vgprs)
     except RuntimeError:
@@ -133,6 +135,29 @@ def test_generated_code_of_the_dane_model():
     for text in (CHORUS, FRACTIONAL_TAPS):
         n, findings, problems = lint_program(text, options=A.OPT_TRAM_DANE | A.OPT_TRAM_ADDR_SHIFT | A.OPT_TRAM_INTERP)
         assert n > 300 and not findings and not problems, (findings[:5], problems[:5])
+
+
+def test_generated_code_with_control_tracks():
+    """registers with schedules (fxb_set_register_track): the head's one compare, the event walk behind the loop - scalar loads,
+    a per-slot compare chain, one value for all or one per instance, the taint check of what arrived"""
+    cases = [("config5", ["damp", "decay", "diff", "lp1", "y3", "w2", "y17"]), ("config3", ["cutoff", "fb", "s3"]), ("config4", ["cutoff"]),
+             ("config2", ["cutoff", "s0", "s30", "t"])]
+    for name, tracked in cases:
+        n, findings, problems = lint_program(P.CONFIGS[name](), tracked=tracked)
+        assert n > 100 and not findings and not problems, (name, findings[:5], problems[:5])
+    import stress_fuzz
+    checked = 0
+    for seed in range(0, 90, 3):
+        rng = np.random.default_rng(8100000 + seed)
+        text = stress_fuzz.random_program(rng, int(rng.integers(4, 60)), int(rng.integers(3, 30)))
+        regs = [l.split()[1] for l in text.split("\n") if l.startswith(("static r", "control c"))]
+        tracked = [str(r) for r in rng.choice(regs, size=min(len(regs), int(rng.integers(1, 6))), replace=False)]
+        res = lint_program(text, tracked=tracked)
+        if res is None:
+            continue
+        checked += 1
+        assert not res[1] and not res[2], (seed, res[1][:5], res[2][:5])
+    assert checked > 15
 
 
 def test_generated_code_of_random_programs():

@@ -71,6 +71,30 @@ def test_listing_reassembles_to_the_same_bytes(last):
     assert seen > 0
 
 
+@needs_llvm
+def test_listing_with_control_tracks_reassembles():
+    for name, tracked in (("config5", ["damp", "decay", "diff", "lp1", "y3", "w2", "y17"]), ("config3", ["cutoff", "fb"])):
+        fe = A.FrontEnd(1)
+        assert fe.load_text(P.CONFIGS[name]())
+        plain = fe.translate(0, 0)[0]
+        for key in tracked:
+            assert fe.track_register(key) == 0
+        assert fe.track_register("nosuch") == 1
+        for stream in range(4):
+            code, listing = fe.translate(0, stream)
+            assert assemble(listing) == code, (name, stream)
+            # ONE compare of the sample counter with the next event in the loop, whatever the number of schedules
+            assert listing.count("s_cmp_eq_u32 s3, s28") == 2, (name, stream)   # (the head's, and the event walk's own)
+        assert fe.translate(0, 0)[0] != plain
+    fe = A.FrontEnd(1)
+    assert fe.load_text(P.CONFIGS["config5"]())
+    names = ["damp", "decay", "diff"] + ["lp%d" % i for i in range(4)] + ["y%d" % i for i in range(9)]
+    for key in names:
+        assert fe.track_register(key) == 0
+    with pytest.raises(RuntimeError):
+        fe.track_register("y20")   # the seventeenth
+
+
 def branch_targets(listing):
     """(line index, target line index) of every SOPP branch of a listing (targets resolved through instruction sizes)"""
     lines = listing.strip().split("\n")

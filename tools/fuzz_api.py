@@ -70,7 +70,8 @@ def run(seed, verbose=False):
             xs = x[pos:pos + S]
             pos += S
             plans = []
-            for name in rng.choice(names[:3], size=int(rng.integers(1, 3)), replace=False):  # (a batch gives at most three registers a schedule slot)
+            pool = names[:3] if rng.integers(0, 2) else list(dict.fromkeys(names))   # (a few registers again and again, or any: up to sixteen get a slot)
+            for name in rng.choice(pool, size=int(rng.integers(1, min(len(pool), 5) + 1)), replace=False):
                 period = int(rng.choice([1, 2, 3, 8]))
                 steps = int(rng.integers(1, S // period + 3))
                 if rng.integers(0, 2):
