@@ -294,6 +294,58 @@ def test_track_limits_and_sharded_tracks(gpu):
     assert np.array_equal(bits(b.get_register_array("damp")), bits(vals[2]))
 
 
+def test_distinct_handles_on_concurrent_host_threads(gpu, monkeypatch, tmp_path):
+    """the reference's objects share nothing (one per thread is safe); so must handles of this library: six host
+    threads at once, each with batches of its own - different programs, sizes and tiers, created, loaded (lowered, translated,
+    module-loaded), run and read concurrently - and a drop-in single-instance handle each"""
+    import threading
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_STAGES", raising=False)
+    jobs = [("config2", 130, 40), ("config3", 200, 60), ("config4", 70, 30), ("config5", 96, 50), ("config2", 4100, 24), ("config4", 300, 17)]
+    errors = []
+
+    def work(k, name, n, s):
+        try:
+            text = progs.CONFIGS[name]()
+            x = progs.stimulus(n, s, first_instance=1000 * k)
+            for rep in range(3):
+                b = gpu.Batch(n, 1, 0)
+                assert b.load_text(text), b.errors()
+                y1 = b.process_block(x[: s // 2])
+                if rep == 1:
+                    b.set_register_i("cutoff" if name != "config5" else "damp", 3, 0.5)
+                y2 = b.process_block(x[s // 2:])
+                for inst in (0, 3, 63, n - 1):
+                    o = Oracle(1)
+                    assert o.load_text(text)
+                    r1 = o.process_block(x[: s // 2, inst].copy())
+                    if rep == 1 and inst == 3:
+                        o.set_register("cutoff" if name != "config5" else "damp", 0.5)
+                    r2 = o.process_block(x[s // 2:, inst].copy())
+                    assert np.array_equal(bits(r1), bits(y1[:, inst])) and np.array_equal(bits(r2), bits(y2[:, inst])), (name, rep, inst)
+                    assert b.instruction_counter_i(inst) == o.instruction_counter()
+            one = gpu.Single(1)
+            path = tmp_path / ("thread%d.da" % k)
+            path.write_bytes(text.encode())
+            assert one.load_file(str(path))
+            o = Oracle(1)
+            assert o.load_text(text)
+            for t in range(6):
+                got = one.process([float(x[t, 0])])
+                assert np.array_equal(bits(got), bits(o.process_block(x[t:t + 1, 0].copy()))), (name, t)
+        except Exception as e:  # noqa: BLE001 - collected and re-raised on the main thread
+            import traceback
+            errors.append("%s: %s\n%s" % (name, e, traceback.format_exc()))
+
+    threads = [threading.Thread(target=work, args=(k,) + job) for k, job in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
+
+
 def test_many_tracks_in_one_block(gpu, track_tier):
     """seven schedules in one 90-sample block - periods 1 .. 40, per instance and for all, several changes due at the same
     sample - as ONE list of events the generated loop walks; against the oracle with set_register in between"""
