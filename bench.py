@@ -90,6 +90,23 @@ def usable_cores():
     return max(1, min(n, 16))
 
 
+def measured_issue_quads(config, n_inst, n_samples):
+    """Quad-cycles in which a SIMD issued vector instructions for one wavefront during one sample, from a COMMITTED rocprofv3 PMC
+    pass of exactly this workload (profiles/*pmc_valu*.json: SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2, tools/pmc_valu.txt,
+    tools/pmc_summary.py) - a constant read from that file, like roofline.traffic; the timing it is set against is this run's."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_valu*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            w = d["bench"]
+            if w["config"] == config and w["instances"] == n_inst and w["samples"] == n_samples:
+                return float(d["derived"]["valu_issue_quad_cycles_per_wave_sample"]), os.path.relpath(f, ROOT)
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
+
+
 def measured_traffic(config, n_inst, n_samples):
     """HBM bytes per launch from a COMMITTED rocprofv3 PMC pass (profiles/*hbm_traffic*.json: FETCH_SIZE and WRITE_SIZE in
     their own passes, gfx950 read correction applied) of exactly this workload - a constant read from that file, not a
@@ -344,6 +361,9 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
             clocks = batch.info("xlate_valu_clocks")
             hz = (clock_mhz * 1e6) if clock_mhz else MAX_CLOCK_HZ
             busy = clocks * (waves / float(SIMDS)) * S / (kernel_ms * 1e-3 * hz)
+            # ... and the same from hardware counters: quad-cycles in which the SIMD issued for a wavefront (dual issue counted once)
+            quads, quads_source = measured_issue_quads(config, n_inst, S)
+            busy_counters = round(quads * 4.0 * (waves * stages / float(SIMDS)) * S / (kernel_ms * 1e-3 * hz), 4) if quads else None
             valu = {"bound": "valu issue", "achieved": round(per_s / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
                     "frac": round(per_s / peak, 4), "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves * stages / float(SIMDS), 3),
                     "stages": stages,
@@ -352,9 +372,12 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
                     "issue_clocks_per_wave_sample": clocks, "clock_mhz": clock_mhz, "power_w": power_w,
                     "clocks_per_valu_per_simd": round(kernel_ms * 1e-3 * hz / (valu_per_wave_sample * max(waves / float(SIMDS), 1.0) * S), 3),
                     "simd_issue_busy": round(busy, 4),
+                    "simd_issue_busy_from_counters": busy_counters, "issue_quad_cycles_source": quads_source,
                     "note": "peak = 1024 SIMDs x 2.4 GHz / 2.12 clocks, the rate of plain fp32 add / mul; conversions, fp64, min/max and compares "
                             "cost 2.6-4.25 clocks each: simd_issue_busy = modelled issue clocks of the executed mix / SIMD clocks available at the "
-                            "measured clock (DESIGN.md section 5); below 2 wavefronts per SIMD a wavefront issues only every ~5th clock"}
+                            "measured clock (DESIGN.md section 5); simd_issue_busy_from_counters = quad-cycles in which a SIMD issued vector instructions "
+                            "(SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2 of a committed PMC pass of this kernel and launch shape) x 4 clocks / the same SIMD clocks; "
+                            "below 2 wavefronts per SIMD a wavefront issues only every ~5th clock"}
         res = {
             "value": round(mips, 1),
             "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 4),

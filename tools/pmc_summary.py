@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 counter passes (tools/pmc_sq.txt) of a bench.py run for the translated / interpreter kernel.
 
-    python tools/pmc_summary.py <dir with pmc_*/..._counter_collection.csv> <samples per launch> [kernel prefix]
+    python tools/pmc_summary.py <dir with pmc_*/..._counter_collection.csv> <samples per launch> [kernel prefix [kernel ms, shader MHz]]
 
 Prints one JSON object: counters averaged over the kernel's dispatches, per wavefront and per wave-sample,
 plus the shares DESIGN.md section 5 quotes (waiting / issuing as a fraction of a wave's resident time).  Only ratios of SQ
@@ -46,6 +46,19 @@ def main():
             if k in per_ws:
                 d[k.lower() + "_share_of_wave_cycles"] = round(per_ws[k] / wc, 4)
         d["waves_per_simd"] = round(waves / 1024.0, 3)
+    # VALU issue from counters (tools/pmc_valu.txt): a SIMD issues vector instructions in quad-cycles, one - or, for the plain
+    # fp32 / integer class from two different wavefronts, TWO (SQ_ACTIVE_INST_VALU2 counts those quad-cycles).  Quad-cycles in
+    # which a wavefront's SIMD issued for it = instructions - dual-issued quad-cycles; x 4 clocks x wavefronts per SIMD against the
+    # clocks of a sample period (bench.py: kernel time x shader clock) = the share of the SIMD's issue slots that were taken.
+    if "SQ_ACTIVE_INST_VALU2" in per_ws and "SQ_INSTS_VALU" in per_ws:
+        quads = per_ws["SQ_INSTS_VALU"] - per_ws["SQ_ACTIVE_INST_VALU2"]
+        d["valu_issue_quad_cycles_per_wave_sample"] = round(quads, 2)
+        d["valu_dual_issued_share_of_instructions"] = round(2.0 * per_ws["SQ_ACTIVE_INST_VALU2"] / per_ws["SQ_INSTS_VALU"], 4)
+        if len(sys.argv) > 4:   # kernel ms per launch and shader clock in MHz of the run (from its bench line)
+            ms, mhz = float(sys.argv[4]), float(sys.argv[5])
+            clocks_per_sample = ms * 1e-3 * mhz * 1e6 / samples
+            d["clocks_per_sample"] = round(clocks_per_sample, 1)
+            d["valu_issue_busy_from_counters"] = round(quads * 4.0 * max(waves / 1024.0, 0.0) / clocks_per_sample, 4)
     out["derived"] = d
     print(json.dumps(out, indent=1))
 

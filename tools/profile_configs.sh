@@ -22,6 +22,8 @@ for c in $CONFIGS; do
   rocprofv3 -i $ROOT/tools/pmc_hbm.txt --kernel-trace -d $OUT/${c}_hbm -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 3 --warmup 1 --no-extras --parity-instances 0 > $OUT/${c}_hbm.json 2> $OUT/${c}_hbm.err || exit 1
   echo "== $c: SQ counters"
   rocprofv3 -i $ROOT/tools/pmc_sq.txt -d $OUT/${c}_pmc -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 2 --warmup 1 --no-extras --parity-instances 0 > $OUT/${c}_pmc.json 2> $OUT/${c}_pmc.err || exit 1
+  echo "== $c: VALU issue counters (dual-issued quad-cycles, instruction classes)"
+  rocprofv3 -i $ROOT/tools/pmc_valu.txt -d $OUT/${c}_valu -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 2 --warmup 1 --no-extras --parity-instances 0 > $OUT/${c}_valu.json 2> $OUT/${c}_valu.err || exit 1
 done
 find $OUT -name "*kernel_stats.csv" | head
 echo done
