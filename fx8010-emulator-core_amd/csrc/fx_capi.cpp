@@ -352,7 +352,7 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     const std::vector<uint32_t>& words = staged ? stagedCode[stream == 4 ? (size_t)plan.stages * 4 : (size_t)stage * 4 + (size_t)stream] : code4[stream];
     const std::string& text = staged ? stagedText[stream == 4 ? (size_t)plan.stages * 4 : (size_t)stage * 4 + (size_t)stream] : text4[stream];
     const int64_t bytes = (int64_t)words.size() * 4;
-    if (code && cap > 0) std::memcpy(code, words.data(), (size_t)std::min<int64_t>(cap, bytes));
+    if (code && cap > 0 && bytes > 0) std::memcpy(code, words.data(), (size_t)std::min<int64_t>(cap, bytes));   // (an empty stream has no data())
     if (listing && listing_cap > 0) {
         const size_t n = std::min<size_t>(text.size(), (size_t)listing_cap - 1);
         std::memcpy(listing, text.data(), n);

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "libfx8010_amd.so")
+# (FX8010_AMD_LIB: another build of the same library - the sanitizer build of `make -C csrc asan`, tests/test_host_sanitizers.py)
+LIB_PATH = os.environ.get("FX8010_AMD_LIB") or os.path.join(_HERE, "..", "libfx8010_amd.so")
 
 _f32p = C.POINTER(C.c_float)
 _lib = None
