@@ -95,6 +95,27 @@ def test_listing_with_control_tracks_reassembles():
         fe.track_register("y20")   # the seventeenth
 
 
+def test_hardware_instruction_counters_are_of_this_code():
+    """profiles/*_pmc_valu.json (rocprofv3, SQ_INSTS_VALU_* per wavefront and sample of the benchmark run) against the
+    translator's own listing of config5's steady fast stream: the committed counters describe the code that is generated today"""
+    import collections
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "*config5_pmc_valu.json")))
+    if not files:
+        pytest.skip("no committed VALU counter pass")
+    hw = json.load(open(files[-1]))["per_wave_sample"]
+    fe = A.FrontEnd(1)
+    assert fe.load_text(P.CONFIGS["config5"]())
+    listing = fe.translate(128, 0)[1]
+    n = collections.Counter(l.split()[0] for l in listing.split("\n") if l)
+    mine = {"SQ_INSTS_VALU_MUL_F32": n["v_mul_f32_e32"], "SQ_INSTS_VALU_ADD_F32": n["v_add_f32_e32"] + n["v_sub_f32_e32"],
+            "SQ_INSTS_VALU_FMA_F32": n["v_fma_f32"], "SQ_INSTS_VALU_FMA_F64": n["v_fma_f64"],
+            "SQ_INSTS_VALU_CVT": n["v_cvt_f64_f32_e32"] + n["v_cvt_f32_f64_e32"]}
+    for key, count in mine.items():
+        assert abs(hw[key] - count) < 0.5, (key, hw[key], count)
+
+
 def branch_targets(listing):
     """(line index, target line index) of every SOPP branch of a listing (targets resolved through instruction sizes)"""
     lines = listing.strip().split("\n")
