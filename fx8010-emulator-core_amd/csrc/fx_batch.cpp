@@ -342,7 +342,15 @@ int Batch::ensureLowered() {
         // Small batches leave SIMDs empty (and a lone wavefront issues an instruction every ~4.5 clocks): cut the program
         // into stages run by the wavefronts of one workgroup (fx_xlate.hpp StageInfo) until ~4 wavefronts per SIMD are in
         // flight.  FX_STAGES pins the number asked for (1 = never).
-        const int wantStages = stagesWanted((int)asmVariant_);
+        int wantStages = stagesWanted((int)asmVariant_);
+        // Measured with config2 at 4 096 instances (profiles/r03b_stage_blocks.txt): a block of 32 samples takes 27 us unstaged, 32 us
+        // in 8 stages with a barrier every 8 samples (3 x 7 steps of 8 samples to fill and drain) and 21 us in 4 stages with a
+        // barrier per sample; 128 samples 69 / 48 / 40 us (8 stages, every 2 samples); from 256 samples on the long steps win
+        const int blockClass = stageBlockClass(std::max(pendingSamples_, 1));
+        const int maxGroup = blockClass == 0 ? 1 : (blockClass == 1 ? 2 : kStageGroupMax);
+        if (blockClass == 0 && !std::getenv("FX_STAGES")) wantStages = std::min(wantStages, 4);
+        stagedForClass_ = blockClass;
+        otherClassBlocks_ = 0;
         stagesWhyNot_.clear();
         if (tmpl && wantStages >= 2) {
             const StagePlan plan = planStages(steadyRecords, lastRecords, xprog, low_.nRows, wantStages);
@@ -352,7 +360,7 @@ int Batch::ensureLowered() {
                 // (several workgroups per CU must fit its 160 KiB of LDS together)
                 const int64_t groupsPerCu = std::max<int64_t>(1, ((n_ + 63) / 64 + 255) / 256);
                 const uint32_t ldsBudget = (uint32_t)std::min<int64_t>(144 * 1024, 160 * 1024 / groupsPerCu - 256);
-                built = buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, plan, &image, nullptr, nullptr, &why, ldsBudget);
+                built = buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, plan, &image, nullptr, nullptr, &why, ldsBudget, maxGroup);
                 if (!built) { stagesWhyNot_ = why; image = XlateImage(); }
             }
         }
@@ -692,6 +700,11 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     if (!piecewise_) {   // (a piece of a pipelined host block: done once for the whole block)
         pendingSamples_ = nSamples;
         if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;  // quiet again: translate
+        // a staged program is generated for a class of block lengths: when the caller has moved to another one for good, again
+        if (useXlate_ && xlateStages_ > 1 && !lowDirty_ && nSamples > 0) {
+            otherClassBlocks_ = stageBlockClass(nSamples) == stagedForClass_ ? 0 : otherClassBlocks_ + 1;
+            if (otherClassBlocks_ >= 4) lowDirty_ = true;
+        }
     }
     int rc = ensureLowered();
     if (rc != 0) return rc;

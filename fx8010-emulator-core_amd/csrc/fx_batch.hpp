@@ -120,6 +120,10 @@ private:
     bool piecewise_ = false;   // processDevice is being called for the pieces of one pipelined host block
     int xlateBuilds_ = 0;      // translations since the handle was created
     int xlateStages_ = 1;                        // wavefronts per workgroup of the translated program (fx_xlate.hpp StageInfo)
+    // a pipeline fills and drains in 3 (K - 1) steps: short blocks get short steps and fewer stages (stageBlockClass); the code is
+    // generated for the class of the block that triggered the translation and again when the blocks stay in another class
+    int stagedForClass_ = -1, otherClassBlocks_ = 0;
+    static int stageBlockClass(int nSamples) { return nSamples <= 48 ? 0 : (nSamples <= 256 ? 1 : 2); }
     std::vector<StageDescriptor> xlateStageDesc_;
     std::vector<std::vector<int>> xlateStageStoreRows_;
     std::string stagesWhyNot_;

@@ -3183,7 +3183,7 @@ std::vector<MicroOp> stageRecords(const std::vector<MicroOp>& all, size_t from, 
 
 bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
                       const XlateProgram& program, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* codeOut,
-                      std::vector<std::string>* listingOut, std::string* err, uint32_t ldsBudget) {
+                      std::vector<std::string>* listingOut, std::string* err, uint32_t ldsBudget, int maxGroup) {
     const int K = (int)plan.cuts.size() + 1;
     if (K < 2) { if (err) *err = "not a staged plan"; return false; }
     size_t n = 0;
@@ -3204,6 +3204,7 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     const uint32_t bufBase = flagBase + 256u * (uint32_t)K;
     const uint32_t scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0), behind the ring
     int group = kStageGroupMax;
+    while (group > 1 && group > maxGroup) group /= 2;
     if (const char* knob = std::getenv("FX_STAGES_GROUP")) {   // tests: a shorter ring than the LDS would allow (1, 2, 4)
         const int g = std::atoi(knob);
         if (g == 1 || g == 2 || g == 4) group = g;

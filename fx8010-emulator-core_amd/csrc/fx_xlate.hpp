@@ -224,6 +224,7 @@ bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vecto
 // then the shared run-once code.  code / listing (optional): [stage * 4 + stream], the run-once code last.
 bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
                       const XlateProgram& prog, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* code,
-                      std::vector<std::string>* listing, std::string* err, uint32_t ldsBudget = 144u * 1024u);  // LDS a workgroup may take (several per CU: less)
+                      std::vector<std::string>* listing, std::string* err, uint32_t ldsBudget = 144u * 1024u,   // LDS a workgroup may take (several per CU: less)
+                      int maxGroup = kStageGroupMax);   // samples between two barriers at most: short blocks want short steps (the pipeline fills and drains in 3 (K - 1) of them)
 
 }  // namespace fx

@@ -97,18 +97,52 @@ def test_wide_packets(gpu, stages, width):
             + "".join("macs a%d, in, in, 0.%02d\n" % (i, i + 1) for i in range(W))
             + "".join("interp s%d_%d, s%d_%d, k, a%d\nmacs a%d, s%d_%d, in, 0.05\n" % (i, j, i, j, i, i, i, j) for j in range(6) for i in range(W))
             + "macs out, 0, a0, 1.0\n" + "".join("macs out, out, a%d, 0.1\n" % i for i in range(1, W)) + "end")
-    N, S = 130, 45
+    N, S = 130, 345
     x = progs.stimulus(N, S)
-    b = run_and_compare(gpu, text, x, [(0, 30), (30, 31), (31, S)], ["a0", "a%d" % (W - 1), "s0_0", "s%d_5" % (W - 1), "out", "ccr"])
+    b = run_and_compare(gpu, text, x, [(0, 300), (300, 301), (301, S)], ["a0", "a%d" % (W - 1), "s0_0", "s%d_5" % (W - 1), "out", "ccr"])
     assert b.info("waves_per_wg") == 8
+
+
+def test_code_follows_the_block_length(gpu, stages):
+    """staged code is generated for a class of block lengths (long steps for long blocks, a barrier per sample and at most four
+    stages for blocks of a few dozen samples); a caller that changes its block length for good gets new code after a few
+    blocks - with the state carried over, bit for bit"""
+    stages(None)
+    N = 130
+    lens = [300, 16, 16, 16, 16, 16, 16, 400, 400, 400, 400, 400, 64, 64, 64, 64, 64]
+    cuts = [0]
+    for n in lens:
+        cuts.append(cuts[-1] + n)
+    x = progs.stimulus(N, cuts[-1])
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(progs.config2())
+    ys, builds, waves = [], [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ys.append(b.process_block(x[lo:hi]))
+        builds.append(b.info("xlate_builds"))
+        waves.append(b.info("waves_per_wg"))
+    assert builds[0] == 1 and builds[4] == 2 and builds[6] == 2 and builds[11] == 3 and builds[-1] == 4, builds
+    assert waves[0] == 8 and waves[5] == 4 and waves[11] == 8 and waves[-1] == 8, waves
+    for n in (0, 63, 64, N - 1):
+        o = Oracle(1)
+        assert o.load_text(progs.config2())
+        for (lo, hi), y in zip(zip(cuts[:-1], cuts[1:]), ys):
+            r = o.process_block(x[lo:hi, n].copy())
+            assert np.array_equal(r.view(np.uint32), np.ascontiguousarray(y[:, n]).view(np.uint32)), (n, lo, hi)
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+    assert b.ood_flags() == 0
 
 
 def test_small_batches_are_staged_by_default(gpu, stages):
     stages(None)
     b = gpu.Batch(300, 1, 0)
     assert b.load_text(progs.config2())
-    b.process_block(progs.stimulus(300, 8))
+    b.process_block(progs.stimulus(300, 300))
     assert b.info("waves_per_wg") == 8          # 5 wavefronts of instances: eight stages each
+    short = gpu.Batch(300, 1, 0)
+    assert short.load_text(progs.config2())
+    short.process_block(progs.stimulus(300, 8))
+    assert short.info("waves_per_wg") == 4      # ... four for blocks this short: a pipeline fills and drains in 3 (K - 1) steps
     big = gpu.Batch(262144, 1, 0)
     assert big.load_text(progs.config2())
     big.process_block(progs.stimulus(262144, 2))

@@ -1,5 +1,5 @@
 """Stage pipelining probe (GPU box): a benchmark program at its BASELINE size with FX_STAGES = 1, 2, 4, ..., checked against the
-oracle on a few instances, kernel time per launch.   python tools/stage_probe.py [config2] [instances] [samples] [stages ...]"""
+oracle on a few instances, kernel time per launch.   python tools/stage_probe.py [config2] [instances] [samples] [stages ... (0 = the library's policy)]"""
 import os
 import sys
 
@@ -32,7 +32,10 @@ def main():
         r2 = o.process_block(x[:, i].copy())
         refs[i] = (r1, r2, o.instruction_counter())
     for K in stages:
-        os.environ["FX_STAGES"] = str(K)
+        if K > 0:
+            os.environ["FX_STAGES"] = str(K)
+        else:
+            os.environ.pop("FX_STAGES", None)   # 0: the library's own policy (instances, block length)
         b = A.Batch(n, 1, 0)
         assert b.load_text(text), b.errors()
         y1 = b.process_block(x)
