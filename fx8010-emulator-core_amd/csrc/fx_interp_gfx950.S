@@ -136,6 +136,50 @@
 #endif
 .endm
 
+// the prologue's batches: request the state row of table entry `entry` into `dst`; later check it (translated programs: taint,
+// below) and put it into its register-file row
+.macro ROW_FETCH entry, dst
+	s_lshr_b32 s65, \entry, 16
+	s_mul_i32 s66, s65, s60
+	s_mul_hi_u32 s67, s65, s60
+	s_add_u32 s66, s66, s10
+	s_addc_u32 s67, s67, s11
+	global_load_dword \dst, v27, s[66:67]
+.endm
+.macro ROW_TAKE entry, src
+#ifdef XLATE
+	v_cmp_class_f32 vcc, \src, v29
+	s_bitcmp1_b32 \entry, 15                              // row of the BOUNDED class (fx_xlate.hpp)
+	s_cbranch_scc0 1f
+	v_cmp_nle_f32_e64 vcc, |\src|, 1.0
+1:
+	s_or_b64 s[78:79], s[78:79], vcc
+	s_and_b32 s64, \entry, 0x7fff
+#else
+	s_and_b32 s64, \entry, 0xffff
+#endif
+#ifndef RF_VGPR
+	s_lshl_b32 s64, s64, 8
+#endif
+	STOREV s64, \src
+.endm
+// ... and the epilogue's: register-file row of table entry `entry` -> `dst`, then to its state row
+.macro ROW_READ entry, dst
+	s_and_b32 s64, \entry, 0xffff
+#ifndef RF_VGPR
+	s_lshl_b32 s64, s64, 8
+#endif
+	LOADV \dst, s64
+.endm
+.macro ROW_STORE entry, src
+	s_lshr_b32 s65, \entry, 16
+	s_mul_i32 s66, s65, s60
+	s_mul_hi_u32 s67, s65, s60
+	s_add_u32 s66, s66, s10
+	s_addc_u32 s67, s67, s11
+	global_store_dword v27, \src, s[66:67]
+.endm
+
 // two-level cpp paste so that SFX expands
 #define FX_PASTE(a, b) a##b
 #define FX_PASTE2(a, b) FX_PASTE(a, b)
@@ -243,6 +287,36 @@ KNAME:
 	s_mov_b32 s62, 0
 	s_cmp_eq_u32 s74, 0
 	s_cbranch_scc1 .Lload_done
+	// Eight rows at a time - ONE trip to the row table and ONE to the state rows per batch instead of two per row: a launch of
+	// a few dozen samples (a real-time caller's block) is mostly prologue and epilogue.  Fewer than eight left: one by one.
+.Lload_batch:
+	s_add_u32 s63, s62, 8
+	s_cmp_gt_u32 s63, s74
+	s_cbranch_scc1 .Lload_loop
+	s_lshl_b32 s63, s62, 2
+	s_load_dwordx8 s[16:23], s[72:73], s63                // ldsRow | stateRow << 16, eight of them
+	s_waitcnt lgkmcnt(0)
+	ROW_FETCH s16, v6
+	ROW_FETCH s17, v7
+	ROW_FETCH s18, v8
+	ROW_FETCH s19, v9
+	ROW_FETCH s20, v10
+	ROW_FETCH s21, v11
+	ROW_FETCH s22, v12
+	ROW_FETCH s23, v13
+	s_waitcnt vmcnt(0)
+	ROW_TAKE s16, v6
+	ROW_TAKE s17, v7
+	ROW_TAKE s18, v8
+	ROW_TAKE s19, v9
+	ROW_TAKE s20, v10
+	ROW_TAKE s21, v11
+	ROW_TAKE s22, v12
+	ROW_TAKE s23, v13
+	s_add_u32 s62, s62, 8
+	s_cmp_lt_u32 s62, s74
+	s_cbranch_scc1 .Lload_batch
+	s_branch .Lload_done
 .Lload_loop:
 	s_lshl_b32 s63, s62, 2
 	s_load_dword s64, s[72:73], s63                       // ldsRow | stateRow << 16
@@ -632,6 +706,39 @@ h_endsample_d:
 	s_mov_b32 s62, 0
 	s_cmp_eq_u32 s75, 0
 	s_cbranch_scc1 .Lstore_done
+	// (eight rows per trip to the row table, like the prologue)
+.Lstore_batch:
+	s_add_u32 s63, s62, 8
+	s_cmp_gt_u32 s63, s75
+	s_cbranch_scc1 .Lstore_loop
+	s_add_u32 s63, s62, s74
+#ifdef XLATE
+	s_add_u32 s63, s63, s54                               // (staged: this stage's rows)
+#endif
+	s_lshl_b32 s63, s63, 2
+	s_load_dwordx8 s[16:23], s[72:73], s63
+	s_waitcnt lgkmcnt(0)
+	ROW_READ s16, v6
+	ROW_READ s17, v7
+	ROW_READ s18, v8
+	ROW_READ s19, v9
+	ROW_READ s20, v10
+	ROW_READ s21, v11
+	ROW_READ s22, v12
+	ROW_READ s23, v13
+	s_waitcnt lgkmcnt(0)
+	ROW_STORE s16, v6
+	ROW_STORE s17, v7
+	ROW_STORE s18, v8
+	ROW_STORE s19, v9
+	ROW_STORE s20, v10
+	ROW_STORE s21, v11
+	ROW_STORE s22, v12
+	ROW_STORE s23, v13
+	s_add_u32 s62, s62, 8
+	s_cmp_lt_u32 s62, s75
+	s_cbranch_scc1 .Lstore_batch
+	s_branch .Lstore_done
 .Lstore_loop:
 	s_add_u32 s63, s62, s74
 #ifdef XLATE
