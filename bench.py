@@ -237,7 +237,7 @@ class ClockSampler:
     def _run(self):
         while not self._stop.is_set():
             self.samples.append((self._read(self.freq), self._read(self.power) if self.power else None))
-            self._stop.wait(0.02)
+            self._stop.wait(0.005)
 
     def start(self):
         import threading
@@ -252,8 +252,9 @@ class ClockSampler:
             return None, None
         self._stop.set()
         self._thread.join()
-        f = [a for a, _ in self.samples if a]
-        w = [b for _, b in self.samples if b]
+        samples = self.samples[1:] if len(self.samples) >= 3 else self.samples   # (the first reading still shows the clock of the idle chip)
+        f = [a for a, _ in samples if a]
+        w = [b for _, b in samples if b]
         return (round(sum(f) / len(f) / 1e6, 1) if f else None), (round(sum(w) / len(w) / 1e6, 1) if w else None)
 
 
@@ -481,7 +482,7 @@ def main():
             # the other single-GPU configurations of BASELINE.json at their instance counts, and ALL of configs[4]
             # (2 097 152 instances, 64 GiB of xTRAM) on this one GPU; fewer launches each, same block length
             extra = {}
-            plan = [("config2", 4096, 10, 256), ("config3", 65536, 10, 256), ("config4", 262144, 6, 256), ("config5_full_1gpu", 2097152, 4, 64)]
+            plan = [("config2", 4096, 60, 256), ("config3", 65536, 10, 256), ("config4", 262144, 6, 256), ("config5_full_1gpu", 2097152, 4, 64)]
             for name, n, k, pn in plan:
                 cfg = "config5" if name.startswith("config5") else name
                 try:
