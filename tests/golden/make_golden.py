@@ -181,6 +181,24 @@ def main():
             cfg.append(c)
     out["configs.json"] = cfg
 
+    # 6a. the delay-line programs past the first read-back.  The cursors advance per executed TRAM instruction
+    # (FX8010.cpp:909-967): config5's four reads + four writes per sample bring the first written word back at sample 2048
+    # of its 8192-slot line, config3's read / write pair at sample 1000 (and again at 2000).  2304 samples cover both; the
+    # input is the synthetic PCM (regenerated at test time, pinned here by its SHA-256), the output is stored.
+    import hashlib
+    longc = []
+    for name in ("config3", "config5"):
+        text = progs.CONFIGS[name]()
+        for inst in (0, 4095):
+            x = progs.stimulus(1, 2304, first_instance=inst)[:, 0].copy()
+            c = run_case("%s_long_inst%d" % (name, inst), text, x, regs=("ccr", "out", "rd", "a", "t") if name == "config3" else ("ccr", "out", "m", "u", "v", "d0", "d3", "w3"))
+            del c["program"]
+            c["input_sha256"] = hashlib.sha256(bytes.fromhex(c.pop("input"))).hexdigest()
+            c["config"] = name
+            c["instance"] = inst
+            longc.append(c)
+    out["configs_long.json"] = longc
+
     # 6b. non-finite values: what the x86 build of the reference does with NaN (either sign, payloads, signalling) and
     # Inf coming in through the PCM input, with NaNs made by the arithmetic itself (Inf * 0, Inf - Inf: the x86 default
     # NaN is NEGATIVE, 0xFFC00000), through saturating and non-saturating instructions, TRAM and the fp64 path

@@ -107,6 +107,34 @@ def test_config_programs(gpu, tier):
         run_case(gpu, dict(case), text=text)
 
 
+def test_delay_lines_past_the_first_read_back(gpu, tier):
+    """configs_long.json: config3 / config5 over 2304 samples of the REFERENCE's own output - config5's 8192-slot line hands
+    back its first written word at sample 2048 (four reads + four writes per sample, cursors per executed TRAM instruction,
+    source/FX8010.cpp:909-967, 1188-1211), config3's at 1000 and 2000 - in uneven blocks, so that reads issued a sample ahead
+    cross block ends after the wrap as well"""
+    import hashlib
+    for case in load("configs_long.json"):
+        text = progs.CONFIGS[case["config"]]()
+        S = case["shape"][0]
+        x1 = progs.stimulus(1, S, first_instance=case["instance"])[:, 0].copy()
+        assert hashlib.sha256(x1.view(np.uint32).tobytes()).hexdigest() == case["input_sha256"], "stimulus generator drifted"
+        N = 67
+        x = np.repeat(x1.reshape(S, 1), N, axis=1).copy()
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        cuts = [0, 999, 1000, 1003, 2047, 2049, 2100, S]
+        y = np.concatenate([b.process_block(x[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])], axis=0)
+        want = f32(case["output"]).view(np.uint32)
+        for n in (0, 63, 64, N - 1):
+            got = np.ascontiguousarray(y[:, n]).view(np.uint32)
+            bad = np.nonzero(want != got)[0]
+            assert bad.size == 0, "%s instance %d: first mismatch at sample %d" % (case["name"], n, bad[0])
+            assert b.instruction_counter_i(n) == case["counter"], (case["name"], n)
+            for reg, bits in case["registers"].items():
+                assert b.get_register_bits_i(reg, n) == bits, (case["name"], reg, n)
+        assert b.ood_flags() == 0
+
+
 def test_lut_probe_all_exponents(gpu, tier):
     probe = load("lut_probe.json")
     x1 = f32(probe["input"])

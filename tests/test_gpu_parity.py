@@ -854,6 +854,82 @@ def test_full_size_shard(gpu, name, monkeypatch):
         assert b.instruction_counter() == N * progs.count_instructions(text) * S * blocks
 
 
+def test_config5_feedback_in_uneven_blocks(gpu, monkeypatch):
+    """the headline program past its delay line's first read-back: 4 reads + 4 writes per sample walk the 8192-slot line in
+    2048 samples (cursors advance per executed TRAM instruction, reference source/FX8010.cpp:909-967, 1188-1211), so only runs
+    longer than that see written data again.  4 100 instances fed from the host over 2 250 samples in uneven blocks - ends at,
+    one before and one behind the wrap, blocks of one and two samples - against the oracle; tests/golden/configs_long.json
+    pins the same stretch with the reference's own words (test_gpu_golden.py)"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    text = progs.config5()
+    N, cuts = 4100, [0, 700, 1399, 2047, 2048, 2049, 2051, 2188, 2250]
+    x = progs.stimulus(N, cuts[-1])
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    y = np.concatenate([b.process_block(x[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])], axis=0)
+    assert b.info("kernel") >= 9
+    for n in (0, 1, 63, 64, 2049, 4031, 4032, 4095, 4096, N - 1):
+        o = Oracle(1)
+        assert o.load_text(text)
+        ref = o.process_block(x[:, n].copy())
+        bad = np.nonzero(bits(ref) != bits(y[:, n]))[0]
+        assert bad.size == 0, "instance %d: first mismatch at sample %d" % (n, bad[0])
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+        for r in ("d0", "d1", "d2", "d3", "m", "w0", "w3", "lp2", "ccr"):
+            assert b.get_register_bits_i(r, n) == o.get_register_bits(r), (r, n)
+        assert o.get_register_bits("d0") & 0x7fffffff, "the line never handed a written word back"
+    assert b.ood_flags() == 0
+    assert b.instruction_counter() == N * progs.count_instructions(text) * cuts[-1]
+
+
+def test_config5_full_shard_beyond_the_delay_line(gpu, monkeypatch):
+    """bench.py's workload as a test: the per-GPU shard of BASELINE configs[4] (262 144 instances, less 37: a ragged last
+    wavefront), PCM resident in HBM and generated there (bench.py device_stimulus), 2 304 samples in three launches - the
+    delay lines (8 GiB) wrap at sample 2048.  Instances spread over the shard against the oracle, bit for bit, and the
+    size-independent property: instances fed the same PCM produce the same words wherever they sit"""
+    import torch
+
+    import bench
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    text = progs.config5()
+    N, cuts = 262144 - 37, [0, 1500, 2050, 2304]
+    S = cuts[-1]
+    dev = torch.device("cuda", 0)
+    x = bench.device_stimulus(torch, N, S, 0, dev)
+    twins = [5, 64 * 500 + 63, N // 2 + 1, N - 1]
+    for t in twins[1:]:
+        x[:, t] = x[:, twins[0]]
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        b.process_block_dev(x[lo:hi].data_ptr(), y[lo:hi].data_ptr(), hi - lo)
+    b.sync()
+    assert b.info("kernel") >= 9 and b.info("waves_per_wg") == 1
+    picks = sorted(set([0, 63, 64, 4097, N - 65, N - 2] + [int(v) for v in np.linspace(0, N - 1, 40)]) - set(twins[1:]))
+    cols = torch.tensor(picks + twins, device=dev)
+    xs = x[:, cols].cpu().numpy()
+    ys = y[:, cols].cpu().numpy()
+    for j, t in enumerate(twins[1:], start=len(picks) + 1):
+        assert np.array_equal(bits(ys[:, j]), bits(ys[:, len(picks)])), "instance %d differs from its twin" % t
+    for j, n in enumerate(picks):
+        assert np.array_equal(bits(xs[:, j]), bits(progs.stimulus(1, S, first_instance=n)[:, 0])), "device stimulus differs from the host's"
+        o = Oracle(1)
+        assert o.load_text(text)
+        ref = o.process_block(xs[:, j].copy())
+        bad = np.nonzero(bits(ref) != bits(ys[:, j]))[0]
+        assert bad.size == 0, "instance %d: first mismatch at sample %d" % (n, bad[0])
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+        assert b.get_register_bits_i("d3", n) == o.get_register_bits("d3") and o.get_register_bits("d3") & 0x7fffffff
+    assert b.ood_flags() == 0
+    assert b.instruction_counter() == N * progs.count_instructions(text) * S
+    del b, x, y
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_api_sequences(gpu, seed, monkeypatch):
     """Random sequences of the calls a host makes between blocks - block lengths from 1 sample up, broadcast control

@@ -86,21 +86,88 @@ def test_every_block_length(gpu, stages, k, group, monkeypatch):
     run_and_compare(gpu, progs.config2(), x, list(zip(cuts[:-1], cuts[1:])), ["t", "s0", "s9", "s30", "out", "ccr"])
 
 
+def wide_packet_program(W):
+    return ("input in 0\noutput out 0\ncontrol k = 0.25\n" + "".join("static a%d\n" % i for i in range(W))
+            + "".join("static s%d_%d\n" % (i, j) for i in range(W) for j in range(6))
+            + "".join("macs a%d, in, in, 0.%02d\n" % (i, i + 1) for i in range(W))
+            + "".join("interp s%d_%d, s%d_%d, k, a%d\nmacs a%d, s%d_%d, in, 0.05\n" % (i, j, i, j, i, i, i, j) for j in range(6) for i in range(W))
+            + "macs out, 0, a0, 1.0\n" + "".join("macs out, out, a%d, 0.1\n" % i for i in range(1, W)) + "end")
+
+
 @pytest.mark.parametrize("width", [4, 12])
 def test_wide_packets(gpu, stages, width):
     """`width` parallel one-pole chains advance side by side: 5 or 13 rows cross every cut.  With 13 rows a buffer takes 32 KB and
     the LDS holds a ring of four for eight stages (group = 1) - by the default policy, no knob"""
     stages(None)
     W = width
-    text = ("input in 0\noutput out 0\ncontrol k = 0.25\n" + "".join("static a%d\n" % i for i in range(W))
-            + "".join("static s%d_%d\n" % (i, j) for i in range(W) for j in range(6))
-            + "".join("macs a%d, in, in, 0.%02d\n" % (i, i + 1) for i in range(W))
-            + "".join("interp s%d_%d, s%d_%d, k, a%d\nmacs a%d, s%d_%d, in, 0.05\n" % (i, j, i, j, i, i, i, j) for j in range(6) for i in range(W))
-            + "macs out, 0, a0, 1.0\n" + "".join("macs out, out, a%d, 0.1\n" % i for i in range(1, W)) + "end")
+    text = wide_packet_program(W)
     N, S = 130, 345
     x = progs.stimulus(N, S)
     b = run_and_compare(gpu, text, x, [(0, 300), (300, 301), (301, S)], ["a0", "a%d" % (W - 1), "s0_0", "s%d_5" % (W - 1), "out", "ccr"])
     assert b.info("waves_per_wg") == 8
+
+
+def compare_sampled(b, text, x, cuts, ys, picks, regs):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(n):
+        o = Oracle(1)
+        assert o.load_text(text)
+        for (lo, hi), y in zip(zip(cuts[:-1], cuts[1:]), ys):
+            r = o.process_block(x[lo:hi, n].copy())
+            if not np.array_equal(r.view(np.uint32), np.ascontiguousarray(y[:, n]).view(np.uint32)):
+                return "instance %d block %d:%d differs" % (n, lo, hi)
+        return o.instruction_counter(), [o.get_register_bits(r) for r in regs]
+
+    with ThreadPoolExecutor(max_workers=8) as pool:   # (the oracle releases the GIL)
+        res = list(pool.map(one, picks))
+    for n, r in zip(picks, res):
+        assert not isinstance(r, str), r
+    for n, r in list(zip(picks, res))[:: max(1, len(picks) // 48)]:   # (each read is a round trip to the device)
+        assert b.instruction_counter_i(n) == r[0], n
+        assert [b.get_register_bits_i(reg, n) for reg in regs] == r[1], n
+
+
+def test_config2_at_its_baseline_shape(gpu, stages):
+    """BASELINE configs[1] as bench.py times it: 4 096 instances of the 64-instruction chain in blocks of >= 300 samples, the
+    library's own choice of stages (eight wavefronts per workgroup, a barrier every eighth sample, the long-block class) -
+    EVERY instance against the oracle over three blocks, state carried"""
+    stages(None)
+    text = progs.config2()
+    N, cuts = 4096, [0, 300, 301, 777]
+    x = progs.stimulus(N, cuts[-1])
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    ys = [b.process_block(x[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    assert b.info("waves_per_wg") == 8 and b.info("kernel") >= 9 and b.info("xlate_builds") == 1
+    compare_sampled(b, text, x, cuts, ys, list(range(N)), ["t", "s0", "s15", "s30", "out", "ccr"])
+    assert b.ood_flags() == 0
+    assert b.instruction_counter() == N * 64 * cuts[-1]
+
+
+@pytest.mark.parametrize("program", ["config2", "wide12"])
+@pytest.mark.parametrize("N", [4096, 32768, 98304, 114688])
+def test_default_policy_across_batch_sizes(gpu, stages, program, N):
+    """no FX_STAGES* knob: the library picks stage count, step length and ring size from the batch (64 .. 1 792 wavefronts of
+    instances: either side of every threshold of the policy, several workgroups per CU sharing its LDS) - for the filter chain
+    (two rows per cut) and for twelve parallel chains (thirteen rows per cut: short rings).  Round 3's sweep found wrong words
+    at 98 304 instances x 8 stages (a ring shorter than the pipeline); these are the shapes it came from"""
+    stages(None)
+    for knob in ("FX_STAGES_GROUP", "FX_STAGES_DEBUG"):
+        os.environ.pop(knob, None)
+    text = progs.config2() if program == "config2" else wide_packet_program(12)
+    cuts = [0, 300, 301, 345]
+    x = progs.stimulus(N, cuts[-1])
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    ys = [b.process_block(x[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    assert b.info("kernel") >= 9
+    picks = sorted(set([0, 63, 64, 511, 512, N // 2 - 1, N // 2, N - 64, N - 1] + [int(v) for v in np.linspace(0, N - 1, 300)]))
+    regs = ["t", "s0", "s30", "out", "ccr"] if program == "config2" else ["a0", "a11", "s0_0", "s11_5", "out", "ccr"]
+    compare_sampled(b, text, x, cuts, ys, picks, regs)
+    assert b.ood_flags() == 0
+    assert b.instruction_counter() == N * progs.count_instructions(text) * cuts[-1]
+    print("policy: %s N=%d -> %d stage(s), LDS %d B per workgroup" % (program, N, b.info("waves_per_wg"), b.info("lds_bytes_per_wg")))
 
 
 def test_code_follows_the_block_length(gpu, stages):

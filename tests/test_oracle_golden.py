@@ -100,6 +100,27 @@ def test_config_programs_against_reference():
         assert o.ood_flags() == 0
 
 
+def test_delay_lines_past_the_first_read_back_against_reference():
+    """configs_long.json: config3 / config5 over 2304 samples - the reference's cursors advance per executed TRAM instruction
+    (source/FX8010.cpp:909-967), so config5's 8192-slot line hands back its first written word at sample 2048 (config3 at 1000
+    and 2000); the 384-sample cases of configs.json never get there"""
+    import hashlib
+    for case in load("configs_long.json"):
+        case = dict(case)
+        text = progs.CONFIGS[case["config"]]()
+        x = progs.stimulus(1, case["shape"][0], first_instance=case["instance"])[:, 0].copy()
+        assert hashlib.sha256(x.view(np.uint32).tobytes()).hexdigest() == case["input_sha256"], "stimulus generator drifted"
+        case["input"] = x.view(np.uint32).tobytes().hex()
+        o = run_oracle(case, text=text)
+        assert o.ood_flags() == 0
+        if case["config"] == "config5":   # the fixture really reads written words back: d0..d3 are no longer the line's zeros
+            assert case["registers"]["d0"] & 0x7fffffff and case["registers"]["d3"] & 0x7fffffff
+            short = Oracle(1)
+            assert short.load_text(text)
+            short.process_block(x[:2048].copy())
+            assert short.get_register_bits("d0") == 0 and short.get_register_bits("d3") == 0   # ... and one sample earlier they were
+
+
 def test_loader_corpus():
     for c in load("parser_corpus.json"):
         o = Oracle(1)
