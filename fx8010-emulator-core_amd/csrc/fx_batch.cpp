@@ -14,7 +14,11 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "../../include/fx8010_amd.h"
 
@@ -58,12 +62,13 @@ Batch::Batch(int64_t nInstances, int channels, int device) : prog_(channels) {
 
 Batch::~Batch() {
     (void)hipSetDevice(device_);
+    drainBuilder(true);
     if (stream_) (void)hipStreamSynchronize(stream_);
     (void)hipFree(dState_);
     (void)hipFree(dITram_);
     (void)hipFree(dXTram_);
     (void)hipFree(dLut_);
-    (void)hipFree(dStream_);
+    clearCodeCache();
     (void)hipFree(dScratch_);
     (void)hipFree(dTracks_);
     (void)hipFree(dIn_);
@@ -76,7 +81,6 @@ Batch::~Batch() {
     }
     if (copyIn_) (void)hipStreamDestroy(copyIn_);
     if (copyOut_) (void)hipStreamDestroy(copyOut_);
-    if (xlateModule_) (void)hipModuleUnload(xlateModule_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -96,8 +100,16 @@ int Batch::hipFail(hipError_t e, const char* where) {
     return fail(e == hipErrorOutOfMemory ? FX_E_MEMORY : FX_E_NODEVICE, std::string(where) + ": " + hipGetErrorString(e));
 }
 
-bool Batch::loadFile(const std::string& path) { return afterLoad(prog_.loadFile(path)) == 1; }
-bool Batch::loadText(const std::string& text) { return afterLoad(prog_.loadText(text)) == 1; }
+bool Batch::loadFile(const std::string& path) { drainBuilder(false); return afterLoad(prog_.loadFile(path)) == 1; }
+bool Batch::loadText(const std::string& text) { drainBuilder(false); return afterLoad(prog_.loadText(text)) == 1; }
+
+int Batch::setOption(unsigned option, bool on) {
+    if (option & ~kOptAll) return -3;
+    drainBuilder(false);
+    prog_.options = on ? (prog_.options | option) : (prog_.options & ~option);
+    lowDirty_ = true;
+    return 0;
+}
 
 int Batch::afterLoad(bool ok) {
     (void)hipSetDevice(device_);
@@ -105,9 +117,26 @@ int Batch::afterLoad(bool ok) {
     const size_t old = hostValue_.size();
     hostValue_.resize(prog_.regs.size());
     forcedLane_.resize(prog_.regs.size(), 0);
+    laneWritten_.resize(prog_.regs.size(), 0);
     for (size_t r = old; r < prog_.regs.size(); ++r) hostValue_[r] = prog_.regs[r].value;
     lowDirty_ = true;
     daneHipOnly_ = false;
+    // code generated for the program as it was is of no use any more (registers and instructions accumulate over loads)
+    clearCodeCache();
+    ++loadGen_;
+    wantedClass_ = -1;
+    otherClassBlocks_ = 0;
+    // registers the program itself keeps per-instance (it writes them, reads them from a delay line or the PCM input): a
+    // property of the program, valid until the next load
+    intrinsicLane_.assign(prog_.regs.size(), 0);
+    readByProgram_.assign(prog_.regs.size(), 0);
+    if (!prog_.instrs.empty()) {   // (also after a load that failed: its registers and instructions have been appended, as in the reference)
+        const Lowered probe = lowerProgram(prog_, hostValue_, std::vector<uint8_t>(prog_.regs.size(), 0), 1, false, 1);
+        for (size_t r = 0; r < probe.rowOfReg.size() && r < intrinsicLane_.size(); ++r) intrinsicLane_[r] = probe.rowOfReg[r] >= 0;
+        for (const Instr& in : prog_.instrs)
+            for (int o : {in.a, in.x, in.y})
+                if (o >= 0 && (size_t)o < readByProgram_.size()) readByProgram_[(size_t)o] = 1;
+    }
     // a load that failed after an earlier good one has still appended registers (literals and declarations are created
     // before the error, as in the reference): the state block must follow, or set_register of a new one would land in
     // the rows behind the registers (output latches, cursors, LFSR, counter)
@@ -116,6 +145,7 @@ int Batch::afterLoad(bool ok) {
         return 0;
     }
     loaded_ = true;
+    if (controlMode_) markControls();   // (a further load may have declared more controls)
     if (ensureState() != 0) return 0;
     return 1;
 }
@@ -173,7 +203,7 @@ int Batch::ensureState() {
     return fillRows(rows, values);
 }
 
-int Batch::ensureTram() {
+int Batch::ensureTram(const Lowered& low) {
     auto grow = [&](float*& buf, int& have, int want) -> int {
         if (want <= have) return 0;
         size_t waves = (size_t)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
@@ -194,8 +224,8 @@ int Batch::ensureTram() {
         have = want;
         return 0;
     };
-    int rc = grow(dITram_, iSlotsAlloc_, low_.iSlots);
-    if (rc == 0) rc = grow(dXTram_, xSlotsAlloc_, low_.xSlots);
+    int rc = grow(dITram_, iSlotsAlloc_, low.iSlots);
+    if (rc == 0) rc = grow(dXTram_, xSlotsAlloc_, low.xSlots);
     return rc;
 }
 
@@ -222,8 +252,8 @@ int Batch::chooseInstPerLane() const {
 bool Batch::intrinsicLane(int reg) const { return reg >= 0 && (size_t)reg < intrinsicLane_.size() && intrinsicLane_[reg] != 0; }
 
 bool Batch::laneResident(int reg) const {
-    if ((reg < (int)forcedLane_.size() && forcedLane_[reg]) || tracked(reg)) return true;
-    return !lowDirty_ ? low_.rowOfReg[reg] >= 0 : (reg < (int)low_.rowOfReg.size() && low_.rowOfReg[reg] >= 0);
+    if ((reg < (int)forcedLane_.size() && (forcedLane_[reg] || laneWritten_[reg])) || tracked(reg)) return true;
+    return !lowDirty_ ? c_.low.rowOfReg[reg] >= 0 : (reg < (int)c_.low.rowOfReg.size() && c_.low.rowOfReg[reg] >= 0);
 }
 
 // How many pipeline stages to ask the translator for; FX_STAGES pins the number (1 = never).  Measured with config2's filter
@@ -239,10 +269,305 @@ int Batch::stagesWanted(int variant) const {
     return 1;
 }
 
+// What the generated code is a function of.  Two calls with equal keys would build the same Code, so a finished one is reused
+// (ensureLowered): the program (a load counter: registers and instructions only ever accumulate), the options, which registers
+// have rows although no instruction writes them (per-instance values, moving controls, control tracks), the values of all the
+// others (they are folded into the code as literals), the block-length class staged code is generated for, whether the
+// translation is put off because compiled-in controls keep changing, and the diagnostic knobs of the environment.
+std::string Batch::codeKey(int blockClass, bool defer) const { return codeKeyFor(laneForced(), blockClass, defer); }
+
+std::string Batch::codeKeyFor(const std::vector<uint8_t>& forced, int blockClass, bool defer) const {
+    std::string k;
+    auto word = [&](int64_t v) { k.append(reinterpret_cast<const char*>(&v), 8); };
+    word(loadGen_); word((int64_t)prog_.options); word(blockClass); word(defer ? 1 : 0); word(daneHipOnly_ ? 1 : 0);
+    word(((iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0) && instPerLane_ != 1) ? instPerLane_ : 0);   // delay lines tiled for K instances per lane pin the HIP C++ kernel
+    for (const char* name : {"FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_STAGES_GROUP"}) {
+        const char* v = std::getenv(name);
+        k.append(v ? v : "");
+        k.push_back('\0');
+    }
+    for (size_t r = 0; r < hostValue_.size(); ++r) {
+        const bool f = r < forced.size() && forced[r];
+        const uint32_t w = f ? 0x7fc0f0f0u : bitsOf(hostValue_[r]);
+        k.push_back(f ? 1 : 0);
+        k.append(reinterpret_cast<const char*>(&w), 4);
+    }
+    for (int reg : trackRegs_) word(reg);   // (slot order is part of the code)
+    return k;
+}
+
+void Batch::releaseCode(Code& c) {
+    if (c.module) (void)hipModuleUnload(c.module);
+    if (c.dStream) (void)hipFree(c.dStream);
+    c.module = nullptr;
+    c.fn = nullptr;
+    c.dStream = nullptr;
+    c.streamCap = 0;
+}
+
+void Batch::clearCodeCache() {
+    (void)hipSetDevice(device_);
+    waitLastLaunch();   // the most recent launch may still run one of them
+    releaseCode(c_);
+    c_ = Code();
+    for (std::unique_ptr<Code>& e : cache_) releaseCode(*e);
+    cache_.clear();
+}
+
+// c_ -> cache_.  The code that is being replaced may still be running: nothing of it is touched; only when the cache is full
+// the least recently used entry goes, behind the most recent launch.
+void Batch::stashCode() {
+    if (c_.key.empty()) {   // nothing finished (a failed build): drop the pieces
+        if (c_.module || c_.dStream) { waitLastLaunch(); releaseCode(c_); }
+        c_ = Code();
+        return;
+    }
+    c_.lastUse = ++useClock_;
+    cache_.push_back(std::make_unique<Code>(std::move(c_)));
+    c_ = Code();
+    if (cache_.size() > kCodeCache) {
+        size_t lru = 0;
+        for (size_t k = 1; k < cache_.size(); ++k)
+            if (cache_[k]->lastUse < cache_[lru]->lastUse) lru = k;
+        waitLastLaunch();
+        releaseCode(*cache_[lru]);
+        cache_.erase(cache_.begin() + (long)lru);
+    }
+}
+
+bool Batch::cachedCode(const std::string& key) const {
+    for (const std::unique_ptr<Code>& e : cache_)
+        if (e->key == key) return true;
+    return false;
+}
+
+bool Batch::adoptCode(const std::string& key) {
+    for (size_t k = 0; k < cache_.size(); ++k)
+        if (cache_[k]->key == key) {
+            c_ = std::move(*cache_[k]);
+            cache_.erase(cache_.begin() + (long)k);
+            c_.lastUse = ++useClock_;
+            return true;
+        }
+    return false;
+}
+
+// staged code is generated for a class of block lengths - when the batch is small enough to be staged at all
+int Batch::keyClass() const {
+    if (stagesWanted(0) < 2) return -1;
+    return wantedClass_ >= 0 ? wantedClass_ : stageBlockClass(std::max(pendingSamples_, 1));
+}
+
+bool Batch::deferWanted() const {
+    // controls that are compiled into the code keep changing (a set_register within the last few blocks): a translation costs
+    // a module load (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until they have been quiet.  (A block of
+    // more than ~half a millisecond of translated code pays for its translation at once.)
+    const char* forceHip = std::getenv("FX_KERNEL");
+    const double blockMs = (double)n_ * (double)pendingSamples_ * (double)std::max<size_t>(prog_.instrs.size(), 1) / 1e10;
+    return controlHeat_ > 0 && blockMs < 0.5 && !(prog_.options & kOptTramDane) && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0);
+}
+
 int Batch::ensureLowered() {
     if (!loaded_ || !prog_.ready) return fail(FX_E_NOTREADY, "no program loaded");
     if (!lowDirty_) return 0;
-    std::vector<int> before = low_.rowOfReg;
+    (void)hipSetDevice(device_);
+    collectBuilt();
+    const int blockClass = keyClass();
+    const bool defer = deferWanted();
+    const std::string key = codeKey(blockClass, defer);
+    if (!c_.key.empty() && c_.key == key) {   // (a register written with the value it had, a schedule armed again: nothing to do)
+        lowDirty_ = false;
+        return 0;
+    }
+    stashCode();
+    bool have = adoptCode(key);
+    if (!have && waitBuild(key)) {   // the builder thread is at it (the control variant, asked for at the first block): shorter than starting over
+        collectBuilt();
+        have = adoptCode(key);
+    }
+    if (have) {   // code for this shape exists: a pointer swap
+        ++cacheHits_;
+        lowDirty_ = false;
+        prebuildControlVariant();
+        return 0;
+    }
+    std::string err;
+    const int rc = buildCodeInto(c_, buildInputs(key, blockClass, defer), false, &err);
+    if (rc == FX_E_RETRY_) {   // (a DANE-model program the translator could not take: the HIP C++ kernel from now on)
+        stashCode();
+        return ensureLowered();
+    }
+    if (rc != 0) return fail(rc, err);
+    lowDirty_ = false;
+    prebuildControlVariant();
+    return 0;
+}
+
+// ---- the builder thread: code generated off the caller's thread -------------------------------------------------------------
+// A translation and its module load take milliseconds; a real-time caller has 667 us per 32-sample block.  Two
+// changes of code can be seen coming: the variant in which the declared controls have rows (wanted at the first touch of a
+// slider - asked for right after the first build) and the code for another class of block lengths (asked for at the first
+// block of that class, while the code in force - correct for every length, only slower - keeps running).  Both are built
+// here and handed over through `finished`; the caller's thread picks them up at its next lowering (collectBuilt) as cache
+// entries, so what it does then is a pointer swap.  FX_BUILDER=0: no thread, everything on the caller's (diagnostics).
+struct Batch::Builder {
+    std::thread thread;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<BuildInputs> jobs;
+    std::string running;                          // key being built
+    std::vector<std::unique_ptr<Code>> finished;
+    std::vector<std::string> failed;              // keys the offline path cannot build (left to the caller's thread)
+    bool quit = false;
+};
+
+bool Batch::builderWanted() const {
+    const char* knob = std::getenv("FX_BUILDER");
+    return !(knob && std::atoi(knob) == 0);
+}
+
+void Batch::requestBuild(BuildInputs&& in) {
+    if (!builderWanted()) return;
+    if (!builder_) {
+        builder_.reset(new Builder);
+        Builder* b = builder_.get();
+        b->thread = std::thread([this, b] {
+            (void)hipSetDevice(device_);
+            std::unique_lock<std::mutex> lock(b->mu);
+            for (;;) {
+                b->cv.wait(lock, [b] { return b->quit || !b->jobs.empty(); });
+                if (b->quit) return;
+                BuildInputs job = std::move(b->jobs.front());
+                b->jobs.pop_front();
+                b->running = job.key;
+                lock.unlock();
+                std::unique_ptr<Code> c(new Code);
+                std::string err;
+                const int rc = buildCodeInto(*c, job, true, &err);
+                if (rc != 0) releaseCode(*c);
+                lock.lock();
+                b->running.clear();
+                if (rc == 0) b->finished.push_back(std::move(c));
+                else b->failed.push_back(job.key);
+                b->cv.notify_all();
+            }
+        });
+    }
+    std::lock_guard<std::mutex> lock(builder_->mu);
+    if (builder_->running == in.key) return;
+    for (const BuildInputs& j : builder_->jobs) if (j.key == in.key) return;
+    for (const std::unique_ptr<Code>& c : builder_->finished) if (c->key == in.key) return;
+    for (const std::string& k : builder_->failed) if (k == in.key) return;
+    builder_->jobs.push_back(std::move(in));
+    builder_->cv.notify_all();
+}
+
+void Batch::collectBuilt() {
+    if (!builder_) return;
+    std::vector<std::unique_ptr<Code>> got;
+    {
+        std::lock_guard<std::mutex> lock(builder_->mu);
+        got.swap(builder_->finished);
+    }
+    for (std::unique_ptr<Code>& c : got) {
+        if (cachedCode(c->key) || c_.key == c->key) { releaseCode(*c); continue; }
+        c->lastUse = ++useClock_;
+        cache_.push_back(std::move(c));
+        if (cache_.size() > kCodeCache) {
+            size_t lru = 0;
+            for (size_t k = 1; k < cache_.size(); ++k)
+                if (cache_[k]->lastUse < cache_[lru]->lastUse) lru = k;
+            waitLastLaunch();
+            releaseCode(*cache_[lru]);
+            cache_.erase(cache_.begin() + (long)lru);
+        }
+    }
+}
+
+bool Batch::buildPending(const std::string& key) {
+    if (!builder_) return false;
+    std::lock_guard<std::mutex> lock(builder_->mu);
+    if (builder_->running == key) return true;
+    for (const BuildInputs& j : builder_->jobs) if (j.key == key) return true;
+    return false;
+}
+
+// true: the builder has (or had) this key in hand and is done with it now
+bool Batch::waitBuild(const std::string& key) {
+    if (!builder_) return false;
+    std::unique_lock<std::mutex> lock(builder_->mu);
+    auto pending = [&] {
+        if (builder_->running == key) return true;
+        for (const BuildInputs& j : builder_->jobs) if (j.key == key) return true;
+        return false;
+    };
+    if (!pending()) {
+        for (const std::unique_ptr<Code>& c : builder_->finished) if (c->key == key) return true;
+        return false;
+    }
+    builder_->cv.wait(lock, [&] { return !pending(); });
+    return true;
+}
+
+// before anything a build reads changes (a load, an option) and at the end: no job running, none queued, nothing to pick up
+void Batch::drainBuilder(bool stop) {
+    if (!builder_) return;
+    {
+        std::unique_lock<std::mutex> lock(builder_->mu);
+        builder_->jobs.clear();
+        builder_->cv.wait(lock, [&] { return builder_->running.empty(); });
+        for (std::unique_ptr<Code>& c : builder_->finished) releaseCode(*c);
+        builder_->finished.clear();
+        builder_->failed.clear();
+        if (stop) {
+            builder_->quit = true;
+            builder_->cv.notify_all();
+        }
+    }
+    if (stop) {
+        builder_->thread.join();
+        builder_.reset();
+    }
+}
+
+void Batch::prebuildControlVariant() {
+    if (controlMode_ || c_.key.empty() || !c_.useXlate || !builderWanted()) return;
+    std::vector<uint8_t> forced = laneForced();
+    bool any = false;
+    for (const std::string& name : prog_.controls) {
+        const int r = prog_.findRegister(name);
+        if (r < 0 || forced[(size_t)r] || intrinsicLane(r) || !readByProgram(r) || !movableControl(r)) continue;
+        forced[(size_t)r] = 1;
+        any = true;
+    }
+    if (!any) return;
+    const int blockClass = keyClass();
+    BuildInputs in = buildInputs(codeKeyFor(forced, blockClass, false), blockClass, false);
+    if (cachedCode(in.key)) return;
+    in.forced = forced;
+    requestBuild(std::move(in));
+}
+
+Batch::BuildInputs Batch::buildInputs(const std::string& key, int blockClass, bool defer) const {
+    BuildInputs in;
+    in.key = key;
+    in.blockClass = blockClass;
+    in.defer = defer;
+    in.hostValue = hostValue_;
+    in.forced = laneForced();
+    in.trackRegs = trackRegs_;
+    return in;
+}
+
+// The lowering itself, into an empty Code: lower the program for the tier that takes it, translate it where it can be
+// translated, load the code object, upload the tables.  offline: on the builder thread, while the batch keeps running other
+// code - nothing of the batch's device state may change (no new state rows, no delay-line allocation) and only the translated
+// tier qualifies; whatever else the program would need is left to the caller's thread (FX_E_NOTREADY).
+int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::string* err) {
+    auto fail = [&](int code, const std::string& what) { *err = what; return code; };
+    auto hipFail = [&](hipError_t e, const char* where) { *err = std::string(where) + ": " + hipGetErrorString(e); return e == hipErrorOutOfMemory ? FX_E_MEMORY : FX_E_NODEVICE; };
+    const int blockClass = in.blockClass;
+    const bool defer = in.defer;
     // Preferred: the hand-written gfx950 interpreter (one instance per lane, bookkeeping in VGPRs).
     // Programs it does not cover run on the HIP C++ kernel.  TRAM tiling pins K once allocated.
     Lowered fresh;
@@ -254,8 +579,8 @@ int Batch::ensureLowered() {
         // first choice: register file in VGPRs (row pitch 1 = plain indices), else in LDS
         const bool tryVgpr = !(forceHip && std::strcmp(forceHip, "asm_lds") == 0);
         if (tryVgpr) {
-            fresh = lowerProgram(prog_, hostValue_, laneForced(), 1, false, 1);
-            asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
+            fresh = lowerProgram(prog_, in.hostValue, in.forced, 1, false, 1);
+            asmOk = fresh.error.empty() && asmEligible(fresh, &c.asmWhyNot);
             if (asmOk) {
                 // smallest VGPR build that holds the register file = most wavefronts per SIMD
                 int v = ASM_V64;
@@ -280,178 +605,169 @@ int Batch::ensureLowered() {
                     for (int q = smallest; q < ASM_VARIANTS; ++q)
                         if (std::strcmp(pin, tags[q]) == 0) v = q;
                 }
-                asmVariant_ = (AsmVariant)v;
+                c.variant = (AsmVariant)v;
             }
         }
         if (!asmOk) {
-            fresh = lowerProgram(prog_, hostValue_, laneForced(), 1, false);
-            asmOk = fresh.error.empty() && asmEligible(fresh, &asmWhyNot_);
-            asmVariant_ = ASM_LDS;
+            fresh = lowerProgram(prog_, in.hostValue, in.forced, 1, false);
+            asmOk = fresh.error.empty() && asmEligible(fresh, &c.asmWhyNot);
+            c.variant = ASM_LDS;
         }
         // the opt-in DANE delay-line model exists as generated code (translated tier) and in the HIP C++ kernel only
-        if (asmOk && fresh.tramDane && (asmVariant_ == ASM_LDS || (forceHip && std::strncmp(forceHip, "asm", 3) == 0))) {
+        if (asmOk && fresh.tramDane && (c.variant == ASM_LDS || (forceHip && std::strncmp(forceHip, "asm", 3) == 0))) {
             asmOk = false;
-            asmWhyNot_ = "opt-in DANE delay-line model: no interpreter handlers";
+            c.asmWhyNot = "opt-in DANE delay-line model: no interpreter handlers";
         }
     } else {
-        asmWhyNot_ = "disabled by FX_KERNEL / FX_INST_PER_LANE";
+        c.asmWhyNot = "disabled by FX_KERNEL / FX_INST_PER_LANE";
     }
-    if (!asmOk) fresh = lowerProgram(prog_, hostValue_, laneForced(), chooseInstPerLane());
+    if (!asmOk && offline) return fail(FX_E_NOTREADY, "offline build: not a program for the assembly tiers");
+    if (!asmOk) fresh = lowerProgram(prog_, in.hostValue, in.forced, chooseInstPerLane());
     if (!fresh.error.empty()) return fail(FX_E_PROGRAM, fresh.error);
-    instPerLane_ = fresh.instPerLane;
-    useAsm_ = asmOk;
-    int rc = ensureState();
-    if (rc != 0) return rc;
-    // registers that were uniform and are per-instance from now on: seed their rows
-    std::vector<uint32_t> rows, values;
-    for (size_t r = 0; r < fresh.rowOfReg.size(); ++r) {
-        const bool was = r < before.size() && before[r] >= 0;
-        const bool forced = forcedLane_[r] != 0 || tracked((int)r);  // already seeded (every register's state row is kept valid)
-        if (fresh.rowOfReg[r] >= 0 && !was && !forced) { rows.push_back((uint32_t)r); values.push_back(bitsOf(hostValue_[r])); }
+    if (offline && (fresh.instPerLane != instPerLane_ || fresh.iSlots > iSlotsAlloc_ || fresh.xSlots > xSlotsAlloc_ || makeLayout((int)prog_.regs.size(), prog_.numChannels).totalRows != stateRows_))
+        return fail(FX_E_NOTREADY, "offline build: the batch's device state would have to change");
+    int rc = 0;
+    if (!offline) {
+        instPerLane_ = fresh.instPerLane;
+        rc = ensureState();
+        if (rc != 0) { *err = lastError_; return rc; }
     }
-    low_ = std::move(fresh);
-    // registers the program itself keeps per-instance (it writes them): a static property, valid until the next load
-    intrinsicLane_.assign(low_.rowOfReg.size(), 0);
-    for (size_t r = 0; r < low_.rowOfReg.size(); ++r) intrinsicLane_[r] = low_.rowOfReg[r] >= 0 && !forcedLane_[r] && !tracked((int)r);
-    if (!rows.empty() && (rc = fillRows(rows, values)) != 0) return rc;
-    if ((rc = ensureTram()) != 0) return rc;
+    c.useAsm = asmOk;
+    // (a register that turns per-instance needs no seeding: the state row of EVERY register holds its current value at all
+    // times - ensureState fills new ones, setRegister writes through - and a per-instance write made before the first block
+    // must survive the first lowering)
+    c.low = std::move(fresh);
+    if (!offline) {
+        if ((rc = ensureTram(c.low)) != 0) { *err = lastError_; return rc; }
+    }
 
     // upload: steady | last | row table
-    useXlate_ = false;
-    xlateStages_ = 1;
-    xlateDeferred_ = false;
-    // (a block of more than ~half a millisecond of translated code pays for its translation at once)
-    const double blockMs = (double)n_ * (double)pendingSamples_ * (double)std::max(low_.staticCount, 1) / 1e10;
-    if (useAsm_ && asmVariant_ != ASM_LDS && controlHeat_ > 0 && blockMs < 0.5 && !low_.tramDane && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0)) {
+    c.useXlate = false;
+    c.stages = 1;
+    c.deferred = false;
+    if (c.useAsm && c.variant != ASM_LDS && defer) {
         // controls are moving (a set_register within the last few blocks): a translation costs a module load
         // (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until the controls have been quiet
-        xlateDeferred_ = true;
-        xlateWhyNot_ = "deferred: control registers are changing";
-    } else if (useAsm_ && asmVariant_ != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
+        c.deferred = true;
+        c.xlateWhyNot = "deferred: control registers are changing";
+    } else if (c.useAsm && c.variant != ASM_LDS && !(forceHip && std::strncmp(forceHip, "asm", 3) == 0)) {
         // first choice for a VGPR build: translate the program into gfx950 code (FX_KERNEL=asm* pins the interpreter)
-        const std::vector<MicroOp> steadyRecords = encodeAsmStream(low_.steady, nullptr, true), lastRecords = encodeAsmStream(low_.last, nullptr, true);
+        const std::vector<MicroOp> steadyRecords = encodeAsmStream(c.low.steady, nullptr, true), lastRecords = encodeAsmStream(c.low.last, nullptr, true);
         std::vector<int> trackRows;
-        for (int reg : trackRegs_) trackRows.push_back(low_.rowOfReg[(size_t)reg]);
-        XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, low_.nRows, low_.inRow, low_.latchRow, trackRows);
+        for (int reg : in.trackRegs) trackRows.push_back(c.low.rowOfReg[(size_t)reg]);
+        XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, c.low.nRows, c.low.inRow, c.low.latchRow, trackRows);
         // 256 bytes per wavefront and slot; the Infinity Cache holds 256 MiB
         xprog.tramStreaming = ((size_t)iSlotsAlloc_ + (size_t)xSlotsAlloc_) * (((size_t)n_ + 63) / 64) * 256 > ((size_t)512 << 20);
         XlateImage image;
         const XlateTemplate* tmpl = nullptr;
         bool built = false;
-        tmpl = xlateTemplate(asmVariant_, &xlateWhyNot_);
+        tmpl = xlateTemplate(c.variant, &c.xlateWhyNot);
         // Small batches leave SIMDs empty (and a lone wavefront issues an instruction every ~4.5 clocks): cut the program
         // into stages run by the wavefronts of one workgroup (fx_xlate.hpp StageInfo) until ~4 wavefronts per SIMD are in
         // flight.  FX_STAGES pins the number asked for (1 = never).
-        int wantStages = stagesWanted((int)asmVariant_);
+        int wantStages = stagesWanted((int)c.variant);
         // Measured with config2 at 4 096 instances (profiles/r03b_stage_blocks.txt): a block of 32 samples takes 27 us unstaged, 32 us
         // in 8 stages with a barrier every 8 samples (3 x 7 steps of 8 samples to fill and drain) and 21 us in 4 stages with a
         // barrier per sample; 128 samples 69 / 48 / 40 us (8 stages, every 2 samples); from 256 samples on the long steps win
-        const int blockClass = stageBlockClass(std::max(pendingSamples_, 1));
         const int maxGroup = blockClass == 0 ? 1 : (blockClass == 1 ? 2 : kStageGroupMax);
         if (blockClass == 0 && !std::getenv("FX_STAGES")) wantStages = std::min(wantStages, 4);
-        stagedForClass_ = blockClass;
-        otherClassBlocks_ = 0;
-        stagesWhyNot_.clear();
+        c.blockClass = blockClass;
+        c.stagesWhyNot.clear();
         if (tmpl && wantStages >= 2) {
-            const StagePlan plan = planStages(steadyRecords, lastRecords, xprog, low_.nRows, wantStages);
-            stagesWhyNot_ = plan.why;
+            const StagePlan plan = planStages(steadyRecords, lastRecords, xprog, c.low.nRows, wantStages);
+            c.stagesWhyNot = plan.why;
             std::string why;
+            c.classMatters = !plan.cuts.empty();
             if (!plan.cuts.empty()) {
                 // (several workgroups per CU must fit its 160 KiB of LDS together)
                 const int64_t groupsPerCu = std::max<int64_t>(1, ((n_ + 63) / 64 + 255) / 256);
-                const uint32_t ldsBudget = (uint32_t)std::min<int64_t>(144 * 1024, 160 * 1024 / groupsPerCu - 256);
+                const uint32_t ldsBudget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(144 * 1024, 160 * 1024 / groupsPerCu - 256));
                 built = buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, plan, &image, nullptr, nullptr, &why, ldsBudget, maxGroup);
-                if (!built) { stagesWhyNot_ = why; image = XlateImage(); }
+                if (!built) { c.stagesWhyNot = why; image = XlateImage(); }
             }
         }
-        if (!built) built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &xlateWhyNot_);
+        if (!built) built = tmpl && buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &c.xlateWhyNot);
         if (built) {
-            waitLastLaunch();  // the previous launch may still run the old code
-            if (xlateModule_) (void)hipModuleUnload(xlateModule_);
-            xlateModule_ = nullptr;
-            xlateFn_ = nullptr;
-            hipError_t me = hipModuleLoadData(&xlateModule_, image.elf.data());
-            if (me == hipSuccess) me = hipModuleGetFunction(&xlateFn_, xlateModule_, tmpl->kernelName.c_str());
+            hipError_t me = hipModuleLoadData(&c.module, image.elf.data());
+            if (me == hipSuccess) me = hipModuleGetFunction(&c.fn, c.module, tmpl->kernelName.c_str());
             if (me != hipSuccess) return hipFail(me, "loading the translated program");
-            xlateSteady_ = (uint64_t)image.steadyFastOff | ((uint64_t)image.steadyOff << 32);
-            xlateLast_ = (uint64_t)image.lastFastOff | ((uint64_t)image.lastOff << 32);
-            xlateCodeBytes_ = image.codeBytes;
-            xlateInitOff_ = image.initOff;
-            xlateLdsBytes_ = image.ldsBytes;
-            xlateWildRow_ = image.wildRow;
-            xlateUnsaturated_ = image.steady.unsaturated;
-            xlateInlined_ = image.steady.inlined;
-            xlateCalled_ = image.steady.called;
-            xlateValu_ = image.steady.valu;
-            xlateValuSlow_ = image.steady.valuSlow;
-            xlateValuClocks_ = image.steady.valuClocks;
-            xlateVgprConstants_ = image.vgprConstants;
-            ++xlateBuilds_;
-            xlateStages_ = image.stages;
-            xlateStageDesc_ = image.stageDesc;
-            xlateStageStoreRows_ = image.stageStoreRows;
-            useXlate_ = true;
+            c.steady = (uint64_t)image.steadyFastOff | ((uint64_t)image.steadyOff << 32);
+            c.last = (uint64_t)image.lastFastOff | ((uint64_t)image.lastOff << 32);
+            c.codeBytes = image.codeBytes;
+            c.initOff = image.initOff;
+            c.ldsBytes = image.ldsBytes;
+            c.wildRow = image.wildRow;
+            c.unsaturated = image.steady.unsaturated;
+            c.inlined = image.steady.inlined;
+            c.called = image.steady.called;
+            c.valu = image.steady.valu;
+            c.valuSlow = image.steady.valuSlow;
+            c.valuClocks = image.steady.valuClocks;
+            c.vgprConstants = image.vgprConstants;
+            if (offline) ++backgroundBuilds_; else ++xlateBuilds_;
+            c.stages = image.stages;
+            c.stageDesc = image.stageDesc;
+            c.stageStoreRows = image.stageStoreRows;
+            c.useXlate = true;
         }
     }
-    if (useAsm_ && !useXlate_ && low_.tramDane) {  // (translation failed: e.g. code larger than the hole) -> HIP C++ kernel
-        daneHipOnly_ = true;
-        return ensureLowered();
+    if (c.useAsm && !c.useXlate && c.low.tramDane) {  // (translation failed: e.g. code larger than the hole) -> HIP C++ kernel
+        if (offline) return fail(FX_E_NOTREADY, "offline build: the translation failed");
+        daneHipOnly_ = true;   // (part of the key: the next round of ensureLowered builds for the HIP C++ kernel)
+        return FX_E_RETRY_;
     }
-    if (useAsm_ && !useXlate_) {
+    if (offline && !c.useXlate) return fail(FX_E_NOTREADY, "offline build: the translation failed (" + c.xlateWhyNot + ")");
+    if (c.useAsm && !c.useXlate) {
         hipError_t pe = hipSuccess;
-        const uint64_t* handlers = asmHandlerTable(asmVariant_, device_, &pe);
+        const uint64_t* handlers = asmHandlerTable(c.variant, device_, &pe);
         if (!handlers) return hipFail(pe, "probe of the assembly interpreter");
-        const bool fold = asmVariant_ != ASM_LDS;
-        low_.steady = encodeAsmStream(low_.steady, handlers, fold);
-        low_.last = encodeAsmStream(low_.last, handlers, fold);
+        const bool fold = c.variant != ASM_LDS;
+        c.low.steady = encodeAsmStream(c.low.steady, handlers, fold);
+        c.low.last = encodeAsmStream(c.low.last, handlers, fold);
     }
-    const size_t nOps = low_.steady.size();
-    const bool staged = useXlate_ && xlateStages_ > 1;
-    const size_t words = nOps * 8 * 2 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size() + (staged ? (size_t)xlateStages_ * 8 : 0);
-    if (words > streamCap_) {
-        waitLastLaunch();
-        (void)hipFree(dStream_);
-        dStream_ = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dStream_), words * 4 + 256);
+    const size_t nOps = c.low.steady.size();
+    const bool staged = c.useXlate && c.stages > 1;
+    const size_t words = nOps * 8 * 2 + c.low.loadRows.size() + c.low.storeRows.size() + c.low.zeroRows.size() + (staged ? (size_t)c.stages * 8 : 0);
+    if (words > c.streamCap) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c.dStream), words * 4 + 256);
         if (e != hipSuccess) return hipFail(e, "hipMalloc stream");
-        streamCap_ = words;
+        c.streamCap = words;
     }
     std::vector<uint32_t> host(words);
-    std::memcpy(host.data(), low_.steady.data(), nOps * 32);
-    std::memcpy(host.data() + nOps * 8, low_.last.data(), nOps * 32);
+    std::memcpy(host.data(), c.low.steady.data(), nOps * 32);
+    std::memcpy(host.data() + nOps * 8, c.low.last.data(), nOps * 32);
     size_t p = nOps * 16;
-    for (const RowCopy& rcp : low_.loadRows) {
+    for (const RowCopy& rcp : c.low.loadRows) {
         // translated programs: bit 15 marks a row of the BOUNDED class (its state value is checked against 1.0)
-        const bool bounded = useXlate_ && rcp.ldsRow < xlateWildRow_.size() && !xlateWildRow_[rcp.ldsRow];
+        const bool bounded = c.useXlate && rcp.ldsRow < c.wildRow.size() && !c.wildRow[rcp.ldsRow];
         host[p++] = rcp.ldsRow | (bounded ? 0x8000u : 0u) | ((uint32_t)rcp.stateRow << 16);
     }
     if (staged) {
         // the store rows grouped by the stage that owns them; each stage's descriptor names its slice
-        for (int k = 0; k < xlateStages_; ++k) {
-            xlateStageDesc_[(size_t)k].storeFirst = (uint32_t)(p - (nOps * 16 + low_.loadRows.size()));
+        for (int k = 0; k < c.stages; ++k) {
+            c.stageDesc[(size_t)k].storeFirst = (uint32_t)(p - (nOps * 16 + c.low.loadRows.size()));
             uint32_t count = 0;
-            for (const RowCopy& rcp : low_.storeRows) {
-                const std::vector<int>& mine = xlateStageStoreRows_[(size_t)k];
+            for (const RowCopy& rcp : c.low.storeRows) {
+                const std::vector<int>& mine = c.stageStoreRows[(size_t)k];
                 if (std::find(mine.begin(), mine.end(), (int)rcp.ldsRow) == mine.end()) continue;
                 host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
                 ++count;
             }
-            xlateStageDesc_[(size_t)k].storeCount = count;
+            c.stageDesc[(size_t)k].storeCount = count;
         }
-        if (p != nOps * 16 + low_.loadRows.size() + low_.storeRows.size()) return fail(FX_E_PROGRAM, "internal: a store row without a stage");
+        if (p != nOps * 16 + c.low.loadRows.size() + c.low.storeRows.size()) return fail(FX_E_PROGRAM, "internal: a store row without a stage");
     } else {
-        for (const RowCopy& rcp : low_.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
+        for (const RowCopy& rcp : c.low.storeRows) host[p++] = rcp.ldsRow | ((uint32_t)rcp.stateRow << 16);
     }
-    for (int zr : low_.zeroRows) host[p++] = (uint32_t)zr;
+    for (int zr : c.low.zeroRows) host[p++] = (uint32_t)zr;
     if (staged) {
         static_assert(sizeof(StageDescriptor) == 32, "StageDescriptor layout");
-        std::memcpy(host.data() + p, xlateStageDesc_.data(), (size_t)xlateStages_ * 32);
-        p += (size_t)xlateStages_ * 8;
+        std::memcpy(host.data() + p, c.stageDesc.data(), (size_t)c.stages * 32);
+        p += (size_t)c.stages * 8;
     }
-    waitLastLaunch();  // the previous launch may still read the old stream
-    hipError_t e = hipMemcpy(dStream_, host.data(), words * 4, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(c.dStream, host.data(), words * 4, hipMemcpyHostToDevice);   // (a buffer of its own: no launch reads it yet)
     if (e != hipSuccess) return hipFail(e, "stream upload");
-    lowDirty_ = false;
+    c.key = in.key;
     return 0;
 }
 
@@ -470,21 +786,57 @@ bool Batch::movableControl(int r) const {
     return true;
 }
 
+// Every declared control (`control name = v`, the reference's control list, source/FX8010.cpp:408-411) that an instruction reads
+// as a plain operand gets its row - all of them at the first touch of any: a host that moves one slider moves others (a preset
+// recall writes the whole panel), and one change of code for the panel is one stall at most - none when the variant was built
+// ahead (prebuildControlVariant).  Registers no instruction reads never get a row: their value cannot reach the code.
+void Batch::markControls() {
+    for (const std::string& name : prog_.controls) {
+        const int r = prog_.findRegister(name);
+        if (r < 0 || forcedLane_[(size_t)r] || intrinsicLane(r) || !readByProgram(r) || !movableControl(r)) continue;
+        forcedLane_[(size_t)r] = 1;
+        lowDirty_ = true;
+    }
+}
+
+bool Batch::readByProgram(int reg) const { return reg >= 0 && (size_t)reg < readByProgram_.size() && readByProgram_[(size_t)reg] != 0; }
+
+bool Batch::declaredControl(int reg) const {
+    if (reg < 0) return false;
+    const std::string& name = prog_.regs[(size_t)reg].name;
+    return std::find(prog_.controls.begin(), prog_.controls.end(), name) != prog_.controls.end();
+}
+
 int Batch::setRegister(const std::string& key, float v) {
     (void)hipSetDevice(device_);
     const int r = prog_.findRegister(key);
     if (r < 0) return 1;
     hostValue_[r] = v;
-    if (tracked(r) || forcedLane_[r] || intrinsicLane(r)) {
-        // the register lives in a row (a schedule, an earlier per-instance or moving-control write, or the program writes it):
-        // the fill below is all there is to do
+    if (tracked(r) || intrinsicLane(r)) {
+        // the register lives in a row whatever the host does (a schedule, or the program writes it): the fill below is all there is to do
+    } else if (forcedLane_[r]) {
+        // a row from an earlier write.  One that only per-instance writes asked for is given back now that every instance holds
+        // the same value again (the register file does not grow with every register a host has ever touched) - unless it is a
+        // moving control, whose next change should stay a fill
+        if (laneWritten_[r] && !(controlMode_ && declaredControl(r)) ) {
+            forcedLane_[r] = 0;
+            lowDirty_ = true;
+        }
+    } else if (!readByProgram(r)) {
+        // no instruction reads it: the value lives in the state row (get_register) and nowhere in the code
     } else if (loaded_ && everLowered_ && movableControl(r)) {
-        forcedLane_[r] = 1;  // a moving control: a row from now on (one re-lowering, this one)
+        // a moving control: a row from now on - and with it the other declared controls (one change of code for the panel)
+        if (declaredControl(r)) {
+            controlMode_ = true;
+            markControls();
+        }
+        forcedLane_[r] = 1;
         lowDirty_ = true;
     } else {
         lowDirty_ = true;    // immediates (and possibly the classification) change
         if (loaded_ && everLowered_) controlHeat_ = kHeatPerChange;
     }
+    laneWritten_[r] = 0;
     if (dState_) {
         // Invariant: the state row of EVERY register holds its current value for every instance, also while the
         // register is uniform (folded into the code) - so that a later per-instance write only has to force the
@@ -503,10 +855,11 @@ int Batch::setRegisterAt(const std::string& key, int64_t inst, float v) {
     if (inst < 0 || inst >= n_) return fail(FX_E_ARG, "instance out of range");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
     waitLastLaunch();
-    if (!forcedLane_[r] && !intrinsicLane(r)) {  // (the row is valid, see setRegister; the next lowering keeps the register per-lane)
+    if (!forcedLane_[r] && !intrinsicLane(r) && readByProgram(r)) {  // (the row is valid, see setRegister; the next lowering keeps the register per-lane)
         forcedLane_[r] = 1;
         lowDirty_ = true;
     }
+    laneWritten_[r] = 1;
     hipError_t e = hipMemcpy(dState_ + (size_t)r * nPad_ + inst, &v, 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipFail(e, "setRegisterAt");
     return 0;
@@ -519,10 +872,11 @@ int Batch::setRegisterArray(const std::string& key, const float* values) {
     if (!values) return fail(FX_E_ARG, "null buffer");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
     waitLastLaunch();
-    if (!forcedLane_[r] && !intrinsicLane(r)) {  // from now on a per-instance row (every lane is overwritten below)
+    if (!forcedLane_[r] && !intrinsicLane(r) && readByProgram(r)) {  // from now on a per-instance row (every lane is overwritten below)
         forcedLane_[r] = 1;
         lowDirty_ = true;
     }
+    laneWritten_[r] = 1;
     hipError_t e = hipMemcpy(dState_ + (size_t)r * nPad_, values, sizeof(float) * (size_t)n_, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipFail(e, "setRegisterArray");
     return 0;
@@ -641,11 +995,13 @@ int Batch::uploadTracks(int nSamples, hipStream_t s) {
             for (int q = 0; q < used[k]; ++q) std::memcpy(&trackStage_[at + (size_t)q * (size_t)nPad_], &t.values[(size_t)q * (size_t)n_], (size_t)n_ * 4);
             at += (size_t)used[k] * (size_t)nPad_;
             forcedLane_[(size_t)reg] = 1;
+            laneWritten_[(size_t)reg] = 1;
         } else {
             std::memcpy(&trackStage_[at], t.values.data(), (size_t)used[k] * 4);
             at += (size_t)used[k];
             hostValue_[(size_t)reg] = t.values[(size_t)used[k] - 1];  // what every instance holds after the block
             forcedLane_[(size_t)reg] = 0;
+            laneWritten_[(size_t)reg] = 0;
         }
     }
     for (size_t i = 0; i < due.size(); ++i) {
@@ -694,31 +1050,64 @@ int Batch::processWithTrackFallback(const float* dIn, float* dOut, int nSamples,
     return 0;
 }
 
+// Staged code is generated for a class of block lengths (a pipeline fills and drains in 3 (K - 1) steps: short blocks want
+// short steps and fewer stages).  The class wanted follows the caller: at once when code for the new class exists already (a
+// pointer swap in ensureLowered), after four blocks in a row otherwise - a stray block of another length is not worth a
+// translation.  Programs that cannot be cut have one code for every length.
+void Batch::noteBlockLength(int nSamples) {
+    if (nSamples <= 0) return;
+    const int cls = stageBlockClass(nSamples);
+    if (wantedClass_ < 0 || c_.key.empty()) {   // the first block after a load (or after a failed build): lowDirty_ is set anyway
+        wantedClass_ = cls;
+        otherClassBlocks_ = 0;
+        return;
+    }
+    if (cls == wantedClass_) { otherClassBlocks_ = 0; return; }
+    if (!c_.classMatters) return;   // one code for every block length
+    ++otherClassBlocks_;
+    const int was = wantedClass_;
+    wantedClass_ = cls;
+    collectBuilt();
+    const int blockClass = keyClass();
+    const bool defer = deferWanted();
+    const std::string key = codeKey(blockClass, defer);
+    if (cachedCode(key)) {
+        otherClassBlocks_ = 0;
+        lowDirty_ = true;
+        return;
+    }
+    // not there: the builder thread makes it while the code in force (right for every length, only slower) keeps running; a
+    // caller without that thread, or whose build cannot be done offline, gets it on its own thread once it has stayed
+    if (!lowDirty_) requestBuild(buildInputs(key, blockClass, defer));
+    if (otherClassBlocks_ >= 4 && !buildPending(key)) {
+        otherClassBlocks_ = 0;
+        lowDirty_ = true;
+        return;
+    }
+    wantedClass_ = was;
+}
+
 int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
     (void)hipSetDevice(device_);
     if (nSamples < 0) return fail(FX_E_ARG, "n_samples < 0");
     if (!piecewise_) {   // (a piece of a pipelined host block: done once for the whole block)
         pendingSamples_ = nSamples;
-        if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;  // quiet again: translate
-        // a staged program is generated for a class of block lengths: when the caller has moved to another one for good, again
-        if (useXlate_ && xlateStages_ > 1 && !lowDirty_ && nSamples > 0) {
-            otherClassBlocks_ = stageBlockClass(nSamples) == stagedForClass_ ? 0 : otherClassBlocks_ + 1;
-            if (otherClassBlocks_ >= 4) lowDirty_ = true;
-        }
+        if (controlHeat_ > 0 && --controlHeat_ == 0 && c_.deferred) lowDirty_ = true;  // quiet again: translate
+        noteBlockLength(nSamples);
     }
     int rc = ensureLowered();
     if (rc != 0) return rc;
     everLowered_ = true;
     if (nSamples == 0) return 0;
     if (!dIn || !dOut) return fail(FX_E_ARG, "null buffer");
-    if (tracksArmed() && !useXlate_) return processWithTrackFallback(dIn, dOut, nSamples, stream);
+    if (tracksArmed() && !c_.useXlate) return processWithTrackFallback(dIn, dOut, nSamples, stream);
     hipStream_t s = pick(stream);
-    if (useXlate_ && !trackRegs_.empty() && (rc = uploadTracks(nSamples, s)) != 0) return rc;
+    if (c_.useXlate && !trackRegs_.empty() && (rc = uploadTracks(nSamples, s)) != 0) return rc;
     KernelArgs a{};
-    const size_t nOps = low_.steady.size();
-    a.steady = dStream_;
-    a.last = dStream_ + nOps * 8;
-    a.rowTable = dStream_ + nOps * 16;
+    const size_t nOps = c_.low.steady.size();
+    a.steady = c_.dStream;
+    a.last = c_.dStream + nOps * 8;
+    a.rowTable = c_.dStream + nOps * 16;
     a.state = dState_;
     a.in = dIn;
     a.out = dOut;
@@ -728,65 +1117,65 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     a.n = n_;
     a.nPad = nPad_;
     a.nOps = (int)nOps;
-    a.nLoad = (int)low_.loadRows.size();
-    a.nStore = (int)low_.storeRows.size();
+    a.nLoad = (int)c_.low.loadRows.size();
+    a.nStore = (int)c_.low.storeRows.size();
     a.nSamples = nSamples;
     a.channels = prog_.numChannels;
     for (int c = 0; c < kMaxChannels; ++c) {
-        a.inRow[c] = c < prog_.numChannels ? low_.inRow[c] : -1;
-        a.latchRow[c] = c < prog_.numChannels ? low_.latchRow[c] : 0;
+        a.inRow[c] = c < prog_.numChannels ? c_.low.inRow[c] : -1;
+        a.latchRow[c] = c < prog_.numChannels ? c_.low.latchRow[c] : 0;
     }
     a.iSlots = iSlotsAlloc_;
     a.xSlots = xSlotsAlloc_;
     a.iSize = prog_.iTramSize;
     a.xSize = prog_.xTramSize;
-    a.nZero = (int)low_.zeroRows.size();
+    a.nZero = (int)c_.low.zeroRows.size();
     const uint32_t rowBytes = 256u * (uint32_t)instPerLane_;
-    a.skipOff = low_.skipRow >= 0 ? (uint32_t)low_.skipRow * rowBytes : 0;
-    a.cursorOff = low_.cursorRow >= 0 ? (uint32_t)low_.cursorRow * rowBytes : 0;
-    a.noiseOff = low_.noiseRow >= 0 ? (uint32_t)low_.noiseRow * rowBytes : 0;
-    a.oodOff = low_.oodRow >= 0 ? (uint32_t)low_.oodRow * rowBytes : 0;
-    a.aliveOff = low_.aliveRow >= 0 ? (uint32_t)low_.aliveRow * rowBytes : 0;
-    a.hasShadow = low_.skipRow >= 0 ? 1 : 0;
+    a.skipOff = c_.low.skipRow >= 0 ? (uint32_t)c_.low.skipRow * rowBytes : 0;
+    a.cursorOff = c_.low.cursorRow >= 0 ? (uint32_t)c_.low.cursorRow * rowBytes : 0;
+    a.noiseOff = c_.low.noiseRow >= 0 ? (uint32_t)c_.low.noiseRow * rowBytes : 0;
+    a.oodOff = c_.low.oodRow >= 0 ? (uint32_t)c_.low.oodRow * rowBytes : 0;
+    a.aliveOff = c_.low.aliveRow >= 0 ? (uint32_t)c_.low.aliveRow * rowBytes : 0;
+    a.hasShadow = c_.low.skipRow >= 0 ? 1 : 0;
     a.instPerLane = instPerLane_;
-    a.tramDane = (low_.tramDane && low_.cursorRow >= 0) ? 1 : 0;
+    a.tramDane = (c_.low.tramDane && c_.low.cursorRow >= 0) ? 1 : 0;
     a.oodRow = stateLayout_.oodRow;
     a.countLo = stateLayout_.countLo;
     a.countHi = stateLayout_.countHi;
-    a.staticCount = low_.staticCount;
-    a.nRows = low_.nRows;
+    a.staticCount = c_.low.staticCount;
+    a.nRows = c_.low.nRows;
     hipError_t e = untimed_ ? hipSuccess : hipEventRecord(ev0_, s);
     if (e == hipSuccess) {
-        if (useAsm_) {
+        if (c_.useAsm) {
             AsmArgs g{};
             g.steady = a.steady; g.last = a.last; g.rowTable = a.rowTable; g.state = a.state;
             g.in = a.in; g.out = a.out; g.itram = a.itram; g.xtram = a.xtram; g.lut = a.lut;
             g.n = a.n; g.nPad = a.nPad; g.nLoad = a.nLoad; g.nStore = a.nStore;
             g.nSamples = a.nSamples; g.channels = a.channels;
             for (int c = 0; c < kMaxChannels; ++c) {
-                g.inOff[c] = a.inRow[c] >= 0 ? a.inRow[c] * (int)low_.rowPitch : -1;
-                g.latchOff[c] = a.latchRow[c] * (int)low_.rowPitch;
+                g.inOff[c] = a.inRow[c] >= 0 ? a.inRow[c] * (int)c_.low.rowPitch : -1;
+                g.latchOff[c] = a.latchRow[c] * (int)c_.low.rowPitch;
             }
             g.iSlots = a.iSlots; g.xSlots = a.xSlots; g.iSize = a.iSize; g.xSize = a.xSize;
             g.cursorRow = stateLayout_.cursorBase; g.noiseRow = stateLayout_.noiseBase;
             g.oodRow = a.oodRow; g.countLo = a.countLo; g.countHi = a.countHi; g.staticCount = a.staticCount;
             g.lutX1Off = kLutX1Off * 8;
-            if (useXlate_) {
+            if (c_.useXlate) {
                 // code streams are named by their byte offset from the kernel entry: {fast, exact} per argument
-                g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)xlateSteady_);
-                g.last = reinterpret_cast<const uint32_t*>((uintptr_t)xlateLast_);
-                g.initOff = (int)xlateInitOff_;
+                g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)c_.steady);
+                g.last = reinterpret_cast<const uint32_t*>((uintptr_t)c_.last);
+                g.initOff = (int)c_.initOff;
                 g.tracks = trackRegs_.empty() ? nullptr : dTracks_;
-                if (xlateStages_ > 1) {
-                    g.stages = dStream_ + nOps * 16 + low_.loadRows.size() + low_.storeRows.size() + low_.zeroRows.size();
-                    g.nStages = xlateStages_;
+                if (c_.stages > 1) {
+                    g.stages = c_.dStream + nOps * 16 + c_.low.loadRows.size() + c_.low.storeRows.size() + c_.low.zeroRows.size();
+                    g.nStages = c_.stages;
                 }
-                e = launchAsmFunction(xlateFn_, g, (unsigned)((n_ + 63) / 64), xlateLdsBytes_, s, (unsigned)xlateStages_);
+                e = launchAsmFunction(c_.fn, g, (unsigned)((n_ + 63) / 64), c_.ldsBytes, s, (unsigned)c_.stages);
             } else {
-                e = launchAsmInterp(g, asmVariant_, asmVariant_ == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
+                e = launchAsmInterp(g, c_.variant, c_.variant == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
             }
         } else {
-            e = launchStepBlock(a, low_.multipass, s);
+            e = launchStepBlock(a, c_.low.multipass, s);
         }
     }
     if (e == hipSuccess && !untimed_) e = hipEventRecord(ev1_, s);
@@ -916,8 +1305,9 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
     waitLastLaunch();
     // the block is ONE call to the bookkeeping of control changes and to the lowering (with its real length), not kHostPieces:
     // a translation must not fire between two pieces
-    pendingSamples_ = nSamples;
-    if (controlHeat_ > 0 && --controlHeat_ == 0 && xlateDeferred_) lowDirty_ = true;
+    pendingSamples_ = nSamples / kHostPieces;   // what the kernel is launched with: the class of block lengths is the piece's
+    if (controlHeat_ > 0 && --controlHeat_ == 0 && c_.deferred) lowDirty_ = true;
+    noteBlockLength(pendingSamples_);
     int rc = ensureLowered();
     if (rc != 0) return rc;
     piecewise_ = true;
@@ -999,31 +1389,34 @@ int64_t Batch::info(int what) {
     if (what == FXB_INFO_NUM_INSTRUCTIONS) return (int64_t)prog_.instrs.size();
     if (what == FXB_INFO_NUM_REGISTERS) return (int64_t)prog_.regs.size();
     if (what == FXB_INFO_GRID) return lastGrid_;
-    if (what == FXB_INFO_WAVES_PER_WG) return (useAsm_ && useXlate_) ? xlateStages_ : 1;
+    if (what == FXB_INFO_WAVES_PER_WG) return (c_.useAsm && c_.useXlate) ? c_.stages : 1;
     if (ensureLowered() != 0) return -1;
     switch (what) {
         case FXB_INFO_INST_PER_LANE: return instPerLane_;
-        case FXB_INFO_KERNEL: return useAsm_ ? (useXlate_ ? 8 + (int)asmVariant_ : 1 + (int)asmVariant_) : 0;
-        case FXB_INFO_XLATE_CODE_BYTES: return useXlate_ ? (int64_t)xlateCodeBytes_ : 0;
-        case FXB_INFO_XLATE_INLINED: return useXlate_ ? xlateInlined_ : 0;
-        case FXB_INFO_XLATE_CALLED: return useXlate_ ? xlateCalled_ : 0;
+        case FXB_INFO_KERNEL: return c_.useAsm ? (c_.useXlate ? 8 + (int)c_.variant : 1 + (int)c_.variant) : 0;
+        case FXB_INFO_XLATE_CODE_BYTES: return c_.useXlate ? (int64_t)c_.codeBytes : 0;
+        case FXB_INFO_XLATE_INLINED: return c_.useXlate ? c_.inlined : 0;
+        case FXB_INFO_XLATE_CALLED: return c_.useXlate ? c_.called : 0;
         case FXB_INFO_XLATE_BUILDS: return xlateBuilds_;
-        case FXB_INFO_XLATE_UNSATURATED: return useXlate_ ? xlateUnsaturated_ : 0;
-        case FXB_INFO_XLATE_VALU: return useXlate_ ? xlateValu_ : 0;
-        case FXB_INFO_XLATE_VALU_SLOW: return useXlate_ ? xlateValuSlow_ : 0;
-        case FXB_INFO_XLATE_VALU_CLOCKS: return useXlate_ ? xlateValuClocks_ : 0;
-        case FXB_INFO_XLATE_VGPR_CONSTANTS: return useXlate_ ? xlateVgprConstants_ : 0;
-        case FXB_INFO_NUM_LANE_REGS: return low_.nLaneRegs;
-        case FXB_INFO_NUM_UNIFORM_REGS: return low_.nUniformRegs;
-        case FXB_INFO_LDS_BYTES_PER_WG: return (useAsm_ && asmVariant_ != ASM_LDS) ? (useXlate_ ? (int64_t)xlateLdsBytes_ : 0) : (int64_t)low_.nRows * 256 * instPerLane_;
-        case FXB_INFO_NUM_ROWS: return low_.nRows;
-        case FXB_INFO_NUM_MICROOPS: return (int64_t)low_.steady.size();
+        case FXB_INFO_XLATE_BACKGROUND_BUILDS: return backgroundBuilds_;
+        case FXB_INFO_CODE_CACHE_HITS: return cacheHits_;
+        case FXB_INFO_CODE_CACHED: return (int64_t)cache_.size() + (c_.key.empty() ? 0 : 1);
+        case FXB_INFO_XLATE_UNSATURATED: return c_.useXlate ? c_.unsaturated : 0;
+        case FXB_INFO_XLATE_VALU: return c_.useXlate ? c_.valu : 0;
+        case FXB_INFO_XLATE_VALU_SLOW: return c_.useXlate ? c_.valuSlow : 0;
+        case FXB_INFO_XLATE_VALU_CLOCKS: return c_.useXlate ? c_.valuClocks : 0;
+        case FXB_INFO_XLATE_VGPR_CONSTANTS: return c_.useXlate ? c_.vgprConstants : 0;
+        case FXB_INFO_NUM_LANE_REGS: return c_.low.nLaneRegs;
+        case FXB_INFO_NUM_UNIFORM_REGS: return c_.low.nUniformRegs;
+        case FXB_INFO_LDS_BYTES_PER_WG: return (c_.useAsm && c_.variant != ASM_LDS) ? (c_.useXlate ? (int64_t)c_.ldsBytes : 0) : (int64_t)c_.low.nRows * 256 * instPerLane_;
+        case FXB_INFO_NUM_ROWS: return c_.low.nRows;
+        case FXB_INFO_NUM_MICROOPS: return (int64_t)c_.low.steady.size();
         case FXB_INFO_ITRAM_SLOTS: return iSlotsAlloc_;
         case FXB_INFO_XTRAM_SLOTS: return xSlotsAlloc_;
-        case FXB_INFO_TRAM_OPS: return low_.tramOpsPerSample;
-        case FXB_INFO_MULTIPASS: return low_.multipass ? 1 : 0;
-        case FXB_INFO_NUM_SHADOWED: return low_.nShadowed;
-        case FXB_INFO_NUM_CCR_LIVE: return low_.nCcrLive;
+        case FXB_INFO_TRAM_OPS: return c_.low.tramOpsPerSample;
+        case FXB_INFO_MULTIPASS: return c_.low.multipass ? 1 : 0;
+        case FXB_INFO_NUM_SHADOWED: return c_.low.nShadowed;
+        case FXB_INFO_NUM_CCR_LIVE: return c_.low.nCcrLive;
         default: return -1;
     }
 }

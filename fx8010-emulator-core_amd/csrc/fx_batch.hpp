@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -59,12 +60,7 @@ public:
     void setChannels(int c) { prog_.loaderChannels = c; }
     void noteError(const std::string& what) { lastError_ = what; }
     // behaviour beyond the reference (fx_model.hpp kOpt*): takes effect for programs loaded afterwards
-    int setOption(unsigned option, bool on) {
-        if (option & ~kOptAll) return -3;
-        prog_.options = on ? (prog_.options | option) : (prog_.options & ~option);
-        lowDirty_ = true;
-        return 0;
-    }
+    int setOption(unsigned option, bool on);
 
 private:
     int fail(int code, const std::string& what);
@@ -72,7 +68,7 @@ private:
     int afterLoad(bool ok);
     int ensureLowered();          // (re)lower + upload the stream when dirty
     int ensureState();            // allocate / grow the state block for the current register count
-    int ensureTram();
+    int ensureTram(const Lowered& low);
     int uploadTracks(int nSamples, hipStream_t s);   // translated tier: header + values -> dTracks_
     int processWithTrackFallback(const float* dIn, float* dOut, int nSamples, hipStream_t stream);  // other tiers: cut the block
     bool tracked(int reg) const;
@@ -86,9 +82,9 @@ private:
 
     Program prog_;
     std::vector<float> hostValue_;      // current value of every register as the host knows it
-    std::vector<uint8_t> forcedLane_;   // registers given per-instance values by setRegisterAt
-    std::vector<uint8_t> intrinsicLane_; // registers per-instance because the program writes them (as of the last lowering)
-    Lowered low_;
+    std::vector<uint8_t> forcedLane_;   // registers that live in a row of the register file although no instruction writes them:
+                                        // per-instance values (setRegisterAt / setRegisterArray / a per-instance schedule) or a moving control
+    std::vector<uint8_t> laneWritten_;  // ... of those, the ones whose instances may really hold different values (a broadcast write clears it)
     bool lowDirty_ = true;
     bool loaded_ = false;
 
@@ -106,39 +102,98 @@ private:
     float* dXTram_ = nullptr;
     int iSlotsAlloc_ = 0, xSlotsAlloc_ = 0;
     int instPerLane_ = 1;
-    bool useAsm_ = false;          // the current lowering runs on the hand-written gfx950 kernel
-    AsmVariant asmVariant_ = ASM_LDS;
-    std::string asmWhyNot_;
-    // translated program (fx_xlate.hpp): a code object of its own per lowering
-    bool useXlate_ = false;
-    hipModule_t xlateModule_ = nullptr;
-    hipFunction_t xlateFn_ = nullptr;
-    uint64_t xlateSteady_ = 0, xlateLast_ = 0;  // {fast, exact} stream offsets as the kernel takes them
-    uint32_t xlateCodeBytes_ = 0, xlateInitOff_ = 0, xlateLdsBytes_ = 0;
+
+    // Everything a lowering produces - the lowered streams, the tier that runs them, the loaded code object of a translated
+    // program and the device copy of its tables.  It is a pure function of a KEY (codeKey(): the program, the values folded
+    // into the code, which registers have rows, the number of stages and the block-length class), so finished ones are
+    // kept: a caller that comes back to a shape it has used before - a block length, a set of moving controls - gets a
+    // pointer swap, not a translation and a module load.
+    struct Code {
+        std::string key;               // empty: nothing built
+        Lowered low;
+        bool useAsm = false;           // runs on the hand-written gfx950 kernel
+        AsmVariant variant = ASM_LDS;
+        std::string asmWhyNot;
+        // translated program (fx_xlate.hpp): a code object of its own
+        bool useXlate = false;
+        hipModule_t module = nullptr;
+        hipFunction_t fn = nullptr;
+        uint64_t steady = 0, last = 0;  // {fast, exact} stream offsets as the kernel takes them
+        uint32_t codeBytes = 0, initOff = 0, ldsBytes = 0;
+        int stages = 1;                 // wavefronts per workgroup of the translated program (fx_xlate.hpp StageInfo)
+        int blockClass = -1;            // the class of block lengths the staged code was generated for
+        bool classMatters = false;      // the program can be cut: code for another class of block lengths would differ
+        std::vector<StageDescriptor> stageDesc;
+        std::vector<std::vector<int>> stageStoreRows;
+        std::string stagesWhyNot;
+        int inlined = 0, called = 0, unsaturated = 0, valu = 0, valuSlow = 0, valuClocks = 0, vgprConstants = 0;
+        std::vector<uint8_t> wildRow;
+        std::string xlateWhyNot;
+        bool deferred = false;          // the interpreter runs this one because controls were moving when it was built
+        uint32_t* dStream = nullptr;    // records / row table / stage descriptors on the device
+        size_t streamCap = 0;
+        uint64_t lastUse = 0;
+    };
+    Code c_;                                     // the code in force
+    std::vector<std::unique_ptr<Code>> cache_;   // finished ones that are not (at most kCodeCache)
+    static constexpr size_t kCodeCache = 8;
+    uint64_t useClock_ = 0;
+    int loadGen_ = 0;
+    int cacheHits_ = 0;
+    std::string codeKey(int blockClass, bool defer) const;
+    std::string codeKeyFor(const std::vector<uint8_t>& forced, int blockClass, bool defer) const;
+    struct Builder;                              // the thread that generates code off the caller's thread (fx_batch.cpp)
+    std::unique_ptr<Builder> builder_;
+    struct BuildInputs;
+    bool builderWanted() const;
+    void requestBuild(BuildInputs&& in);
+    void collectBuilt();                         // what the builder has finished -> cache_
+    bool buildPending(const std::string& key);
+    bool waitBuild(const std::string& key);
+    void drainBuilder(bool stop);
+    void prebuildControlVariant();
+    int keyClass() const;
+    void noteBlockLength(int nSamples);
+    bool deferWanted() const;
+    bool cachedCode(const std::string& key) const;
+    void stashCode();                            // c_ -> cache_ (evicting the least recently used), c_ = empty
+    bool adoptCode(const std::string& key);      // cache_ -> c_
+    void releaseCode(Code& c);                   // unload / free what a Code holds on the device
+    void clearCodeCache();
+    struct BuildInputs {                         // what a build reads of the batch's changing state (a snapshot: builds also run on the builder thread)
+        std::string key;
+        int blockClass = -1;
+        bool defer = false;
+        std::vector<float> hostValue;
+        std::vector<uint8_t> forced;             // laneForced()
+        std::vector<int> trackRegs;
+    };
+    BuildInputs buildInputs(const std::string& key, int blockClass, bool defer) const;
+    static constexpr int FX_E_RETRY_ = -1000;    // internal: build again (the key has changed)
+    int buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::string* err);
+    int wantedClass_ = -1;                       // block-length class the code should be for (sticky: see processDevice)
+    bool readByProgram(int reg) const;
+    bool declaredControl(int reg) const;
+    void markControls();
+    std::vector<uint8_t> intrinsicLane_, readByProgram_;   // per register, as of the last load
+    bool controlMode_ = false;                   // the declared controls have rows (the host has moved one)
+
     int stagesWanted(int variant) const;
     bool movableControl(int reg) const;
     bool piecewise_ = false;   // processDevice is being called for the pieces of one pipelined host block
-    int xlateBuilds_ = 0;      // translations since the handle was created
-    int xlateStages_ = 1;                        // wavefronts per workgroup of the translated program (fx_xlate.hpp StageInfo)
+    int xlateBuilds_ = 0;                    // translations on the caller's thread since the handle was created
+    std::atomic<int> backgroundBuilds_{0};   // ... and on the builder thread
     // a pipeline fills and drains in 3 (K - 1) steps: short blocks get short steps and fewer stages (stageBlockClass); the code is
     // generated for the class of the block that triggered the translation and again when the blocks stay in another class
-    int stagedForClass_ = -1, otherClassBlocks_ = 0;
+    int otherClassBlocks_ = 0;
     static int stageBlockClass(int nSamples) { return nSamples <= 48 ? 0 : (nSamples <= 256 ? 1 : 2); }
-    std::vector<StageDescriptor> xlateStageDesc_;
-    std::vector<std::vector<int>> xlateStageStoreRows_;
-    std::string stagesWhyNot_;
-    int xlateInlined_ = 0, xlateCalled_ = 0, xlateUnsaturated_ = 0, xlateValu_ = 0, xlateValuSlow_ = 0, xlateValuClocks_ = 0, xlateVgprConstants_ = 0;
-    std::vector<uint8_t> xlateWildRow_;
-    std::string xlateWhyNot_;
     // control changes re-lower; while they keep coming the interpreter tier is used (see ensureLowered)
     static constexpr int kHeatPerChange = 8;  // blocks a change keeps the translation deferred
     int controlHeat_ = 0;
     int pendingSamples_ = 0;  // block length of the call that triggered the lowering
-    bool xlateDeferred_ = false, everLowered_ = false;
+    bool everLowered_ = false;
     bool daneHipOnly_ = false;  // a DANE-model program that the translator could not take: HIP C++ kernel from now on
     double* dLut_ = nullptr;
-    uint32_t* dStream_ = nullptr;
-    size_t streamCap_ = 0;
     // control tracks (fx_xlate.hpp TrackEvent): registers the generated loop can re-load by itself, and what is armed
     struct PendingTrack { int period = 0, steps = 0; bool perInstance = false; std::vector<float> values; };
     std::vector<int> trackRegs_;           // register of slot t

@@ -223,7 +223,13 @@ enum {
     FXB_INFO_XLATE_VALU_SLOW = 23,  /* ... those of the ~4-clock issue class (conversions, min/max/med3, compares, fp64, SGPR sources) */
     FXB_INFO_XLATE_VALU_CLOCKS = 24,/* ... modelled SIMD issue clocks of all of them per wavefront and sample period */
     FXB_INFO_XLATE_VGPR_CONSTANTS = 25, /* uniform constants the translated code keeps in spare VGPRs */
-    FXB_INFO_XLATE_BUILDS = 26     /* translations (code generation + module load) since the handle was created */
+    FXB_INFO_XLATE_BUILDS = 26,    /* translations (code generation + module load) on the CALLER's thread since the handle was created: each one
+                                      held a process call up for a few milliseconds */
+    FXB_INFO_CODE_CACHE_HITS = 27, /* changes of code that were a pointer swap: the shape (block-length class, set of registers with rows, compiled-in
+                                      values) had been generated before - by an earlier call or ahead of time by the builder thread */
+    FXB_INFO_CODE_CACHED = 28,     /* generated code objects the handle holds (the one in force included) */
+    FXB_INFO_XLATE_BACKGROUND_BUILDS = 29 /* translations on the handle's builder thread (ahead of time: the variant with the declared controls in
+                                      rows, code for another class of block lengths); FX_BUILDER=0 in the environment turns the thread off */
 };
 int64_t fxb_info(fxb_handle* h, int what);
 

@@ -552,21 +552,26 @@ def test_set_register_broadcast_and_per_instance(gpu, k):
     assert b.get_register_i("nonexistent", 0) == 1.0
 
 
-def test_moving_controls_become_rows_once(gpu, monkeypatch):
+@pytest.mark.parametrize("builder", [True, False], ids=["builder_thread", "callers_thread_only"])
+def test_moving_controls_become_rows_once(gpu, monkeypatch, builder):
     """The reference's setRegisterValue is a store (source/FX8010.cpp:236-253), called every 8 samples by its harness
     (source/main.cpp:107-114).  Here a control starts out compiled into the generated code; the first change after the program
-    has run gives it a row of the register file (ONE re-translation), every later change is a fill of that row: the translated
-    tier runs every block of a slider sweep.  Results are the reference's throughout."""
+    has run gives the declared controls - all of them: a host that moves one moves others - rows of the register file, and
+    every later change of any of them is a fill of its row: the translated tier runs every block of a slider sweep.  The
+    variant with the rows is generated ahead of time on the handle's builder thread, so the first touch is a pointer swap;
+    without that thread (FX_BUILDER=0) it is ONE re-translation on the caller's.  Results are the reference's throughout."""
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
-    text = HDR + "control mix = 0.25\nmacs a, a, vol, in\ninterp b, b, vol, a\nmacs out, b, a, mix\nend"
+    if not builder:
+        monkeypatch.setenv("FX_BUILDER", "0")
+    text = HDR + "control mix = 0.25\ncontrol unused = 0.5\nmacs a, a, vol, in\ninterp b, b, vol, a\nmacs out, b, a, mix\nend"
     N = 70
     b = gpu.Batch(N, 1, 0)
     assert b.load_text(text), b.errors()
     o = Oracle(1)
     assert o.load_text(text)
     x = progs.stimulus(N, 8 * 40)
-    tiers, builds = [], []
+    tiers, builds, rows = [], [], []
     for blk in range(40):
         if 3 <= blk < 30:
             v = float(np.float32(0.1 + 0.03 * blk))
@@ -575,6 +580,7 @@ def test_moving_controls_become_rows_once(gpu, monkeypatch):
         if blk in (10, 11, 25):
             b.set_register("mix", 0.5 - 0.01 * blk)
             o.set_register("mix", 0.5 - 0.01 * blk)
+            b.set_register("unused", 0.01 * blk)   # a control no instruction reads: its value lives in the state row only
         if blk == 20:   # non-finite values through a moving control: the row is checked like any state row
             b.set_register("vol", float("inf"))
             o.set_register("vol", float("inf"))
@@ -584,12 +590,57 @@ def test_moving_controls_become_rows_once(gpu, monkeypatch):
         assert np.array_equal(bits(ref), bits(y[:, 5])), "block %d" % blk
         tiers.append(b.info("kernel"))
         builds.append(b.info("xlate_builds"))
+        rows.append(b.info("num_rows"))
     assert all(t >= 9 for t in tiers), tiers                 # the translated tier on every block
-    assert builds[2] == 1 and builds[3] == 2 and builds[9] == 2   # the first change of vol: one more translation, then none
-    assert builds[10] == 3 and builds[-1] == 3                    # ... likewise for mix
+    if builder:
+        assert builds[-1] == 1 and b.info("xlate_background_builds") == 1 and b.info("code_cache_hits") == 1, builds
+    else:
+        assert builds[2] == 1 and builds[3] == 2 and builds[-1] == 2, builds   # the first change of vol: one more translation (mix joins it), then none
+    assert rows[3] == rows[2] + 2 and rows[-1] == rows[3], rows   # vol and mix; `unused` never gets a row
+    assert b.get_register_i("unused", 7) == np.float32(0.25)
     assert b.instruction_counter_i(5) == o.instruction_counter()
     for n in (0, 63, 69):
         assert b.get_register_bits_i("vol", n) == o.get_register_bits("vol") and b.get_register_bits_i("b", n) is not None
+
+
+def test_rows_do_not_pile_up(gpu, monkeypatch):
+    """a per-instance write gives a register a row; a broadcast write after it gives the row back (every instance holds the same
+    value again) - coming back to code that was generated before is a swap; registers no instruction reads take per-instance
+    values without ever getting a row"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    text = HDR + "static g = 0.5\nstatic memo = 0.125\nmacs a, a, g, in\nmacs out, a, vol, 0.5\nend"
+    N = 70
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    oracles = [Oracle(1) for _ in range(N)]
+    for o in oracles:
+        assert o.load_text(text)
+    x = progs.stimulus(N, 8 * 12)
+    rows = []
+    for blk in range(12):
+        if blk == 2:
+            vals = np.linspace(0.1, 0.9, N).astype(np.float32)
+            b.set_register_array("g", vals)
+            b.set_register_array("memo", vals)
+            for n, o in enumerate(oracles):
+                o.set_register("g", float(vals[n]))
+                o.set_register("memo", float(vals[n]))
+        if blk == 5:
+            b.set_register("g", 0.5)
+            for o in oracles:
+                o.set_register("g", 0.5)
+        if blk == 8:
+            b.set_register_i("g", 3, 0.75)
+            oracles[3].set_register("g", 0.75)
+        xs = x[8 * blk:8 * blk + 8]
+        y = b.process_block(xs)
+        for n in (0, 3, 64, 69):
+            assert np.array_equal(bits(oracles[n].process_block(xs[:, n].copy())), bits(y[:, n])), (blk, n)
+        rows.append(b.info("num_rows"))
+    assert rows[2] == rows[1] + 1 and rows[5] == rows[1] and rows[8] == rows[2], rows
+    assert b.info("code_cache_hits") >= 2   # back to the code of blocks 0-1 at block 5, to that of blocks 2-4 at block 8
+    assert b.get_register_bits_i("memo", 69) == oracles[69].get_register_bits("memo") and b.get_register_bits_i("memo", 0) == oracles[0].get_register_bits("memo")
 
 
 def test_controls_that_shape_the_code_are_compiled_in(gpu, monkeypatch):

@@ -170,11 +170,13 @@ def test_default_policy_across_batch_sizes(gpu, stages, program, N):
     print("policy: %s N=%d -> %d stage(s), LDS %d B per workgroup" % (program, N, b.info("waves_per_wg"), b.info("lds_bytes_per_wg")))
 
 
-def test_code_follows_the_block_length(gpu, stages):
+def test_code_follows_the_block_length(gpu, stages, monkeypatch):
     """staged code is generated for a class of block lengths (long steps for long blocks, a barrier per sample and at most four
     stages for blocks of a few dozen samples); a caller that changes its block length for good gets new code after a few
-    blocks - with the state carried over, bit for bit"""
+    blocks - with the state carried over, bit for bit - and code that was generated before comes back at once.  (Without the
+    builder thread, so that the block at which code changes is the same in every run.)"""
     stages(None)
+    monkeypatch.setenv("FX_BUILDER", "0")
     N = 130
     lens = [300, 16, 16, 16, 16, 16, 16, 400, 400, 400, 400, 400, 64, 64, 64, 64, 64]
     cuts = [0]
@@ -188,8 +190,10 @@ def test_code_follows_the_block_length(gpu, stages):
         ys.append(b.process_block(x[lo:hi]))
         builds.append(b.info("xlate_builds"))
         waves.append(b.info("waves_per_wg"))
-    assert builds[0] == 1 and builds[4] == 2 and builds[6] == 2 and builds[11] == 3 and builds[-1] == 4, builds
-    assert waves[0] == 8 and waves[5] == 4 and waves[11] == 8 and waves[-1] == 8, waves
+    # 300: built; the fourth 16-sample block: built; the first 400-sample block: the code of block 0 again (no build); the fourth 64-sample block: built
+    assert builds[0] == 1 and builds[3] == 1 and builds[4] == 2 and builds[11] == 2 and builds[14] == 2 and builds[-1] == 3, builds
+    assert waves[0] == 8 and waves[5] == 4 and waves[7] == 8 and waves[-1] == 8, waves
+    assert b.info("code_cache_hits") == 1 and b.info("code_cached") == 3
     for n in (0, 63, 64, N - 1):
         o = Oracle(1)
         assert o.load_text(progs.config2())
@@ -197,6 +201,45 @@ def test_code_follows_the_block_length(gpu, stages):
             r = o.process_block(x[lo:hi, n].copy())
             assert np.array_equal(r.view(np.uint32), np.ascontiguousarray(y[:, n]).view(np.uint32)), (n, lo, hi)
         assert b.instruction_counter_i(n) == o.instruction_counter()
+    assert b.ood_flags() == 0
+
+
+@pytest.mark.parametrize("builder", [True, False], ids=["builder_thread", "callers_thread_only"])
+def test_returning_to_a_block_length_is_a_swap(gpu, stages, monkeypatch, builder):
+    """a host that alternates between two block lengths - runs of five 16-sample blocks and five 400-sample blocks, ten times
+    over (the caller the reference is written for processes 32-sample blocks, source/main.cpp:103-122, include/FX8010.h:38) -
+    gets each class of code generated once: every later change is a pointer swap.  With the builder thread no translation at
+    all happens on the caller's thread after the first block"""
+    stages(None)
+    if not builder:
+        monkeypatch.setenv("FX_BUILDER", "0")
+    N = 130
+    lens = ([16] * 5 + [400] * 5) * 10
+    cuts = [0]
+    for n in lens:
+        cuts.append(cuts[-1] + n)
+    x = progs.stimulus(N, cuts[-1])
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(progs.config2())
+    ys, waves = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ys.append(b.process_block(x[lo:hi]))
+        waves.append(b.info("waves_per_wg"))
+    assert b.info("xlate_builds") <= (1 if builder else 3), (b.info("xlate_builds"), b.info("xlate_background_builds"))
+    assert b.info("code_cache_hits") >= (10 if builder else 17)
+    if not builder:   # (the builder thread delivers when it is done: a few blocks later than this)
+        assert waves[4] == 4 and waves[9] == 8, waves   # by the end of each run its own code is in force
+        assert waves[10] == 4 and waves[15] == 8        # ... and from the second round on at a run's first block
+    assert waves[-10] == 4 and waves[-6] == 4 and waves[-5] == 8 and waves[-1] == 8, waves
+    for n in (0, 63, 64, N - 1):
+        o = Oracle(1)
+        assert o.load_text(progs.config2())
+        for (lo, hi), y in zip(zip(cuts[:-1], cuts[1:]), ys):
+            r = o.process_block(x[lo:hi, n].copy())
+            assert np.array_equal(r.view(np.uint32), np.ascontiguousarray(y[:, n]).view(np.uint32)), (n, lo, hi)
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+        for reg in ("t", "s0", "s30", "out", "ccr"):
+            assert b.get_register_bits_i(reg, n) == o.get_register_bits(reg), (reg, n)
     assert b.ood_flags() == 0
 
 
