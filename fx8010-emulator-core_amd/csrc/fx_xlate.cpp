@@ -1221,9 +1221,30 @@ class Translator {
         // must lie in [0, W), W a constant of the grid (fx_frontend.cpp lutGuessWindowHi) - one unsigned compare of d's high
         // word, three LDS reads instead of four.  A miss (one lane in ~10^5 within reach of a threshold) reads the thresholds
         // after all and corrects the index as the guarded form does.
-        lutFetch(site, window == 0, quick);
+        static const int prio = std::getenv("FX_XLATE_LUTPRIO") ? std::atoi(std::getenv("FX_XLATE_LUTPRIO")) : 0;   // diagnostics
+        // diagnostics, WRONG RESULTS (timing only): 1 = no branch to the miss path, 2 = no LDS reads and no wait, 4 = reads but no wait
+        static const int probe = std::getenv("FX_XLATE_LUTPROBE_WRONG_RESULTS") ? std::atoi(std::getenv("FX_XLATE_LUTPROBE_WRONG_RESULTS")) : 0;
+        if (prio > 0 && lds) e_.sopp(0x0fu, "s_setprio", (uint32_t)prio & 3u, true);
+        if (!(lds && (probe & 2))) lutFetch(site, window == 0, quick);
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
-        if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
+        {
+            // diagnostics: how much independent work fits into the LDS round trip for nothing?  FX_XLATE_LUTPAD=n pads every
+            // LOG / EXP with n plain (double-rate class) instructions on a spare register, FX_XLATE_LUTPAD_SLOW=n with n
+            // conversions (the 4-clock class) between the reads and their wait (tools/lut_pad_probe.sh)
+            static const int pad = std::getenv("FX_XLATE_LUTPAD") ? std::atoi(std::getenv("FX_XLATE_LUTPAD")) : 0;
+            static const int padSlow = std::getenv("FX_XLATE_LUTPAD_SLOW") ? std::atoi(std::getenv("FX_XLATE_LUTPAD_SLOW")) : 0;
+            static const int padAfter = std::getenv("FX_XLATE_LUTPAD_AFTER") ? std::atoi(std::getenv("FX_XLATE_LUTPAD_AFTER")) : 0;
+            if (lds && !padAfter) {
+                for (int k = 0; k < pad; ++k) e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 31, vreg(31), 31);
+                for (int k = 0; k < padSlow; ++k) e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(31), vreg(31));
+            }
+            if (lds && (probe & 6)) {} else if (lds) e_.waitLgkm0(); else e_.waitVmcnt(0);
+            if (lds && padAfter) {   // the same instructions BEHIND the wait: what they cost when nothing hides them
+                for (int k = 0; k < pad; ++k) e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 31, vreg(31), 31);
+                for (int k = 0; k < padSlow; ++k) e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(31), vreg(31));
+            }
+        }
+        if (prio > 0 && lds) e_.sopp(0x0fu, "s_setprio", 0, true);
         // the segment arithmetic goes ahead on the guess while the scalar unit makes up its mind (the compares' results
         // reach it a pipeline later: checking first would stall the wave twice per LOG/EXP); a miss redoes it
         if (window) {
@@ -1236,7 +1257,8 @@ class Translator {
             lutSegmentMath(0);
             e_.sop2(SOP2_OR_B64, "s_or_b64", vcc, vcc, sreg64(kSTemp));
         }
-        if (lds) {
+        if (lds && (probe & 1)) {
+        } else if (lds) {
             // the miss path lives behind the loop (emitDeferred): the hit path falls through its branch
             defer(e_.branchForward(SOPP_CBRANCH_VCCNZ, "s_cbranch_vccnz"), [this, site]() { lutMiss(site); });
         } else {
