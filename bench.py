@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SIMDS = 1024           # 256 CUs x 4 SIMD-32
 MAX_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md: max clock
 FAST_VALU_CLOCKS = 2.12  # measured: SIMD clocks per wave64 v_mul_f32 / v_add_f32 with >= 2 wavefronts resident (tools/micro/valu_rate.hip)
+NOMINAL_VALU_CLOCKS = 2.0  # MI355X_MICROARCH.md: a wave64 plain fp32 instruction occupies a SIMD-32 for two clocks (the nominal peak)
 
 
 def parse():
@@ -53,6 +54,10 @@ def parse():
     ap.add_argument("--parity-instances", type=int, default=1024, help="instances checked against the oracle after the timed region (0 disables)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations (they run by default for N=1, default workload)")
     ap.add_argument("--sharded", action="store_true", help="one process, --gpus devices through fxb_create_sharded")
+    ap.add_argument("--cpu-baseline", default="reference", choices=["reference", "port"],
+                    help="what is timed on the host cores: 'reference' = oracle/_ref/libfxref.so, the UNMODIFIED reference compiled by `make -C oracle ref` "
+                         "(build() does that wherever /root/reference exists; the .so is git-ignored and travels to the GPU box) - the policy; "
+                         "'port' = oracle/libfxoracle.so, this repo's C restatement (also what a tree without the prebuilt reference falls back to, and says so)")
     return ap.parse_args()
 
 
@@ -90,21 +95,26 @@ def usable_cores():
     return max(1, min(n, 16))
 
 
-def measured_issue_quads(config, n_inst, n_samples):
+def measured_issue_quads(config, n_inst, n_samples, code_hash):
     """Quad-cycles in which a SIMD issued vector instructions for one wavefront during one sample, from a COMMITTED rocprofv3 PMC
-    pass of exactly this workload (profiles/*pmc_valu*.json: SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2, tools/pmc_valu.txt,
-    tools/pmc_summary.py) - a constant read from that file, like roofline.traffic; the timing it is set against is this run's."""
+    pass of exactly this workload AND this code (profiles/*pmc_valu*.json: SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2, tools/pmc_valu.txt,
+    tools/pmc_summary.py) - a constant read from that file, like roofline.traffic; the timing it is set against is this run's.
+    The file names the code object it was collected on (bench.code_hash = fxb_info xlate_code_hash of that run): a pass of
+    other code - the generated code has changed since - is not used.  -> (quads or None, file or the reason there is none)"""
     import glob
 
+    stale = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_valu*.json")), reverse=True):
         try:
             d = json.load(open(f))
             w = d["bench"]
             if w["config"] == config and w["instances"] == n_inst and w["samples"] == n_samples:
-                return float(d["derived"]["valu_issue_quad_cycles_per_wave_sample"]), os.path.relpath(f, ROOT)
+                if w.get("code_hash") == code_hash:
+                    return float(d["derived"]["valu_issue_quad_cycles_per_wave_sample"]), os.path.relpath(f, ROOT)
+                stale = stale or "stale: %s is a pass of other code (%s, this run %s)" % (os.path.relpath(f, ROOT), w.get("code_hash"), code_hash)
         except (OSError, ValueError, KeyError):
             pass
-    return None, None
+    return None, stale
 
 
 def measured_traffic(config, n_inst, n_samples):
@@ -124,14 +134,20 @@ def measured_traffic(config, n_inst, n_samples):
     return None, None
 
 
-def cpu_baseline(text, budget_s):
-    """Time the reference (or, without oracle/_ref, the C port) on the host cores: bounded sample."""
+def cpu_baseline(text, budget_s, want="reference"):
+    """Time the CPU side on the host cores: bounded sample.  Policy (--cpu-baseline): the unmodified reference, prebuilt as
+    oracle/_ref/libfxref.so; a tree that does not have it (a fresh clone without /root/reference) times this repo's C
+    restatement instead and says so in the line (kind "port", "fallback")."""
     import tempfile
 
     import fx8010_programs as progs
     from pyoracle import Oracle, Reference
 
-    cls, kind = (Reference, "reference") if Reference.available() else (Oracle, "port")
+    fallback = None
+    if want == "reference" and not Reference.available():
+        fallback = "oracle/_ref/libfxref.so is not in this tree (built by `make -C oracle ref` where /root/reference exists): the C restatement oracle/libfxoracle.so was timed"
+        print("bench.py: " + fallback, file=sys.stderr)
+    cls, kind = (Reference, "reference") if (want == "reference" and fallback is None) else (Oracle, "port")
     cores = usable_cores()
     fd, path = tempfile.mkstemp(suffix=".da")
     with os.fdopen(fd, "wb") as fh:
@@ -149,7 +165,7 @@ def cpu_baseline(text, budget_s):
         n1 = max(4096, samples // 8)
         s1, _, _ = cls.bench(path, n1, 1, stim)
         i1 = per_sample * n1
-        return {"value": round(mips, 1), "unit": "MIPS", "cores": cores, "kind": kind,
+        return {"value": round(mips, 1), "unit": "MIPS", "cores": cores, "kind": kind, "policy": "--cpu-baseline " + want, "fallback": fallback,
                 "sample": "%d host threads x %d process() calls each of the same program (%.0f instr/sample), %.1f s" % (cores, samples, per_sample, secs),
                 "single_thread_mips": round(i1 / s1 / 1e6, 1)}
     finally:
@@ -323,6 +339,9 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
     last_ms = batch.last_kernel_ms()
     executed = batch.instruction_counter() - c0  # reference counting: END/SKIP count, skipped don't
     ood = batch.ood_flags()
+    # every device's own time: one entry per rank (torchrun) or per shard (--sharded)
+    per_gpu_kernel_ms = batch.shard_kernel_ms() if sharded else shard.gather_scalars(dist, kernel_ms, reduce_dev)
+    per_gpu_elapsed_s = shard.gather_scalars(dist, elapsed, reduce_dev)
     elapsed = shard.reduce_scalar(dist, elapsed, "max", reduce_dev)        # slowest rank
     executed_all = shard.reduce_scalar(dist, executed, "sum", reduce_dev)  # whole job
 
@@ -357,33 +376,38 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
         if valu_per_wave_sample > 0:
             per_s = valu_per_wave_sample * waves * S / (kernel_ms * 1e-3)
             peak = SIMDS * MAX_CLOCK_HZ / FAST_VALU_CLOCKS
+            peak_nominal = SIMDS * MAX_CLOCK_HZ / NOMINAL_VALU_CLOCKS
+            code_hash = "%016x" % batch.info("xlate_code_hash")
             # issue time of the instructions a wave executes per sample, by class (cost table: fx_xlate.cpp Emitter::issueCost,
             # measured by tools/micro/mix_cost.hip), against the SIMD cycles that were available at the clock the chip held
             clocks = batch.info("xlate_valu_clocks")
             hz = (clock_mhz * 1e6) if clock_mhz else MAX_CLOCK_HZ
             busy = clocks * (waves / float(SIMDS)) * S / (kernel_ms * 1e-3 * hz)
             # ... and the same from hardware counters: quad-cycles in which the SIMD issued for a wavefront (dual issue counted once)
-            quads, quads_source = measured_issue_quads(config, n_inst, S)
+            quads, quads_source = measured_issue_quads(config, n_inst, S, code_hash)
             busy_counters = round(quads * 4.0 * (waves * stages / float(SIMDS)) * S / (kernel_ms * 1e-3 * hz), 4) if quads else None
             valu = {"bound": "valu issue", "achieved": round(per_s / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
-                    "frac": round(per_s / peak, 4), "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves * stages / float(SIMDS), 3),
+                    "frac": round(per_s / peak, 4), "peak_nominal_2clk": round(peak_nominal / 1e9, 1), "frac_of_nominal_2clk_peak": round(per_s / peak_nominal, 4),
+                    "code_hash": code_hash, "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves * stages / float(SIMDS), 3),
                     "stages": stages,
                     "valu_per_emulated_instr": round(valu_per_wave_sample / max(executed / float(steps * S * n_inst * n_dev), 1e-9), 3),
                     "valu_4clock_class_per_wave_sample": batch.info("xlate_valu_slow"),
                     "issue_clocks_per_wave_sample": clocks, "clock_mhz": clock_mhz, "power_w": power_w,
                     "clocks_per_valu_per_simd": round(kernel_ms * 1e-3 * hz / (valu_per_wave_sample * max(waves / float(SIMDS), 1.0) * S), 3),
-                    "simd_issue_busy": round(busy, 4),
                     "simd_issue_busy_from_counters": busy_counters, "issue_quad_cycles_source": quads_source,
-                    "note": "peak = 1024 SIMDs x 2.4 GHz / 2.12 clocks, the rate of plain fp32 add / mul; conversions, fp64, min/max and compares "
-                            "cost 2.6-4.25 clocks each: simd_issue_busy = modelled issue clocks of the executed mix / SIMD clocks available at the "
-                            "measured clock (DESIGN.md section 5); simd_issue_busy_from_counters = quad-cycles in which a SIMD issued vector instructions "
-                            "(SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2 of a committed PMC pass of this kernel and launch shape) x 4 clocks / the same SIMD clocks; "
-                            "below 2 wavefronts per SIMD a wavefront issues only every ~5th clock"}
+                    "simd_issue_busy_model": round(min(busy, 1.0), 4), "simd_issue_busy_model_uncapped": round(busy, 4),
+                    "note": "peak = 1024 SIMDs x 2.4 GHz / 2.12 clocks, the measured rate of plain fp32 add / mul (peak_nominal_2clk: the data-sheet 2 clocks); "
+                            "conversions, fp64, min/max and compares cost 2.6-4.25 clocks each.  simd_issue_busy_from_counters = quad-cycles in which a SIMD "
+                            "issued vector instructions (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2 of a committed PMC pass of this launch shape AND this code "
+                            "object: code_hash; null when the committed pass is of other code) x 4 clocks / the SIMD clocks available at the measured clock; "
+                            "simd_issue_busy_model = modelled issue clocks of the executed mix / the same SIMD clocks (a four-wavefront calibration: "
+                            "capped at 1, the uncapped figure beside it; DESIGN.md section 5); below 2 wavefronts per SIMD a wavefront issues only every ~5th clock"}
         res = {
             "value": round(mips, 1),
             "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 4),
             "config": {
                 "workload": "%s: %d instances/GPU x %d-instr program, block of %d samples, mono 48 kHz" % (config, n_inst, P, S),
+                "name": config, "instances_per_gpu": n_inst, "samples_per_step": S,
                 "instances_total": n_inst * max(n_dev, 1) * (dist.get_world_size() if dist is not None else 1),
                 "instr_per_sample_static": P,
                 "instr_per_sample_executed": round(executed / float(steps * S * n_inst * n_dev), 3),
@@ -402,6 +426,9 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
                 "kernel": kernel_name(batch),
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_last_launch": round(last_ms, 4),
+                "per_gpu_kernel_ms": [round(v, 4) for v in per_gpu_kernel_ms],
+                "per_gpu_kernel_ms_note": ("last launch of each shard (library events on the shard's stream)" if sharded else "mean of the timed launches on each rank's device (HIP events on the launch stream)"),
+                "per_gpu_elapsed_s": [round(v, 6) for v in per_gpu_elapsed_s],
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": "the interpreter is instruction-issue bound (>= 12 emulated instr per algorithmic HBM byte): see roofline.valu and DESIGN.md section 5",
                 "emulated_instr_per_s_per_gpu": round(executed / n_dev / (kernel_ms * 1e-3 * steps), 1),
@@ -477,7 +504,7 @@ def main():
             out["parity"] = res["parity"]
         single = n_gpus == 1
         if single and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(text, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(text, args.cpu_seconds, args.cpu_baseline)
         if single and not args.no_extras and args.config == "config5" and not args.instances and S == 4096:
             # the other single-GPU configurations of BASELINE.json at their instance counts, and ALL of configs[4]
             # (2 097 152 instances, 64 GiB of xTRAM) on this one GPU; fewer launches each, same block length
@@ -493,7 +520,10 @@ def main():
                                    "valu_frac": (r["roofline"]["valu"] or {}).get("frac"), "waves_per_simd": (r["roofline"]["valu"] or {}).get("waves_per_simd"),
                                    "stages": (r["roofline"]["valu"] or {}).get("stages"),
                                    "valu_per_emulated_instr": (r["roofline"]["valu"] or {}).get("valu_per_emulated_instr"),
-                                   "simd_issue_busy": (r["roofline"]["valu"] or {}).get("simd_issue_busy"), "clock_mhz": (r["roofline"]["valu"] or {}).get("clock_mhz"),
+                                   "simd_issue_busy_from_counters": (r["roofline"]["valu"] or {}).get("simd_issue_busy_from_counters"),
+                                   "issue_quad_cycles_source": (r["roofline"]["valu"] or {}).get("issue_quad_cycles_source"),
+                                   "simd_issue_busy_model": (r["roofline"]["valu"] or {}).get("simd_issue_busy_model"),
+                                   "code_hash": (r["roofline"]["valu"] or {}).get("code_hash"), "clock_mhz": (r["roofline"]["valu"] or {}).get("clock_mhz"),
                                    "power_w": (r["roofline"]["valu"] or {}).get("power_w"),
                                    "parity_checked": (r.get("parity") or {}).get("parity_checked"), "parity_ok": (r.get("parity") or {}).get("parity_ok")}
                 except Exception as e:  # an extra must never take the headline line down

@@ -694,6 +694,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
             c.steady = (uint64_t)image.steadyFastOff | ((uint64_t)image.steadyOff << 32);
             c.last = (uint64_t)image.lastFastOff | ((uint64_t)image.lastOff << 32);
             c.codeBytes = image.codeBytes;
+            c.codeHash = imageHash(image);
             c.initOff = image.initOff;
             c.ldsBytes = image.ldsBytes;
             c.wildRow = image.wildRow;
@@ -1399,6 +1400,7 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_CALLED: return c_.useXlate ? c_.called : 0;
         case FXB_INFO_XLATE_BUILDS: return xlateBuilds_;
         case FXB_INFO_XLATE_BACKGROUND_BUILDS: return backgroundBuilds_;
+        case FXB_INFO_XLATE_CODE_HASH: return c_.useXlate ? (int64_t)c_.codeHash : 0;
         case FXB_INFO_CODE_CACHE_HITS: return cacheHits_;
         case FXB_INFO_CODE_CACHED: return (int64_t)cache_.size() + (c_.key.empty() ? 0 : 1);
         case FXB_INFO_XLATE_UNSATURATED: return c_.useXlate ? c_.unsaturated : 0;

@@ -120,6 +120,7 @@ private:
         hipFunction_t fn = nullptr;
         uint64_t steady = 0, last = 0;  // {fast, exact} stream offsets as the kernel takes them
         uint32_t codeBytes = 0, initOff = 0, ldsBytes = 0;
+        uint64_t codeHash = 0;          // imageHash() of the code object
         int stages = 1;                 // wavefronts per workgroup of the translated program (fx_xlate.hpp StageInfo)
         int blockClass = -1;            // the class of block lengths the staged code was generated for
         bool classMatters = false;      // the program can be cut: code for another class of block lengths would differ

@@ -154,6 +154,10 @@ int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instanc
     if (n_instances) *n_instances = h->batch.countOf(shard);
     return 0;
 }
+float fxb_shard_kernel_ms(fxb_handle* h, int shard) {
+    if (!h || shard < 0 || shard >= h->batch.shards()) return -1.0f;
+    return guard(&h->batch.front(), -1.0f, [&] { return h->batch.lastKernelMsOf(shard); });
+}
 int fxb_shard_plan(int64_t n, int n_shards, int64_t* first_instance, int64_t* n_instances_out) {
     if (n_shards < 1 || !first_instance || !n_instances_out) return FX_E_ARG;
     try {
@@ -365,6 +369,46 @@ int64_t fxp_translate_staged(fxp_handle* h, int vgprs, int stages, int stage, in
     if (!h) return FX_E_ARG;
     try {
         return translateImpl(h, vgprs, stream, code, cap, listing, listing_cap, stages, stage, stages_out, info, info_cap);
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return codeOf(e);
+    } catch (...) {
+        h->err = "unknown error";
+        return FX_E_PROGRAM;
+    }
+}
+int64_t fxp_code_hash(fxp_handle* h, int vgprs, int stages, unsigned flags) {
+    if (!h) return FX_E_ARG;
+    try {
+        if (!h->prog.ready) { h->err = "no program loaded"; return FX_E_NOTREADY; }
+        std::vector<float> values(h->prog.regs.size());
+        for (size_t r = 0; r < values.size(); ++r) values[r] = h->prog.regs[r].value;
+        std::vector<uint8_t> perLane(values.size(), 0);
+        for (int r : h->tracked) perLane[(size_t)r] = 1;
+        fx::Lowered low = fx::lowerProgram(h->prog, values, perLane, 1, false, 1);
+        if (!low.error.empty()) { h->err = low.error; return FX_E_PROGRAM; }
+        std::string why;
+        if (!fx::asmEligible(low, &why)) { h->err = "not eligible: " + why; return FX_E_PROGRAM; }
+        int want = -1;
+        for (int q = fx::ASM_V64; q < fx::ASM_VARIANTS; ++q)
+            if (fx::kAsmVgprRows[q] + 32 == vgprs && low.nRows <= fx::kAsmVgprRows[q]) want = q;
+        if (want < 0) { h->err = "no such VGPR build, or too small for the program"; return FX_E_ARG; }
+        const fx::XlateTemplate* tmpl = fx::xlateTemplate((fx::AsmVariant)want, &h->err);
+        if (!tmpl) return FX_E_PROGRAM;
+        const std::vector<fx::MicroOp> steadyRecords = fx::encodeAsmStream(low.steady, nullptr, true), lastRecords = fx::encodeAsmStream(low.last, nullptr, true);
+        std::vector<int> trackRows;
+        for (int r : h->tracked) trackRows.push_back(low.rowOfReg[(size_t)r]);
+        fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow, trackRows);
+        xprog.tramStreaming = (flags & 1u) != 0;
+        fx::XlateImage image;
+        bool built = false;
+        if (stages >= 2) {
+            const fx::StagePlan sp = fx::planStages(steadyRecords, lastRecords, xprog, low.nRows, stages);
+            if (!sp.cuts.empty()) built = fx::buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, sp, &image, nullptr, nullptr, &h->err);
+            if (!built) image = fx::XlateImage();
+        }
+        if (!built && !fx::buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &h->err)) return FX_E_PROGRAM;
+        return (int64_t)fx::imageHash(image);
     } catch (const std::exception& e) {
         h->err = e.what();
         return codeOf(e);

@@ -98,6 +98,10 @@ int Sharded::fan(const std::function<int(int, Batch&)>& f) {
         DeviceGuard guard;
         return f(0, *shards_[0]->batch);
     }
+    // one post at a time per handle: every worker has ONE mailbox slot, and a second host thread (a UI thread reading a register
+    // while the audio thread processes a block) must not overwrite a task that has not been picked up yet - its caller would
+    // wait for `done` forever.  (A handle is still not meant for concurrent use: calls are serialised, not made independent.)
+    std::lock_guard<std::mutex> post(post_);
     for (size_t k = 0; k < shards_.size(); ++k) {
         Worker* w = shards_[k].get();
         std::lock_guard<std::mutex> lock(w->mu);
@@ -124,6 +128,7 @@ int Sharded::runOn(int k, const std::function<int(Batch&)>& f) {
         DeviceGuard guard;
         return f(*w->batch);
     }
+    std::lock_guard<std::mutex> post(post_);
     {
         std::lock_guard<std::mutex> lock(w->mu);
         w->task = [&f, w] { return f(*w->batch); };
@@ -255,6 +260,11 @@ float Sharded::lastKernelMs() {
     float worst = -1.0f;
     for (float p : part) worst = std::max(worst, p);
     return worst;
+}
+float Sharded::lastKernelMsOf(int k) {
+    float ms = -1.0f;
+    runOn(k, [&](Batch& b) { ms = b.lastKernelMs(); return 0; });
+    return ms;
 }
 int64_t Sharded::info(int what) {
     std::vector<int64_t> part(shards_.size(), 0);

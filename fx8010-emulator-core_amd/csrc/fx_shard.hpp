@@ -70,6 +70,7 @@ public:
     int64_t instructionCounterAt(int64_t inst);
     uint32_t oodFlags();
     float lastKernelMs();  // slowest shard
+    float lastKernelMsOf(int k);
     int64_t info(int what);
     const std::string& lastError();
 
@@ -96,6 +97,7 @@ private:
     int64_t n_ = 0;
     std::vector<std::unique_ptr<Worker>> shards_;
     std::string lastError_;
+    std::mutex post_;   // serialises posts to the workers' mailboxes (fan / runOn)
 };
 
 }  // namespace fx

@@ -3342,6 +3342,19 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     return true;
 }
 
+uint64_t imageHash(const XlateImage& image) {
+    uint64_t h = 0xcbf29ce484222325ull;   // FNV-1a over 8-byte words
+    const size_t n = image.elf.size() / 8;
+    for (size_t k = 0; k < n; ++k) {
+        uint64_t w;
+        std::memcpy(&w, image.elf.data() + 8 * k, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+    }
+    for (size_t k = 8 * n; k < image.elf.size(); ++k) h = (h ^ image.elf[k]) * 0x100000001b3ull;
+    h = (h ^ (uint64_t)image.stages ^ ((uint64_t)image.ldsBytes << 8)) * 0x100000001b3ull;
+    return h & 0x7fffffffffffffffull;
+}
+
 bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
                      const XlateTemplate& tmpl, const XlateProgram& prog, XlateImage* out, std::string* err) {
     std::vector<uint32_t> code[5];

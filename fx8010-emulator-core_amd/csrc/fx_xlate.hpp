@@ -213,6 +213,9 @@ struct XlateImage {
     std::vector<uint8_t> wildRow;  // row classes the code relies on: the loader flags BOUNDED rows in the row table
     int vgprConstants = 0;         // uniform constants the code keeps in VGPRs above the register file
 };
+// a fingerprint of the code object (template and generated code): what a profile of a launch is a profile OF (bench.py ties the
+// committed hardware-counter passes to it; 63 bits)
+uint64_t imageHash(const XlateImage& image);
 // Lays the four streams out ([steady fast][steady exact][last fast][last exact]) and translates them; code[k] /
 // listing[k] in that order (listing may be nullptr); code[4] = the run-once code (LDS tables), empty when none.  Without a fast stream (non-finite uniform operand) the
 // fast offsets equal the exact ones.

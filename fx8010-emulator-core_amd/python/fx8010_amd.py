@@ -23,7 +23,7 @@ INFO = {
     "num_instructions": 0, "num_registers": 1, "num_lane_regs": 2, "num_uniform_regs": 3, "lds_bytes_per_wg": 4,
     "waves_per_wg": 5, "num_microops": 6, "itram_slots": 7, "xtram_slots": 8, "tram_ops": 9, "multipass": 10,
     "num_shadowed": 11, "num_ccr_live": 12, "device": 13, "grid": 14, "inst_per_lane": 15, "kernel": 16, "num_rows": 17,
-    "xlate_code_bytes": 18, "xlate_inlined": 19, "xlate_called": 20, "xlate_unsaturated": 21, "xlate_valu": 22, "xlate_valu_slow": 23, "xlate_valu_clocks": 24, "xlate_vgpr_constants": 25, "xlate_builds": 26, "code_cache_hits": 27, "code_cached": 28, "xlate_background_builds": 29,
+    "xlate_code_bytes": 18, "xlate_inlined": 19, "xlate_called": 20, "xlate_unsaturated": 21, "xlate_valu": 22, "xlate_valu_slow": 23, "xlate_valu_clocks": 24, "xlate_vgpr_constants": 25, "xlate_builds": 26, "code_cache_hits": 27, "code_cached": 28, "xlate_background_builds": 29, "xlate_code_hash": 30,
 }
 
 # every symbol include/fx8010_amd.h declares (tests check that the library exports them all)
@@ -31,7 +31,7 @@ SYMBOLS = [
     "fx_create", "fx_destroy", "fx_load_file", "fx_process", "fx_process_block", "fx_set_register", "fx_get_register",
     "fx_instruction_counter", "fx_error_count", "fx_error_desc", "fx_error_row", "fx_control_count", "fx_control_at",
     "fx_meta_get", "fx_set_option", "fxb_set_option", "fxp_set_option", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
-    "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_shard_plan", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
+    "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_shard_kernel_ms", "fxb_shard_plan", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
     "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
     "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error",
@@ -39,7 +39,7 @@ SYMBOLS = [
     "fxp_create", "fxp_destroy", "fxp_load_file", "fxp_load_text", "fxp_num_registers", "fxp_register_name",
     "fxp_register_type", "fxp_register_ioindex", "fxp_register_value", "fxp_num_instructions", "fxp_instruction",
     "fxp_itram_size", "fxp_xtram_size", "fxp_error_count", "fxp_error_desc", "fxp_error_row", "fxp_control_count",
-    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_translate", "fxp_track_register", "fxp_translate_staged", "fxp_last_error",
+    "fxp_control_at", "fxp_meta_get", "fxp_ready", "fxp_lut", "fxp_lower", "fxp_lower_info", "fxp_translate", "fxp_track_register", "fxp_translate_staged", "fxp_code_hash", "fxp_last_error",
 ]
 
 
@@ -72,6 +72,7 @@ def load():
     sig("fxb_create_sharded", vp, i64, i32, C.c_uint64); sig("fxb_create_on_devices", vp, i64, i32, C.POINTER(C.c_int), i32)
     sig("fxb_shard_count", i32, vp); sig("fxb_shard_info", i32, vp, i32, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64))
     sig("fxb_shard_plan", i32, i64, i32, C.POINTER(i64), C.POINTER(i64))
+    sig("fxb_shard_kernel_ms", f32, vp, i32)
     sig("fxb_process_block_dev_shards", i32, vp, C.POINTER(vp), C.POINTER(vp), i32)
     sig("fxb_load_file", i32, vp, cp); sig("fxb_load_text", i32, vp, cp)
     sig("fxb_set_register", i32, vp, cp, f32); sig("fxb_set_register_i", i32, vp, cp, i64, f32)
@@ -98,6 +99,7 @@ def load():
     sig("fxp_translate", i64, vp, i32, i32, vp, i64, C.c_char_p, i64)
     sig("fxp_track_register", i32, vp, cp)
     sig("fxp_translate_staged", i64, vp, i32, i32, i32, i32, vp, i64, C.c_char_p, i64, C.POINTER(C.c_int), C.POINTER(C.c_int), i32)
+    sig("fxp_code_hash", i64, vp, i32, i32, C.c_uint)
     _lib = lib
     return lib
 
@@ -215,6 +217,13 @@ class FrontEnd(_Reports):
         self.stage_store = [int(v) for v in info[head + 1: head + 1 + int(info[head])]] if k > 1 else []   # per row: the stage that stores it
         return code.raw[:n], text.value.decode("ascii"), k, [int(v) for v in info[:head]]
 
+    def code_hash(self, vgprs, stages=1, tram_streaming=False):
+        """fingerprint of the code object a batch would load (fxb_info xlate_code_hash of a batch in that situation)"""
+        v = int(self._lib.fxp_code_hash(self._h, int(vgprs), int(stages), 1 if tram_streaming else 0))
+        if v < 0:
+            raise RuntimeError("fxp_code_hash: %d %s" % (v, self.last_error()))
+        return v
+
     def last_error(self):
         return self._lib.fxp_last_error(self._h).decode("latin-1")
 
@@ -262,6 +271,10 @@ class Batch(_Reports):
             self._check(self._lib.fxb_shard_info(self._h, k, C.byref(dev), C.byref(first), C.byref(cnt)), "shard_info")
             out.append((dev.value, first.value, cnt.value))
         return out
+
+    def shard_kernel_ms(self):
+        """HIP-event time of every shard's most recent launch, ms"""
+        return [float(self._lib.fxb_shard_kernel_ms(self._h, k)) for k in range(self._lib.fxb_shard_count(self._h))]
 
     def process_block_dev_shards(self, d_in, d_out, n_samples):
         """d_in / d_out: one device pointer (int) per shard; asynchronous."""

@@ -54,3 +54,15 @@ def reduce_scalar(dist, value, op, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_scalars(dist, value, device="cpu"):
+    """[value of rank 0, value of rank 1, ...] on every rank (a one-element list without a process group)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]

@@ -130,6 +130,9 @@ fxb_handle* fxb_create_on_devices(int64_t n_instances, int num_channels, const i
 int fxb_shard_count(fxb_handle* h);
 /* device ordinal, first global instance and instance count of a shard; 0 or FX_E_ARG.  Any out pointer may be NULL. */
 int fxb_shard_info(fxb_handle* h, int shard, int* device, int64_t* first_instance, int64_t* n_instances);
+/* HIP-event time of shard `shard`'s most recent launch in ms (fxb_last_kernel_ms is the slowest shard's); -1 when unknown.  A
+ * scaling run reports every device with it ("report per-device times too"). */
+float fxb_shard_kernel_ms(fxb_handle* h, int shard);
 /* The partition fxb_create_sharded / fxb_create_on_devices use for n_instances over n_shards devices, without creating
  * anything (no device needed): first_instance[k], n_instances[k] for k < n_shards.  0, or FX_E_ARG when a shard would be
  * empty (fewer wavefronts than shards) or an argument is invalid. */
@@ -228,6 +231,8 @@ enum {
     FXB_INFO_CODE_CACHE_HITS = 27, /* changes of code that were a pointer swap: the shape (block-length class, set of registers with rows, compiled-in
                                       values) had been generated before - by an earlier call or ahead of time by the builder thread */
     FXB_INFO_CODE_CACHED = 28,     /* generated code objects the handle holds (the one in force included) */
+    FXB_INFO_XLATE_CODE_HASH = 30, /* fingerprint (63 bits) of the code object in force, 0 when the program is not translated: what a profile of a
+                                      launch is a profile of (fxp_code_hash computes the same without a device) */
     FXB_INFO_XLATE_BACKGROUND_BUILDS = 29 /* translations on the handle's builder thread (ahead of time: the variant with the declared controls in
                                       rows, code for another class of block lengths); FX_BUILDER=0 in the environment turns the thread off */
 };
@@ -284,6 +289,12 @@ int fxp_track_register(fxp_handle* h, const char* key);
  * handed over}, then the LDS bytes of a workgroup, the number of register-file rows and, per row, the stage that stores it. */
 int64_t fxp_translate_staged(fxp_handle* h, int vgprs, int stages, int stage, int stream, void* code, int64_t cap, char* listing, int64_t listing_cap,
                              int* stages_out, int* info, int info_cap);
+/* Fingerprint (63 bits, >= 0; negative FX_E_*) of the code object a batch would load for this program with its registers' initial
+ * values: the `vgprs` build (64 ... 256), cut into at most `stages` stages (1: not cut; the default LDS budget and step length
+ * of a small batch with long blocks), flags bit 0 = delay lines larger than the caches (non-temporal TRAM accesses).  Equals
+ * fxb_info(FXB_INFO_XLATE_CODE_HASH) of a batch in that situation: tests and bench.py use it to tell whether a committed profile
+ * still describes the code that is generated today. */
+int64_t fxp_code_hash(fxp_handle* h, int vgprs, int stages, unsigned flags);
 const char* fxp_last_error(fxp_handle* h);
 
 /* library / device probe: number of HIP devices visible (0 if none), never throws */

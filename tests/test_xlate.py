@@ -116,6 +116,34 @@ def test_hardware_instruction_counters_are_of_this_code():
         assert abs(hw[key] - count) < 0.5, (key, hw[key], count)
 
 
+def test_committed_counter_passes_name_the_code_generated_today():
+    """every profiles/*_pmc_valu.json that carries the fingerprint of the code object it was collected on (bench.code_hash, since
+    round 4) - the unstaged streams of config3 / 4 / 5 and config2's eight stages - against the fingerprint of what the
+    translator generates now for that configuration (fxp_code_hash, no device): bench.py prints
+    simd_issue_busy_from_counters from a committed pass only when the two agree, this test says when a pass has gone stale"""
+    import glob
+    import json
+    newest = {}
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "*_pmc_valu.json"))):
+        d = json.load(open(f))
+        b = d.get("bench", {})
+        if b.get("code_hash") and b.get("config") in P.CONFIGS:
+            newest[b["config"]] = (f, d)
+    for config, (f, d) in newest.items():
+        b = d["bench"]
+        m = re.match(r"fx_xlate_v(\d+)", d["workload"]["kernel"])
+        assert m, (f, d["workload"]["kernel"])
+        fe = A.FrontEnd(1)
+        option = getattr(P, "CONFIG_OPTIONS", {}).get(config, 0)
+        if option:
+            fe.set_option(option)
+        assert fe.load_text(P.CONFIGS[config]())
+        slots = {"config5": 8192, "config3": 1000, "tram_bound": 8192, "config5_dane": 8192}.get(config, 0)
+        streaming = slots * ((b["instances"] + 63) // 64) * 256 > (512 << 20)   # (fx_batch.cpp: delay lines beyond the caches)
+        now = "%016x" % fe.code_hash(int(m.group(1)), b.get("stages") or 1, streaming)
+        assert now == b["code_hash"], "%s was collected on other code than is generated today (%s vs %s): run tools/profile_configs.sh again" % (os.path.basename(f), b["code_hash"], now)
+
+
 def branch_targets(listing):
     """(line index, target line index) of every SOPP branch of a listing (targets resolved through instruction sizes)"""
     lines = listing.strip().split("\n")

@@ -2,6 +2,11 @@
 """Summarise rocprofv3 counter passes (tools/pmc_sq.txt) of a bench.py run for the translated / interpreter kernel.
 
     python tools/pmc_summary.py <dir with pmc_*/..._counter_collection.csv> <samples per launch> [kernel prefix [kernel ms, shader MHz]]
+    python tools/pmc_summary.py <dir> --bench <bench.py's JSON line of the same workload, unprofiled> [kernel prefix]
+
+With --bench the samples per launch, the kernel time, the shader clock and - what ties the counters to the code they were
+collected on - the code object's fingerprint (roofline.valu.code_hash) are taken from that line and recorded under "bench":
+bench.py only uses a committed pass whose fingerprint is the running code's.
 
 Prints one JSON object: counters averaged over the kernel's dispatches, per wavefront and per wave-sample,
 plus the shares DESIGN.md section 5 quotes (waiting / issuing as a fraction of a wave's resident time).  Only ratios of SQ
@@ -18,6 +23,18 @@ from collections import defaultdict
 
 
 def main():
+    root = sys.argv[1]
+    bench = None
+    if sys.argv[2] == "--bench":
+        line = [l for l in open(sys.argv[3]).read().split("\n") if l.startswith("{")][-1]
+        b = json.loads(line)
+        v = b["roofline"]["valu"] or {}
+        bench = {"config": b["config"]["name"], "instances": b["config"]["instances_per_gpu"], "samples": b["config"]["samples_per_step"],
+                 "code_hash": v.get("code_hash"), "kernel_ms": b["roofline"]["kernel_ms"], "clock_mhz": v.get("clock_mhz"), "stages": v.get("stages"),
+                 "value_mips": b["value"], "file": os.path.basename(sys.argv[3])}
+        samples = bench["samples"]
+        prefix = sys.argv[4] if len(sys.argv) > 4 else "fx_"
+        sys.argv = sys.argv[:2] + [str(samples), prefix] + ([str(bench["kernel_ms"]), str(bench["clock_mhz"])] if bench["clock_mhz"] else [])
     root, samples = sys.argv[1], int(sys.argv[2])
     prefix = sys.argv[3] if len(sys.argv) > 3 else "fx_"
     sums, counts, meta = defaultdict(float), defaultdict(int), {}
@@ -60,6 +77,8 @@ def main():
             d["clocks_per_sample"] = round(clocks_per_sample, 1)
             d["valu_issue_busy_from_counters"] = round(quads * 4.0 * max(waves / 1024.0, 0.0) / clocks_per_sample, 4)
     out["derived"] = d
+    if bench:
+        out["bench"] = bench
     print(json.dumps(out, indent=1))
 
 

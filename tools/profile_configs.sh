@@ -24,6 +24,20 @@ for c in $CONFIGS; do
   rocprofv3 -i $ROOT/tools/pmc_sq.txt -d $OUT/${c}_pmc -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 2 --warmup 1 --no-extras --parity-instances 0 > $OUT/${c}_pmc.json 2> $OUT/${c}_pmc.err || exit 1
   echo "== $c: VALU issue counters (dual-issued quad-cycles, instruction classes)"
   rocprofv3 -i $ROOT/tools/pmc_valu.txt -d $OUT/${c}_valu -o ${c} --output-format csv -- python3 $ROOT/bench.py --config $c --cpu-seconds 0 --steps 2 --warmup 1 --no-extras --parity-instances 0 > $OUT/${c}_valu.json 2> $OUT/${c}_valu.err || exit 1
+  # the summaries that get committed under profiles/ (bench.py reads <tag>_<config>_pmc_valu.json and <tag>_hbm_traffic_<config>.json)
+  python3 $ROOT/tools/pmc_summary.py $OUT/${c}_pmc --bench $OUT/${c}_bench.json > $OUT/${TAG}_${c}_pmc_sq.json
+  python3 $ROOT/tools/pmc_summary.py $OUT/${c}_valu --bench $OUT/${c}_bench.json > $OUT/${TAG}_${c}_pmc_valu.json
+  python3 - $OUT/${c}_bench.json $OUT/${c}_hbm $c > $OUT/${TAG}_hbm_traffic_${c}.json <<PY
+import json, subprocess, sys
+b = json.loads([l for l in open(sys.argv[1]).read().split("\n") if l.startswith("{")][-1])
+out = subprocess.run([sys.executable, "$ROOT/tools/hbm_traffic.py", sys.argv[2], sys.argv[3], str(b["config"]["instances_per_gpu"]), str(b["config"]["samples_per_step"]),
+                      str(b["roofline"]["algorithmic_bytes_per_launch"])], stdout=subprocess.PIPE, text=True).stdout
+d = json.loads(out)
+d["code_hash"] = (b["roofline"]["valu"] or {}).get("code_hash")
+print(json.dumps(d, indent=1))
+PY
+  cp $OUT/${c}_bench.json $OUT/${TAG}_${c}_bench.json
+  f=$(find $OUT/${c}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${c}_kernel_stats.csv
 done
-find $OUT -name "*kernel_stats.csv" | head
+ls $OUT | grep "^${TAG}_"
 echo done
