@@ -1336,6 +1336,159 @@ int Batch::sync() {
     return e == hipSuccess ? 0 : hipFail(e, "sync");
 }
 
+// ---- state snapshot ------------------------------------------------------------------------------------------------------------
+int Batch::snapshotShape(SnapshotHeader* hdr) {
+    (void)hipSetDevice(device_);
+    int rc = ensureLowered();
+    if (rc != 0) return rc;
+    *hdr = SnapshotHeader();
+    hdr->n = n_;
+    hdr->channels = prog_.numChannels;
+    hdr->nRegs = (int32_t)prog_.regs.size();
+    hdr->stateRows = stateRows_;
+    hdr->iSlots = iSlotsAlloc_;
+    hdr->xSlots = xSlotsAlloc_;
+    return 0;
+}
+
+namespace {
+// delay memory on the device: [wave][slot][64 * K] (K instances per lane: the HIP C++ tier), an instance i at
+// wave i / (64 K), column i % (64 K); in an image: [instance][slot]
+constexpr size_t kTramChunkBytes = (size_t)64 << 20;
+}
+
+int Batch::saveStateColumns(uint8_t* image, const SnapshotHeader& hdr, int64_t first) {
+    (void)hipSetDevice(device_);
+    if (!image || first < 0 || first + n_ > hdr.n) return fail(FX_E_ARG, "snapshot: bad image");
+    SnapshotHeader mine;
+    int rc = snapshotShape(&mine);
+    if (rc != 0) return rc;
+    if (mine.channels != hdr.channels || mine.nRegs != hdr.nRegs || mine.stateRows != hdr.stateRows || mine.iSlots != hdr.iSlots || mine.xSlots != hdr.xSlots)
+        return fail(FX_E_ARG, "snapshot: the image was laid out for another program");
+    waitLastLaunch();
+    hipError_t e = hipStreamSynchronize(stream_);
+    uint8_t* rows = image + sizeof(SnapshotHeader);
+    if (e == hipSuccess)
+        e = hipMemcpy2D(rows + (size_t)first * 4, (size_t)hdr.n * 4, dState_, (size_t)nPad_ * 4, (size_t)n_ * 4, (size_t)stateRows_, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hipFail(e, "snapshot: state rows");
+    uint8_t* sec = rows + (size_t)hdr.stateRows * (size_t)hdr.n * 4;
+    for (int which = 0; which < 2; ++which) {
+        const float* dev = which ? dXTram_ : dITram_;
+        const int slots = which ? xSlotsAlloc_ : iSlotsAlloc_;
+        float* out = reinterpret_cast<float*>(sec);
+        sec += (size_t)hdr.n * (size_t)slots * 4;
+        if (slots == 0) continue;
+        const size_t cols = 64 * (size_t)instPerLane_, waveFloats = (size_t)slots * cols;
+        const size_t waves = ((size_t)n_ + cols - 1) / cols, chunk = std::max<size_t>(1, kTramChunkBytes / (waveFloats * 4));
+        std::vector<float> tmp(std::min(waves, chunk) * waveFloats);
+        for (size_t w0 = 0; w0 < waves; w0 += chunk) {
+            const size_t nw = std::min(chunk, waves - w0);
+            e = hipMemcpy(tmp.data(), dev + w0 * waveFloats, nw * waveFloats * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return hipFail(e, "snapshot: delay memory");
+            for (size_t w = 0; w < nw; ++w)
+                for (size_t j = 0; j < cols; ++j) {
+                    const size_t inst = (w0 + w) * cols + j;
+                    if (inst >= (size_t)n_) break;
+                    float* line = out + ((size_t)first + inst) * (size_t)slots;
+                    const float* src = tmp.data() + w * waveFloats + j;
+                    for (int s = 0; s < slots; ++s) line[s] = src[(size_t)s * cols];
+                }
+        }
+    }
+    return 0;
+}
+
+int Batch::loadStateColumns(const uint8_t* image, const SnapshotHeader& hdr, int64_t first) {
+    (void)hipSetDevice(device_);
+    if (!image || first < 0 || first + n_ > hdr.n) return fail(FX_E_ARG, "snapshot: bad image");
+    SnapshotHeader mine;
+    int rc = snapshotShape(&mine);
+    if (rc != 0) return rc;
+    if (hdr.magic != mine.magic || hdr.version != mine.version) return fail(FX_E_ARG, "snapshot: not a state image of this library version");
+    if (mine.channels != hdr.channels || mine.nRegs != hdr.nRegs || mine.stateRows != hdr.stateRows || hdr.iSlots > mine.iSlots || hdr.xSlots > mine.xSlots)
+        return fail(FX_E_ARG, "snapshot: the image is of another program (registers, channels or delay lines differ)");
+    waitLastLaunch();
+    hipError_t e = hipStreamSynchronize(stream_);
+    const uint8_t* rows = image + sizeof(SnapshotHeader);
+    if (e == hipSuccess)
+        e = hipMemcpy2D(dState_, (size_t)nPad_ * 4, rows + (size_t)first * 4, (size_t)hdr.n * 4, (size_t)n_ * 4, (size_t)stateRows_, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hipFail(e, "snapshot: state rows");
+    // what the host knows about the registers follows the image: a register every instance holds the same value of is a
+    // broadcast write of that value, any other one a per-instance write (as if the caller had made them)
+    for (int r = 0; r < hdr.nRegs; ++r) {
+        if (tracked(r) || intrinsicLane(r)) continue;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(rows + ((size_t)r * (size_t)hdr.n + (size_t)first) * 4);
+        bool same = true;
+        for (int64_t i = 1; i < n_ && same; ++i) same = row[i] == row[0];
+        float v;
+        std::memcpy(&v, &row[0], 4);
+        if (same) {
+            const bool moved = bitsOf(hostValue_[(size_t)r]) != row[0];
+            hostValue_[(size_t)r] = v;
+            if (forcedLane_[(size_t)r]) {
+                if (laneWritten_[(size_t)r] && !(controlMode_ && declaredControl(r))) { forcedLane_[(size_t)r] = 0; lowDirty_ = true; }
+            } else if (moved && readByProgram(r)) {
+                lowDirty_ = true;   // (compiled in: the next block is generated with the image's value - loading a snapshot is not the audio path)
+            }
+            laneWritten_[(size_t)r] = 0;
+        } else {
+            if (!forcedLane_[(size_t)r] && readByProgram(r)) { forcedLane_[(size_t)r] = 1; lowDirty_ = true; }
+            laneWritten_[(size_t)r] = 1;
+        }
+    }
+    const uint8_t* sec = rows + (size_t)hdr.stateRows * (size_t)hdr.n * 4;
+    for (int which = 0; which < 2; ++which) {
+        float* dev = which ? dXTram_ : dITram_;
+        const int alloc = which ? xSlotsAlloc_ : iSlotsAlloc_, slots = which ? hdr.xSlots : hdr.iSlots;
+        const float* in = reinterpret_cast<const float*>(sec);
+        sec += (size_t)hdr.n * (size_t)slots * 4;
+        if (alloc == 0) continue;
+        const size_t cols = 64 * (size_t)instPerLane_, waveFloats = (size_t)alloc * cols;
+        const size_t waves = ((size_t)n_ + cols - 1) / cols, chunk = std::max<size_t>(1, kTramChunkBytes / (waveFloats * 4));
+        std::vector<float> tmp(std::min(waves, chunk) * waveFloats);
+        for (size_t w0 = 0; w0 < waves; w0 += chunk) {
+            const size_t nw = std::min(chunk, waves - w0);
+            std::fill(tmp.begin(), tmp.begin() + (long)(nw * waveFloats), 0.0f);
+            for (size_t w = 0; w < nw; ++w)
+                for (size_t j = 0; j < cols; ++j) {
+                    const size_t inst = (w0 + w) * cols + j;
+                    if (inst >= (size_t)n_) break;
+                    const float* line = in + ((size_t)first + inst) * (size_t)slots;
+                    float* dst = tmp.data() + w * waveFloats + j;
+                    for (int s = 0; s < slots; ++s) dst[(size_t)s * cols] = line[s];
+                }
+            e = hipMemcpy(dev + w0 * waveFloats, tmp.data(), nw * waveFloats * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return hipFail(e, "snapshot: delay memory");
+        }
+    }
+    return 0;
+}
+
+int Batch::getTramAt(int which, int64_t inst, float* out, int nSlots) {
+    (void)hipSetDevice(device_);
+    if (inst < 0 || inst >= n_ || !out || nSlots < 0 || which < 0 || which > 1) return fail(FX_E_ARG, "get_tram: bad argument");
+    int rc = ensureLowered();
+    if (rc != 0) return rc;
+    waitLastLaunch();
+    const float* dev = which ? dXTram_ : dITram_;
+    const int alloc = which ? xSlotsAlloc_ : iSlotsAlloc_;
+    for (int s = 0; s < nSlots; ++s) out[s] = 0.0f;   // (slots the program cannot reach are not allocated: zero, as in a fresh reference object)
+    const int take = std::min(nSlots, alloc);
+    if (take <= 0) return 0;
+    const size_t cols = 64 * (size_t)instPerLane_;
+    const float* src = dev + ((size_t)inst / cols) * (size_t)alloc * cols + (size_t)inst % cols;
+    hipError_t e = hipMemcpy2D(out, 4, src, cols * 4, 4, (size_t)take, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : hipFail(e, "get_tram");
+}
+
+int Batch::getCursorsAt(int64_t inst, int32_t out4[4]) {
+    (void)hipSetDevice(device_);
+    if (inst < 0 || inst >= n_ || !out4 || !dState_) return fail(FX_E_ARG, "get_cursors: bad argument");
+    waitLastLaunch();
+    hipError_t e = hipMemcpy2D(out4, 4, dState_ + (size_t)stateLayout_.cursorBase * nPad_ + inst, (size_t)nPad_ * 4, 4, 4, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : hipFail(e, "get_cursors");
+}
+
 int64_t Batch::instructionCounter() {
     (void)hipSetDevice(device_);
     if (!dState_) return 0;

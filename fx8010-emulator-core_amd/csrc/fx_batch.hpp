@@ -44,6 +44,27 @@ public:
     int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
     int sync();
 
+    // State snapshot (the reference keeps all DSP state in plain members, include/FX8010.h:162-217, 288-291: registers, output
+    // latches, delay memory and its four positions, the LFSR words, the instruction counter).  The image is laid out by GLOBAL
+    // instance, so a batch saved from one partition can be loaded into another: this batch's instances are columns
+    // [first, first + n) of an image of nTotal instances.  Sections behind the header: state rows [stateRows][nTotal] u32,
+    // iTRAM [nTotal][iSlots] f32, xTRAM [nTotal][xSlots] f32.
+    struct SnapshotHeader {
+        uint32_t magic = 0x54535846u, version = 1;   // "FXST"
+        int64_t n = 0;
+        int32_t channels = 0, nRegs = 0, stateRows = 0, iSlots = 0, xSlots = 0, reserved[7] = {};
+    };
+    static_assert(sizeof(SnapshotHeader) == 64, "SnapshotHeader layout");
+    int snapshotShape(SnapshotHeader* hdr);   // what this batch would save (lowers the program first); n = this batch's instances
+    static int64_t snapshotBytes(const SnapshotHeader& hdr) {
+        return (int64_t)sizeof(SnapshotHeader) + (int64_t)hdr.n * 4 * ((int64_t)hdr.stateRows + hdr.iSlots + hdr.xSlots);
+    }
+    int saveStateColumns(uint8_t* image, const SnapshotHeader& hdr, int64_t first);
+    int loadStateColumns(const uint8_t* image, const SnapshotHeader& hdr, int64_t first);
+    // one instance's delay memory as the reference holds it (which: 0 smallDelayBuffer, 1 largeDelayBuffer), and its positions
+    int getTramAt(int which, int64_t inst, float* out, int nSlots);
+    int getCursorsAt(int64_t inst, int32_t out4[4]);
+
     int64_t instructionCounter();
     int64_t instructionCounterAt(int64_t inst);
     uint32_t oodFlags();

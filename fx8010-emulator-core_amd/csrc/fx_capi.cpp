@@ -189,6 +189,15 @@ int fxb_process_block_dev_shards(fxb_handle* h, const float* const* d_in, float*
     return h ? guardCode(&h->batch.front(), [&] { return h->batch.processDeviceShards(d_in, d_out, n); }) : FX_E_ARG;
 }
 int fxb_sync(fxb_handle* h) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.sync(); }) : FX_E_ARG; }
+int64_t fxb_state_size(fxb_handle* h) { return h ? guard(&h->batch.front(), (int64_t)FX_E_PROGRAM, [&] { return h->batch.stateBytes(); }) : FX_E_ARG; }
+int fxb_save_state(fxb_handle* h, void* buf, int64_t cap) { return h ? guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.saveState(buf, cap); }) : FX_E_ARG; }
+int fxb_load_state(fxb_handle* h, const void* buf, int64_t bytes) { return h ? guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.loadState(buf, bytes); }) : FX_E_ARG; }
+int fxb_get_tram_i(fxb_handle* h, int which, int64_t inst, float* out, int n_slots) {
+    return h ? guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.getTramAt(which, inst, out, n_slots); }) : FX_E_ARG;
+}
+int fxb_get_cursors_i(fxb_handle* h, int64_t inst, int32_t* out4) {
+    return h ? guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.getCursorsAt(inst, out4); }) : FX_E_ARG;
+}
 int64_t fxb_instruction_counter(fxb_handle* h) { return h ? guard(&h->batch.front(), (int64_t)-1, [&] { return h->batch.instructionCounter(); }) : 0; }
 int64_t fxb_instruction_counter_i(fxb_handle* h, int64_t inst) { return h ? guard(&h->batch.front(), (int64_t)0, [&] { return h->batch.instructionCounterAt(inst); }) : 0; }
 uint32_t fxb_ood_flags(fxb_handle* h) { return h ? guard(&h->batch.front(), ~0u, [&] { return h->batch.oodFlags(); }) : 0; }

@@ -1,6 +1,8 @@
 // fx_shard.cpp — fan-out / fan-in over the shards of a multi-GPU batch (see fx_shard.hpp).
 #include "fx_shard.hpp"
 
+#include <cstring>
+
 #include <algorithm>
 #include <stdexcept>
 
@@ -260,6 +262,46 @@ float Sharded::lastKernelMs() {
     float worst = -1.0f;
     for (float p : part) worst = std::max(worst, p);
     return worst;
+}
+int64_t Sharded::stateBytes() {
+    lastError_.clear();
+    Batch::SnapshotHeader hdr;
+    if (runOn(0, [&](Batch& b) { return b.snapshotShape(&hdr); }) != 0) return -1;
+    hdr.n = n_;
+    return Batch::snapshotBytes(hdr);
+}
+int Sharded::saveState(void* buf, int64_t cap) {
+    lastError_.clear();
+    Batch::SnapshotHeader hdr;
+    int rc = runOn(0, [&](Batch& b) { return b.snapshotShape(&hdr); });
+    if (rc != 0) return rc;
+    hdr.n = n_;
+    if (!buf || cap < Batch::snapshotBytes(hdr)) { lastError_ = "save_state: buffer smaller than fxb_state_size()"; return FX_E_ARG; }
+    std::memcpy(buf, &hdr, sizeof(hdr));
+    return fan([&](int k, Batch& b) { return b.saveStateColumns(static_cast<uint8_t*>(buf), hdr, shards_[(size_t)k]->first); });
+}
+int Sharded::loadState(const void* buf, int64_t bytes) {
+    lastError_.clear();
+    Batch::SnapshotHeader hdr;
+    if (!buf || bytes < (int64_t)sizeof(hdr)) { lastError_ = "load_state: no image"; return FX_E_ARG; }
+    std::memcpy(&hdr, buf, sizeof(hdr));
+    if (hdr.magic != Batch::SnapshotHeader().magic || hdr.n != n_ || bytes < Batch::snapshotBytes(hdr)) {
+        lastError_ = "load_state: not a state image of a batch of this many instances (or truncated)";
+        return FX_E_ARG;
+    }
+    return fan([&](int k, Batch& b) { return b.loadStateColumns(static_cast<const uint8_t*>(buf), hdr, shards_[(size_t)k]->first); });
+}
+int Sharded::getTramAt(int which, int64_t inst, float* out, int nSlots) {
+    lastError_.clear();
+    const int k = shardOf(inst);
+    if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
+    return runOn(k, [&](Batch& b) { return b.getTramAt(which, inst - shards_[(size_t)k]->first, out, nSlots); });
+}
+int Sharded::getCursorsAt(int64_t inst, int32_t out4[4]) {
+    lastError_.clear();
+    const int k = shardOf(inst);
+    if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
+    return runOn(k, [&](Batch& b) { return b.getCursorsAt(inst - shards_[(size_t)k]->first, out4); });
 }
 float Sharded::lastKernelMsOf(int k) {
     float ms = -1.0f;

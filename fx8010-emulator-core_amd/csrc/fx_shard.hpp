@@ -66,6 +66,14 @@ public:
     int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
     int sync();
 
+    // state snapshot of the whole batch, laid out by global instance (fx_batch.hpp SnapshotHeader): an image saved from one
+    // partition loads into any other with the same program and instance count
+    int64_t stateBytes();
+    int saveState(void* buf, int64_t cap);
+    int loadState(const void* buf, int64_t bytes);
+    int getTramAt(int which, int64_t inst, float* out, int nSlots);
+    int getCursorsAt(int64_t inst, int32_t out4[4]);
+
     int64_t instructionCounter();
     int64_t instructionCounterAt(int64_t inst);
     uint32_t oodFlags();

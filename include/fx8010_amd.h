@@ -164,6 +164,22 @@ int fxb_set_register_track(fxb_handle* h, const char* key, const float* values, 
 /* white-noise generator seeds of one instance (reference: g_x1/g_x2, include/FX8010.h:290-291;
  * every instance starts with the reference's seeds) */
 int fxb_seed_noise_i(fxb_handle* h, int64_t instance, int32_t x1, int32_t x2);
+/* State snapshot.  The reference keeps all DSP state in plain members (include/FX8010.h:162-217, 288-291: register values, output
+ * latches, smallDelayBuffer / largeDelayBuffer and their four positions, the LFSR words, the instruction counter); a batch's
+ * state is the same per instance.  fxb_save_state writes fxb_state_size(h) bytes: a 64-byte header, then - by GLOBAL instance -
+ * the state rows [row][instance], iTRAM [instance][slot] and xTRAM [instance][slot] (slots: as many as the program can reach).
+ * fxb_load_state takes such an image into a batch of the same instance count with the same program loaded, whatever its
+ * partition into shards (a sharded handle can be re-partitioned: save, destroy, create on other devices, load); the registers'
+ * host side follows the image (a register every instance holds one value of counts as a broadcast write of that value).
+ * Synchronous; 0 or FX_E_*.  Sizes: config5's 262 144 instances carry 8 GiB of xTRAM. */
+int64_t fxb_state_size(fxb_handle* h);
+int fxb_save_state(fxb_handle* h, void* buf, int64_t cap);
+int fxb_load_state(fxb_handle* h, const void* buf, int64_t bytes);
+/* one instance's delay memory as the reference holds it (which: 0 = smallDelayBuffer / iTRAM, 1 = largeDelayBuffer / xTRAM; the first
+ * n_slots words; words the program cannot reach read 0) and its positions {iTRAM write, iTRAM read, xTRAM write, xTRAM read}
+ * (reference smallDelayWritePos ... largeDelayReadPos, include/FX8010.h:214-217) */
+int fxb_get_tram_i(fxb_handle* h, int which, int64_t instance, float* out, int n_slots);
+int fxb_get_cursors_i(fxb_handle* h, int64_t instance, int32_t* out4);
 /* S sample periods for all N instances.  Host buffers: synchronous (returns with `out` filled).  Blocks of a few KB are read
  * and written by the kernel in pinned memory of the library (no staged copies); blocks of >= 32 MB are copied in, processed and
  * copied out in overlapping pieces (fastest from pinned caller buffers: both DMA directions at once); everything else is H2D,

@@ -697,6 +697,16 @@ int fxo_channels(fxo_t* f) { return f->channels; }
 unsigned fxo_ood_flags(fxo_t* f) { return f->ood; }
 void fxo_set_option(fxo_t* f, unsigned option, int on) { if (on) f->opts |= option; else f->opts &= ~option; }
 void fxo_seed_noise(fxo_t* f, int32_t x1, int32_t x2) { f->g_x1 = x1; f->g_x2 = x2; }
+/* the members a test cannot reach through outputs alone (FX8010.h:210-217, 290-291): delay memory, cursors, LFSR words */
+int fxo_tram(fxo_t* f, int which, float* out, int n) {
+    const float* buf = which ? f->xtram : f->itram;
+    const int have = which ? MAX_XDELAY_SIZE : MAX_IDELAY_SIZE;
+    if (n > have) n = have;
+    for (int k = 0; k < n; ++k) out[k] = buf ? buf[k] : 0.0f;   /* (xTRAM is allocated on first use: all zero until then) */
+    return n;
+}
+void fxo_cursors(fxo_t* f, int out4[4]) { out4[0] = f->iw; out4[1] = f->ir; out4[2] = f->xw; out4[3] = f->xr; }
+void fxo_lfsr(fxo_t* f, int32_t out2[2]) { out2[0] = f->g_x1; out2[1] = f->g_x2; }
 int fxo_error_count(fxo_t* f) { return f->nerrs; }
 const char* fxo_error_desc(fxo_t* f, int i) { return (i < 0 || i >= f->nerrs) ? "" : f->errs[i].desc; }
 int fxo_error_row(fxo_t* f, int i) { return (i < 0 || i >= f->nerrs) ? -1 : f->errs[i].row; }

@@ -49,6 +49,11 @@ int fxo_channels(fxo_t*);
 unsigned fxo_ood_flags(fxo_t*);
 void fxo_seed_noise(fxo_t*, int32_t x1, int32_t x2);
 void fxo_set_option(fxo_t*, unsigned option, int on);   /* before loading: FXO_OPT_* */
+/* state a test cannot see through outputs alone: delay memory (which: 0 smallDelayBuffer, 1 largeDelayBuffer; first n words),
+ * the four positions {iTRAM write, iTRAM read, xTRAM write, xTRAM read}, the LFSR words {g_x1, g_x2} */
+int fxo_tram(fxo_t*, int which, float* out, int n);
+void fxo_cursors(fxo_t*, int out4[4]);
+void fxo_lfsr(fxo_t*, int32_t out2[2]);
 
 int fxo_error_count(fxo_t*);
 const char* fxo_error_desc(fxo_t*, int i);

@@ -193,6 +193,12 @@ class Oracle(_Base):
             lib.fxo_xtram_size.argtypes = [C.c_void_p]
             lib.fxo_lut.argtypes = [C.c_void_p, C.c_int, C.c_int]
             lib.fxo_lut.restype = C.POINTER(C.c_double)
+            lib.fxo_tram.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            lib.fxo_tram.restype = C.c_int
+            lib.fxo_cursors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            lib.fxo_cursors.restype = None
+            lib.fxo_lfsr.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+            lib.fxo_lfsr.restype = None
             cls._lib = lib
         return cls._lib
 
@@ -213,6 +219,24 @@ class Oracle(_Base):
 
     def seed_noise(self, x1, x2):
         self._lib.fxo_seed_noise(self._h, C.c_int32(x1), C.c_int32(x2))
+
+    def tram(self, which, n):
+        """first n words of the delay memory (0: smallDelayBuffer, 1: largeDelayBuffer) as float32"""
+        out = np.zeros(n, dtype=np.float32)
+        self._lib.fxo_tram.restype = C.c_int
+        got = self._lib.fxo_tram(self._h, int(which), out.ctypes.data_as(C.c_void_p), int(n))
+        return out[:got]
+
+    def cursors(self):
+        """[iTRAM write, iTRAM read, xTRAM write, xTRAM read] positions"""
+        buf = (C.c_int * 4)()
+        self._lib.fxo_cursors(self._h, buf)
+        return list(buf)
+
+    def lfsr(self):
+        buf = (C.c_int32 * 2)()
+        self._lib.fxo_lfsr(self._h, buf)
+        return [int(buf[0]), int(buf[1])]
 
     def registers(self):
         n = self._lib.fxo_num_registers(self._h)

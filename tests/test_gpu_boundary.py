@@ -497,3 +497,105 @@ def test_large_host_block_in_pinned_buffers_is_processed_in_overlapping_pieces(g
         ref = o.process_block(x[:40, inst].copy())
         assert np.array_equal(bits(ref), bits(yb[:, inst])), inst
         assert b.instruction_counter_i(inst) == o.instruction_counter()
+
+
+def test_delay_memory_positions_and_lfsr_against_the_oracle(gpu):
+    """the state a caller cannot see through outputs (reference include/FX8010.h:210-217, 290-291), read back and compared with
+    the oracle's directly: config5's delay line word for word after it has wrapped (2 100 samples: first read-back at 2048),
+    config3's 1000-slot line after two wraps, the four positions, the LFSR words of a noise program"""
+    for name, S, which, words in (("config5", 2100, 1, 8192), ("config3", 2300, 0, 1000)):
+        text = progs.CONFIGS[name]()
+        N = 70
+        x = progs.stimulus(N, S)
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        cuts = [0, 600, 601, 2047, S]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            b.process_block(x[lo:hi])
+        for n in (0, 63, 64, N - 1):
+            o = Oracle(1)
+            assert o.load_text(text)
+            o.process_block(x[:, n].copy())
+            assert np.array_equal(bits(b.get_tram_i(which, n, words)), bits(o.tram(which, words))), (name, n)
+            assert b.get_cursors_i(n) == o.cursors(), (name, n)
+            assert not np.any(b.get_tram_i(1 - which, n, 16))   # the other delay memory: untouched
+    text = ("itramsize 6 \nstatic noise\nstatic rd\nstatic a\ninput in 0\noutput out 0\nidelay read, rd, at, 0\nmacs a, in, noise, 0.5\n"
+            "idelay write, a, at, 2\nmacs out, rd, noise, 0.25\nend")
+    N, S = 130, 77
+    x = progs.stimulus(N, S)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    for n in range(N):
+        b.seed_noise_i(n, 99 + n, -5 * n)
+    b.process_block(x[:40])
+    b.process_block(x[40:])
+    img = b.save_state()
+    hdr = np.frombuffer(img[:64].tobytes(), dtype=np.int32)
+    rows = img[64:64 + int(hdr[6]) * N * 4].view(np.uint32).reshape(int(hdr[6]), N)   # (state rows of the image: [row][instance])
+    for n in (0, 64, N - 1):
+        o = Oracle(1)
+        assert o.load_text(text)
+        o.seed_noise(99 + n, -5 * n)
+        o.process_block(x[:, n].copy())
+        assert np.array_equal(bits(b.get_tram_i(0, n, 8192)), bits(o.tram(0, 8192))), n   # (writes at position + 2: beyond itramsize, inside the reference's array)
+        assert b.get_cursors_i(n) == o.cursors()
+        nregs = int(hdr[5])
+        lfsr = [int(v) for v in rows[nregs + 1 + 4: nregs + 1 + 6, n].view(np.int32)]     # latches (1 channel), 4 positions, then g_x1, g_x2
+        assert lfsr == o.lfsr(), n
+
+
+@pytest.mark.parametrize("name", ["config5", "config4", "config2"])
+def test_state_snapshot_round_trip_and_repartition(gpu, name):
+    """fxb_save_state / fxb_load_state: a batch is stopped in the middle of a run, its image loaded into a NEW handle - one
+    shard, and three shards (an image is laid out by global instance: a sharded handle can be re-partitioned) - and both carry
+    on exactly like the batch that was never stopped: outputs, registers, counters, delay memory; per-instance register values
+    and a moved control travel with the image"""
+    text = progs.CONFIGS[name]()
+    N, S = 333, 2200 if name == "config5" else 120
+    x = progs.stimulus(N, S + 60)
+    key = {"config5": "u", "config4": "o", "config2": "s7"}[name]
+    ctl = {"config5": "decay", "config4": "cutoff", "config2": "cutoff"}[name]
+    a = gpu.Batch(N, 1, 0)
+    assert a.load_text(text), a.errors()
+    a.process_block(x[:S // 2])
+    a.set_register_i(key, 200, 0.3125)
+    a.set_register(ctl, 0.4)
+    a.process_block(x[S // 2:S])
+    img = a.save_state()
+    ya = a.process_block(x[S:])
+    one = gpu.Batch(N, 1, 0)
+    three = gpu.Batch(N, 1, devices=[0, 0, 0])
+    for h in (one, three):
+        assert h.load_text(text)
+        h.load_state(img)
+        assert h.get_register_i(ctl, 5) == np.float32(0.4)
+        y = h.process_block(x[S:])
+        assert np.array_equal(bits(y), bits(ya)), name
+        assert h.instruction_counter() == a.instruction_counter()
+        for n in (0, 63, 64, 200, N - 1):
+            assert h.instruction_counter_i(n) == a.instruction_counter_i(n)
+            for r in (key, ctl, "out", "ccr"):
+                assert h.get_register_bits_i(r, n) == a.get_register_bits_i(r, n), (r, n)
+            if name == "config5":
+                assert np.array_equal(bits(h.get_tram_i(1, n, 8192)), bits(a.get_tram_i(1, n, 8192)))
+                assert h.get_cursors_i(n) == a.get_cursors_i(n)
+        assert h.ood_flags() == 0
+    # ... and the image of the re-partitioned handle is the image of the single one
+    assert np.array_equal(one.save_state(), three.save_state())
+    # against the oracle: the instance that was given a value of its own
+    o = Oracle(1)
+    assert o.load_text(text)
+    o.process_block(x[:S // 2, 200].copy())
+    o.set_register(key, 0.3125)
+    o.set_register(ctl, 0.4)
+    ref = o.process_block(x[S // 2:, 200].copy())[S - S // 2:]
+    assert np.array_equal(bits(ref), bits(ya[:, 200]))
+    # an image of another program or another batch size is refused
+    other = gpu.Batch(N, 1, 0)
+    assert other.load_text(progs.config3())
+    with pytest.raises(RuntimeError):
+        other.load_state(img)
+    small = gpu.Batch(N - 1, 1, 0)
+    assert small.load_text(text)
+    with pytest.raises(RuntimeError):
+        small.load_state(img)
