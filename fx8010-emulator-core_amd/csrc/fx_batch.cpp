@@ -11,6 +11,7 @@
 // stream); their state rows are refreshed when they turn per-instance.
 #include "fx_batch.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -126,6 +127,7 @@ int Batch::afterLoad(bool ok) {
     ++loadGen_;
     wantedClass_ = -1;
     otherClassBlocks_ = 0;
+    for (Tuner& t : tune_) t = Tuner();
     // registers the program itself keeps per-instance (it writes them, reads them from a delay line or the PCM input): a
     // property of the program, valid until the next load
     intrinsicLane_.assign(prog_.regs.size(), 0);
@@ -256,17 +258,87 @@ bool Batch::laneResident(int reg) const {
     return !lowDirty_ ? c_.low.rowOfReg[reg] >= 0 : (reg < (int)c_.low.rowOfReg.size() && c_.low.rowOfReg[reg] >= 0);
 }
 
-// How many pipeline stages to ask the translator for; FX_STAGES pins the number (1 = never).  Measured with config2's filter
-// chain at S = 2048 (tools/stage_probe.py, profiles/r03b_stage_policy.txt): 8 stages are worth x 3.1 / 2.7 / 1.7 at 16 / 256 / 512
-// wavefronts of instances (up to two groups per CU), 4 stages + 30 % / + 8 % / + 7 % at 768 / 1 024 / 1 536 (one wavefront per SIMD
-// becomes four, but every stage adds ~11 instructions per sample), and from 1 792 wavefronts on the plain program is faster.
-int Batch::stagesWanted(int variant) const {
-    if (const char* knob = std::getenv("FX_STAGES")) return std::max(1, std::min(16, std::atoi(knob)));
-    (void)variant;
-    const int64_t waves = (n_ + 63) / 64;
-    if (waves <= 512) return 8;
-    if (waves <= 1536) return 4;
-    return 1;
+// Small batches leave SIMDs empty (and a lone wavefront issues an instruction only every ~4 clocks): a program that can be cut
+// runs as a pipeline of stages over the wavefronts of a workgroup (fx_xlate.hpp StageInfo).  Beyond two wavefronts of instances
+// per SIMD the plain program has always been the faster one.  FX_STAGES pins the number asked for (1 = never).
+bool Batch::stagingPossible() const {
+    if (const char* knob = std::getenv("FX_STAGES")) return std::atoi(knob) >= 2;
+    return (n_ + 63) / 64 < 2048;
+}
+
+// How many stages?  The planner's own costs decide (planStages: cost of every stage, pipeline overhead included, in units of
+// ~1.4 per vector instruction), with a model of the machine calibrated on tools/stage_policy_probe.sh (profiles/r04_stage_policy*.txt:
+// the filter chain, twelve parallel chains with 13-row packets, a delay line + SKIP + LOG / EXP program; 16 .. 2 048 wavefronts):
+//   a wavefront alone:   L = 2.85 clocks x cost of the slowest stage + 165 (loop control, PCM) + 100 per LOG / EXP round trip
+//                            + 5 per row its packets carry + the barrier: (100 + 15 K) clocks x 1 / 0.42 / 0.1 / 0 per sample for one
+//                            every 1 / 2 / 4 / 8 samples (tools/stage_block_probe.py, profiles/r04_stage_block_probe.txt)
+//   the CU's issue slots: G workgroups per CU x 2.4 clocks x the cost of ALL stages / (4 SIMDs x 0.8) - for K < 4 the wavefronts of
+//                            the G workgroups can pile up on K SIMDs of the CU (as many as the VGPR build lets a SIMD hold)
+//   a sample takes the larger of the two; a block also fills and drains the pipeline: 3 (K - 1) steps of `group` samples.
+// The options come back cheapest first.  The model is good to ~ 20 % (how the dispatcher spreads workgroups over the CUs is not
+// in it), so options within kTuneBand of the best are MEASURED on the caller's own blocks before one is kept (noteLaunchTime).
+std::vector<Batch::StageOption> Batch::rankStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
+                                                  const XlateProgram& xprog, int nRows, int blockClass, int wavesPerSimdCap) const {
+    std::vector<StageOption> out;
+    if (const char* knob = std::getenv("FX_STAGES")) {
+        StageOption o;
+        o.wanted = std::max(1, std::min(16, std::atoi(knob)));
+        out.push_back(o);
+        return out;
+    }
+    const double W = (double)((n_ + 63) / 64);
+    const int64_t groupsPerCu = std::max<int64_t>(1, ((n_ + 63) / 64 + 255) / 256);
+    const uint32_t ldsBudget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(144 * 1024, 160 * 1024 / groupsPerCu - 256));
+    const int maxGroup = blockClass == 0 ? 1 : (blockClass == 1 ? 2 : kStageGroupMax);
+    const double blockSamples = blockClass == 0 ? 32.0 : (blockClass == 1 ? 128.0 : 2048.0);
+    const double kClocksPerCost = 2.85, kIssuePerCost = 2.4, kFixed = 165.0, kLut = 100.0, kEta = 0.8;
+    StageOption plain;
+    bool havePlain = false;
+    std::vector<int> seen;
+    for (int wanted : {8, 4, 2}) {
+        if (!stagingPossible()) break;
+        const StagePlan plan = planStages(steadyRecords, lastRecords, xprog, nRows, wanted);
+        if (!havePlain && plan.totalCost > 0) {
+            plain.wanted = plain.stages = 1;
+            const double lone = kClocksPerCost * plan.totalCost + kFixed + kLut * plan.totalLuts;
+            const double shared = std::ceil(W / 1024.0) * kIssuePerCost * plan.totalCost / kEta;
+            plain.predicted = std::max(lone, shared);
+            havePlain = true;
+        }
+        if (plan.cuts.empty()) continue;
+        const int k = (int)plan.cuts.size() + 1;
+        if (std::find(seen.begin(), seen.end(), k) != seen.end()) continue;
+        seen.push_back(k);
+        StageLds lds;
+        if (!stageLdsLayout(xprog, plan, ldsBudget, maxGroup, &lds)) continue;
+        int worst = 0, luts = 0, sum = 0;
+        for (size_t s = 0; s < plan.stageCost.size(); ++s) {
+            worst = std::max(worst, plan.stageCost[s]);
+            luts = std::max(luts, plan.stageLuts[s]);
+            sum += plan.stageCost[s];
+        }
+        size_t rows = 0;
+        for (size_t c2 = 0; c2 < plan.live.size(); ++c2) rows = std::max(rows, plan.live[c2].size() + (c2 + 1 < plan.live.size() ? plan.live[c2 + 1].size() : 0));
+        const double barrier = (100.0 + 15.0 * k) * (lds.group >= 8 ? 0.0 : (lds.group == 4 ? 0.1 : (lds.group == 2 ? 0.42 : 1.0)));
+        const double lone = kClocksPerCost * worst + kFixed + kLut * luts + 5.0 * (double)rows + barrier;
+        const double G = std::ceil(W / 256.0);
+        double shared = G * kIssuePerCost * sum / (4.0 * kEta);
+        // (K < 4: measured between an even spread and a pile-up of the G workgroups' wavefronts on K SIMDs - the filter chain and the
+        // parallel chains in two stages sit near the pile-up, the delay-line program near the even spread: the geometric mean)
+        if (k < 4) {
+            const double piled = std::min(G, (double)wavesPerSimdCap) * kIssuePerCost * worst / kEta;
+            if (piled > std::max(shared, lone)) shared = std::sqrt(std::max(shared, lone) * piled);
+        }
+        StageOption o;
+        o.wanted = wanted;
+        o.stages = k;
+        o.group = lds.group;
+        o.predicted = std::max(lone, shared) * (1.0 + 3.0 * (k - 1) * lds.group / blockSamples);
+        out.push_back(o);
+    }
+    if (havePlain || out.empty()) out.push_back(plain);
+    std::stable_sort(out.begin(), out.end(), [](const StageOption& a, const StageOption& b2) { return a.predicted < b2.predicted; });
+    return out;
 }
 
 // What the generated code is a function of.  Two calls with equal keys would build the same Code, so a finished one is reused
@@ -274,12 +346,12 @@ int Batch::stagesWanted(int variant) const {
 // have rows although no instruction writes them (per-instance values, moving controls, control tracks), the values of all the
 // others (they are folded into the code as literals), the block-length class staged code is generated for, whether the
 // translation is put off because compiled-in controls keep changing, and the diagnostic knobs of the environment.
-std::string Batch::codeKey(int blockClass, bool defer) const { return codeKeyFor(laneForced(), blockClass, defer); }
+std::string Batch::codeKey(int blockClass, bool defer) const { return codeKeyFor(laneForced(), blockClass, defer, pickFor(blockClass)); }
 
-std::string Batch::codeKeyFor(const std::vector<uint8_t>& forced, int blockClass, bool defer) const {
+std::string Batch::codeKeyFor(const std::vector<uint8_t>& forced, int blockClass, bool defer, int pick) const {
     std::string k;
     auto word = [&](int64_t v) { k.append(reinterpret_cast<const char*>(&v), 8); };
-    word(loadGen_); word((int64_t)prog_.options); word(blockClass); word(defer ? 1 : 0); word(daneHipOnly_ ? 1 : 0);
+    word(loadGen_); word((int64_t)prog_.options); word(blockClass); word(pick); word(defer ? 1 : 0); word(daneHipOnly_ ? 1 : 0);
     word(((iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0) && instPerLane_ != 1) ? instPerLane_ : 0);   // delay lines tiled for K instances per lane pin the HIP C++ kernel
     for (const char* name : {"FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_STAGES_GROUP"}) {
         const char* v = std::getenv(name);
@@ -354,7 +426,7 @@ bool Batch::adoptCode(const std::string& key) {
 
 // staged code is generated for a class of block lengths - when the batch is small enough to be staged at all
 int Batch::keyClass() const {
-    if (stagesWanted(0) < 2) return -1;
+    if (!stagingPossible()) return -1;
     return wantedClass_ >= 0 ? wantedClass_ : stageBlockClass(std::max(pendingSamples_, 1));
 }
 
@@ -388,6 +460,7 @@ int Batch::ensureLowered() {
     if (have) {   // code for this shape exists: a pointer swap
         ++cacheHits_;
         lowDirty_ = false;
+        adoptStageOptions();
         prebuildControlVariant();
         return 0;
     }
@@ -399,8 +472,90 @@ int Batch::ensureLowered() {
     }
     if (rc != 0) return fail(rc, err);
     lowDirty_ = false;
+    adoptStageOptions();
     prebuildControlVariant();
     return 0;
+}
+
+// The code in force came with the planner's ranking of the stage counts (Code::stageOptions).  The first code of a class of
+// block lengths starts that class's tuner: the options the model cannot tell apart (within kTuneBand of the cheapest, three at
+// most) are generated on the builder thread and then timed on the caller's own launches, kTuneRuns each (noteLaunchTime); the
+// fastest is kept.  FX_STAGES_TUNE=0 (or no builder thread): the model's choice stands.
+void Batch::adoptStageOptions() {
+    const int cls = c_.blockClass;
+    if (cls < 0 || cls >= 3 || !c_.useXlate || keyClass() != cls) return;
+    Tuner& t = tune_[cls];
+    if (t.init) return;
+    t = Tuner();
+    t.init = true;
+    t.pick = c_.stagePick;
+    // (built for "the cheapest": from now on the code goes by the stage count it was built for)
+    c_.key = codeKeyFor(laneForced(), cls, c_.deferred, t.pick);
+    static const bool tuneOff = std::getenv("FX_STAGES_TUNE") && std::atoi(std::getenv("FX_STAGES_TUNE")) == 0;
+    if (c_.stageOptions.empty() || std::getenv("FX_STAGES")) { t.done = true; return; }
+    const double best = c_.stageOptions.front().predicted;
+    for (const StageOption& o : c_.stageOptions)
+        if (t.options.size() < 3 && (t.options.empty() || o.predicted <= best * kTuneBand)) t.options.push_back(o);
+    bool mine = false;
+    for (const StageOption& o : t.options) mine = mine || o.wanted == t.pick;
+    if (!mine || t.options.size() < 2 || tuneOff || !builderWanted()) { t.options.clear(); t.done = true; return; }
+    t.bestNs.assign(t.options.size(), 0.0f);
+    t.runs.assign(t.options.size(), 0);
+    for (const StageOption& o : t.options) {
+        if (o.wanted == t.pick) continue;
+        BuildInputs in = buildInputs(codeKeyFor(laneForced(), cls, false, o.wanted), cls, false);
+        in.stagePick = o.wanted;
+        requestBuild(std::move(in));
+    }
+}
+
+// Called at the head of a process call: what the previous launch took goes to the tuner of its class, and the tuner decides what
+// the next launch runs - the same option again (kTuneRuns launches each), the next one whose code the builder has finished, or,
+// when every option has been timed, the fastest for good.  All options compute the same words: a trial costs time, never bits.
+void Batch::noteLaunchTime() {
+    const int cls = lastLaunchClass_;
+    if (cls < 0 || cls >= 3) return;
+    Tuner& t = tune_[cls];
+    if (!t.init || t.done) return;
+    if (lastLaunchTimed_ && launched_ && hipEventQuery(ev1_) == hipSuccess) {
+        lastLaunchTimed_ = false;
+        float ms = -1.0f;
+        if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess && ms > 0.0f && lastLaunchSamples_ >= kTuneMinSamples)
+            for (size_t k = 0; k < t.options.size(); ++k)
+                if (t.options[k].wanted == lastLaunchPick_) {
+                    const float ns = ms * 1e6f / (float)lastLaunchSamples_;
+                    t.bestNs[k] = t.runs[k] == 0 ? ns : std::min(t.bestNs[k], ns);
+                    ++t.runs[k];
+                    ++t.trials;
+                }
+    }
+    if (lowDirty_ || keyClass() != cls) return;
+    size_t cur = 0;
+    while (cur < t.options.size() && t.options[cur].wanted != t.pick) ++cur;
+    if (cur == t.options.size() || t.runs[cur] < kTuneRuns) return;
+    collectBuilt();
+    bool waiting = false;
+    for (size_t k = 0; k < t.options.size(); ++k) {
+        if (t.runs[k] >= kTuneRuns) continue;
+        const std::string key = codeKeyFor(laneForced(), cls, false, t.options[k].wanted);
+        if (cachedCode(key)) {   // its turn
+            t.pick = t.options[k].wanted;
+            lowDirty_ = true;
+            return;
+        }
+        waiting = waiting || buildPending(key);   // (neither there nor on its way: the builder could not make it - out of the race)
+    }
+    if (waiting) return;
+    size_t bestK = cur;
+    for (size_t k = 0; k < t.options.size(); ++k)
+        if (t.runs[k] >= kTuneRuns && t.bestNs[k] < t.bestNs[bestK]) bestK = k;
+    t.done = true;
+    if (t.options[bestK].wanted != t.pick) {
+        t.pick = t.options[bestK].wanted;
+        lowDirty_ = true;
+    } else {
+        prebuildControlVariant();
+    }
 }
 
 // ---- the builder thread: code generated off the caller's thread -------------------------------------------------------------
@@ -532,6 +687,7 @@ void Batch::drainBuilder(bool stop) {
 
 void Batch::prebuildControlVariant() {
     if (controlMode_ || c_.key.empty() || !c_.useXlate || !builderWanted()) return;
+    if (c_.blockClass >= 0 && c_.blockClass < 3 && tune_[c_.blockClass].init && !tune_[c_.blockClass].done) return;   // (stage counts are still on trial: once one is kept)
     std::vector<uint8_t> forced = laneForced();
     bool any = false;
     for (const std::string& name : prog_.controls) {
@@ -542,7 +698,7 @@ void Batch::prebuildControlVariant() {
     }
     if (!any) return;
     const int blockClass = keyClass();
-    BuildInputs in = buildInputs(codeKeyFor(forced, blockClass, false), blockClass, false);
+    BuildInputs in = buildInputs(codeKeyFor(forced, blockClass, false, pickFor(blockClass)), blockClass, false);
     if (cachedCode(in.key)) return;
     in.forced = forced;
     requestBuild(std::move(in));
@@ -556,6 +712,7 @@ Batch::BuildInputs Batch::buildInputs(const std::string& key, int blockClass, bo
     in.hostValue = hostValue_;
     in.forced = laneForced();
     in.trackRegs = trackRegs_;
+    in.stagePick = pickFor(blockClass);
     return in;
 }
 
@@ -596,7 +753,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
                 }
                 // a small batch is cut into stages (below): each stage wants spare registers for its packets and its input
                 // bursts, and at most 4 wavefronts per SIMD will be resident anyway - the 128-register build costs nothing
-                if (stagesWanted(v) >= 2)
+                if (stagingPossible())
                     while (v < ASM_V128) ++v;
                 const char* pin = forceHip ? std::strstr(forceHip, "_v") : nullptr;
                 if (pin && (std::strncmp(forceHip, "asm_v", 5) == 0 || std::strncmp(forceHip, "xlate_v", 7) == 0)) {
@@ -665,12 +822,15 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
         // Small batches leave SIMDs empty (and a lone wavefront issues an instruction every ~4.5 clocks): cut the program
         // into stages run by the wavefronts of one workgroup (fx_xlate.hpp StageInfo) until ~4 wavefronts per SIMD are in
         // flight.  FX_STAGES pins the number asked for (1 = never).
-        int wantStages = stagesWanted((int)c.variant);
+        // how many stages: the caller's pick (a measured one, or an option on trial), else the cheapest by the planner's costs
+        c.stageOptions = tmpl ? rankStages(steadyRecords, lastRecords, xprog, c.low.nRows, blockClass, kAsmWavesPerSimd[c.variant]) : std::vector<StageOption>();
+        int wantStages = in.stagePick > 0 ? in.stagePick : (c.stageOptions.empty() ? 1 : c.stageOptions.front().wanted);
+        c.stagePick = wantStages;
         // Measured with config2 at 4 096 instances (profiles/r03b_stage_blocks.txt): a block of 32 samples takes 27 us unstaged, 32 us
         // in 8 stages with a barrier every 8 samples (3 x 7 steps of 8 samples to fill and drain) and 21 us in 4 stages with a
         // barrier per sample; 128 samples 69 / 48 / 40 us (8 stages, every 2 samples); from 256 samples on the long steps win
+        // (rankStages charges a block of the class's typical length with the 3 (K - 1) steps of filling and draining)
         const int maxGroup = blockClass == 0 ? 1 : (blockClass == 1 ? 2 : kStageGroupMax);
-        if (blockClass == 0 && !std::getenv("FX_STAGES")) wantStages = std::min(wantStages, 4);
         c.blockClass = blockClass;
         c.stagesWhyNot.clear();
         if (tmpl && wantStages >= 2) {
@@ -1094,6 +1254,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     if (!piecewise_) {   // (a piece of a pipelined host block: done once for the whole block)
         pendingSamples_ = nSamples;
         if (controlHeat_ > 0 && --controlHeat_ == 0 && c_.deferred) lowDirty_ = true;  // quiet again: translate
+        noteLaunchTime();
         noteBlockLength(nSamples);
     }
     int rc = ensureLowered();
@@ -1183,6 +1344,10 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
     if (e != hipSuccess) return hipFail(e, "launch fx_step_block");
     launched_ = !untimed_;  // (an untimed launch is synchronised by its caller before anything else happens)
     timed_ = !untimed_;
+    lastLaunchTimed_ = !untimed_ && !piecewise_;
+    lastLaunchPick_ = c_.stagePick;
+    lastLaunchSamples_ = nSamples;
+    lastLaunchClass_ = c_.useXlate ? c_.blockClass : -1;
     lastGrid_ = (unsigned)((n_ + 64 * instPerLane_ - 1) / (64 * instPerLane_));
     return 0;
 }
@@ -1553,6 +1718,7 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_CALLED: return c_.useXlate ? c_.called : 0;
         case FXB_INFO_XLATE_BUILDS: return xlateBuilds_;
         case FXB_INFO_XLATE_BACKGROUND_BUILDS: return backgroundBuilds_;
+        case FXB_INFO_STAGE_TRIALS: { int64_t n = 0; for (const Tuner& t : tune_) n += t.trials; return n; }
         case FXB_INFO_XLATE_CODE_HASH: return c_.useXlate ? (int64_t)c_.codeHash : 0;
         case FXB_INFO_CODE_CACHE_HITS: return cacheHits_;
         case FXB_INFO_CODE_CACHED: return (int64_t)cache_.size() + (c_.key.empty() ? 0 : 1);

@@ -124,6 +124,7 @@ private:
     int iSlotsAlloc_ = 0, xSlotsAlloc_ = 0;
     int instPerLane_ = 1;
 
+    struct StageOption { int wanted = 1, stages = 1, group = 0; double predicted = 0.0; };   // wanted: what planStages is asked for (1: the plain program)
     // Everything a lowering produces - the lowered streams, the tier that runs them, the loaded code object of a translated
     // program and the device copy of its tables.  It is a pure function of a KEY (codeKey(): the program, the values folded
     // into the code, which registers have rows, the number of stages and the block-length class), so finished ones are
@@ -148,6 +149,8 @@ private:
         std::vector<StageDescriptor> stageDesc;
         std::vector<std::vector<int>> stageStoreRows;
         std::string stagesWhyNot;
+        std::vector<StageOption> stageOptions;   // what rankStages made of the program (cheapest first)
+        int stagePick = 1;                       // ... and the one this code was built for
         int inlined = 0, called = 0, unsaturated = 0, valu = 0, valuSlow = 0, valuClocks = 0, vgprConstants = 0;
         std::vector<uint8_t> wildRow;
         std::string xlateWhyNot;
@@ -163,7 +166,7 @@ private:
     int loadGen_ = 0;
     int cacheHits_ = 0;
     std::string codeKey(int blockClass, bool defer) const;
-    std::string codeKeyFor(const std::vector<uint8_t>& forced, int blockClass, bool defer) const;
+    std::string codeKeyFor(const std::vector<uint8_t>& forced, int blockClass, bool defer, int pick) const;
     struct Builder;                              // the thread that generates code off the caller's thread (fx_batch.cpp)
     std::unique_ptr<Builder> builder_;
     struct BuildInputs;
@@ -189,6 +192,7 @@ private:
         std::vector<float> hostValue;
         std::vector<uint8_t> forced;             // laneForced()
         std::vector<int> trackRegs;
+        int stagePick = 0;                       // stages to ask the planner for; 0: the cheapest by its costs (rankStages)
     };
     BuildInputs buildInputs(const std::string& key, int blockClass, bool defer) const;
     static constexpr int FX_E_RETRY_ = -1000;    // internal: build again (the key has changed)
@@ -200,7 +204,26 @@ private:
     std::vector<uint8_t> intrinsicLane_, readByProgram_;   // per register, as of the last load
     bool controlMode_ = false;                   // the declared controls have rows (the host has moved one)
 
-    int stagesWanted(int variant) const;
+    // ---- how many stages (rankStages: the planner's costs; noteLaunchTime: options the model cannot tell apart are measured)
+    bool stagingPossible() const;
+    std::vector<StageOption> rankStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& xprog,
+                                        int nRows, int blockClass, int wavesPerSimdCap) const;
+    static constexpr double kTuneBand = 1.6;     // options predicted within this factor of the cheapest are tried
+    static constexpr int kTuneRuns = 3, kTuneMinSamples = 8;
+    struct Tuner {
+        bool init = false, done = false;
+        std::vector<StageOption> options;        // on trial (the model's cheapest first)
+        std::vector<float> bestNs;               // per option: the fastest launch seen, ns per sample
+        std::vector<int> runs;
+        int pick = 0;                            // StageOption::wanted in force; 0: nothing built yet (the build picks the model's cheapest)
+        int trials = 0;
+    };
+    Tuner tune_[3];                              // per block-length class
+    int pickFor(int blockClass) const { return (blockClass >= 0 && blockClass < 3) ? tune_[blockClass].pick : 0; }
+    void adoptStageOptions();                    // after a build / an adoption: the options the code came with start the class's tuner
+    void noteLaunchTime();                       // the previous launch's time -> the tuner; move to the next option / settle
+    int lastLaunchPick_ = 0, lastLaunchSamples_ = 0, lastLaunchClass_ = -1;
+    bool lastLaunchTimed_ = false;
     bool movableControl(int reg) const;
     bool piecewise_ = false;   // processDevice is being called for the pieces of one pipelined host block
     int xlateBuilds_ = 0;                    // translations on the caller's thread since the handle was created

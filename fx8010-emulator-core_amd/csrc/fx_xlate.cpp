@@ -3079,13 +3079,37 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
         }
         std::reverse(cuts.begin(), cuts.end());
     }
+    P.totalCost = total;
+    for (size_t i = 0; i < n; ++i) P.totalLuts += steadyRecords[i].w[0] == AS_LUT ? 1 : 0;
     if (std::getenv("FX_STAGES_DEBUG")) {
         std::string line;
         for (size_t b = 0; b <= n; ++b) line += allowed[b] ? '+' : '.';
         std::fprintf(stderr, "planStages: %zu records, total cost %d, boundaries %s\n", n, total, line.c_str());
     }
+    P.totalCost = total;
     if (cuts.empty()) return no("no legal cut");
     P.cuts = cuts;
+    {   // what the plan expects each stage to cost (the units of costOf: roughly vector instructions), pipeline overhead included
+        size_t lo = 0;
+        std::vector<size_t> edges{0};
+        for (int b : cuts) edges.push_back((size_t)b);
+        edges.push_back(n);
+        for (size_t k = 0; k + 1 < edges.size(); ++k) {
+            int c = cum[edges[k + 1]] - cum[edges[k]] + kFixedCost;
+            if (edges[k] == 0) c += kInputCost; else c += kRecvCost * (int)liveAt[edges[k]].size();
+            if (edges[k + 1] == n) c += kOutputCost; else c += kSendCost * (int)liveAt[edges[k + 1]].size();
+            int luts = 0;
+            for (size_t i = edges[k]; i < edges[k + 1]; ++i) luts += steadyRecords[i].w[0] == AS_LUT ? 1 : 0;
+            P.stageCost.push_back(c);
+            P.stageLuts.push_back(luts);
+        }
+        (void)lo;
+    }
+    if (std::getenv("FX_STAGES_DEBUG")) {
+        std::string line;
+        for (size_t k = 0; k < P.stageCost.size(); ++k) line += " " + std::to_string(P.stageCost[k]) + "(" + std::to_string(P.stageLuts[k]) + ")";
+        std::fprintf(stderr, "planStages: wanted %d -> %zu stages, cost per stage (LOG/EXP):%s\n", wanted, P.stageCost.size(), line.c_str());
+    }
     for (int b : cuts) {
         std::vector<int> l = liveAt[(size_t)b];
         std::sort(l.begin(), l.end());
@@ -3203,6 +3227,33 @@ std::vector<MicroOp> stageRecords(const std::vector<MicroOp>& all, size_t from, 
 }
 }  // namespace
 
+// LDS of a staged program: the LOG/EXP tables (shared by all stages: every wavefront stages the same bytes), one flag row per
+// stage ("my packets may hold non-finite values", Translator::stageFlagCheck), the ring of 4 * group packet buffers (the
+// generated code steps through them with an add and an AND: the stride is a power of two), the epilogue's scratch
+bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* L) {
+    const int K = (int)plan.cuts.size() + 1;
+    const uint32_t tableBytes = program.lutTables.empty() ? 0u : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
+    L->cutOff.clear();
+    uint32_t bufStride = 0;
+    for (const auto& l : plan.live) { L->cutOff.push_back(bufStride); bufStride += 256u * (uint32_t)l.size(); }
+    uint32_t pow2 = 256u;
+    while (pow2 < bufStride) pow2 <<= 1;
+    L->bufStride = pow2;
+    L->flagBase = (tableBytes + 255u) & ~255u;
+    L->bufBase = L->flagBase + 256u * (uint32_t)K;
+    L->scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0), behind the ring
+    int group = kStageGroupMax;
+    while (group > 1 && group > maxGroup) group /= 2;
+    if (const char* knob = std::getenv("FX_STAGES_GROUP")) {   // tests: a shorter ring than the LDS would allow (1, 2, 4)
+        const int g = std::atoi(knob);
+        if (g == 1 || g == 2 || g == 4) group = g;
+    }
+    while (group > 1 && L->bufBase + 4u * (uint32_t)group * L->bufStride + L->scratchBytes > ldsBudget) group /= 2;
+    L->group = group;
+    L->bytes = L->bufBase + 4u * (uint32_t)group * L->bufStride + L->scratchBytes;
+    return !(L->bufBase + L->bufStride > 0xff00u || L->bytes > std::min(ldsBudget, 160u * 1024u));
+}
+
 bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
                       const XlateProgram& program, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* codeOut,
                       std::vector<std::string>* listingOut, std::string* err, uint32_t ldsBudget, int maxGroup) {
@@ -3210,29 +3261,11 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     if (K < 2) { if (err) *err = "not a staged plan"; return false; }
     size_t n = 0;
     while (n < steadyRecords.size() && steadyRecords[n].w[0] != AS_ENDSAMPLE) ++n;
-    // LDS: the LOG/EXP tables (shared by all stages: every wavefront stages the same bytes), then two buffers of packets
-    const uint32_t tableBytes = program.lutTables.empty() ? 0u : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
-    std::vector<uint32_t> cutOff;
-    uint32_t bufStride = 0;
-    for (const auto& l : plan.live) { cutOff.push_back(bufStride); bufStride += 256u * (uint32_t)l.size(); }
-    // kStageBuffers buffers; the generated code steps through them with an add and an AND: the stride is a power of two
-    {
-        uint32_t pow2 = 256u;
-        while (pow2 < bufStride) pow2 <<= 1;
-        bufStride = pow2;
-    }
-    // (in front of the ring: one flag row per stage - "my packets may hold non-finite values", Translator::stageFlagCheck)
-    const uint32_t flagBase = (tableBytes + 255u) & ~255u;
-    const uint32_t bufBase = flagBase + 256u * (uint32_t)K;
-    const uint32_t scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0), behind the ring
-    int group = kStageGroupMax;
-    while (group > 1 && group > maxGroup) group /= 2;
-    if (const char* knob = std::getenv("FX_STAGES_GROUP")) {   // tests: a shorter ring than the LDS would allow (1, 2, 4)
-        const int g = std::atoi(knob);
-        if (g == 1 || g == 2 || g == 4) group = g;
-    }
-    while (group > 1 && bufBase + 4u * (uint32_t)group * bufStride + scratchBytes > ldsBudget) group /= 2;
-    if (bufBase + bufStride > 0xff00u || bufBase + 4u * (uint32_t)group * bufStride + scratchBytes > std::min(ldsBudget, 160u * 1024u)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
+    StageLds L;
+    if (!stageLdsLayout(program, plan, ldsBudget, maxGroup, &L)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
+    const std::vector<uint32_t>& cutOff = L.cutOff;
+    const uint32_t bufStride = L.bufStride, flagBase = L.flagBase, bufBase = L.bufBase, scratchBytes = L.scratchBytes;
+    const int group = L.group;
     std::vector<std::vector<uint32_t>> code((size_t)K * 4 + 1);
     std::vector<std::string> listing((size_t)K * 4 + 1);
     uint32_t at = tmpl.holeOff;

@@ -108,6 +108,10 @@ struct StagePlan {
     std::vector<int> pcmStage;                // per channel: the stage that stores its PCM output
     std::vector<uint32_t> inMask;             // per stage: channels whose PCM input it reads
     std::string why;                          // why the program is not cut (diagnostics)
+    // what the planner expects: cost of the whole program and of each stage (pipeline overhead included) in the units of its
+    // balance - roughly vector instructions per sample - and the LOG / EXP round trips in them (Batch::chooseStages)
+    int totalCost = 0, totalLuts = 0;
+    std::vector<int> stageCost, stageLuts;
 };
 
 // What the translator needs to know about the program beyond its records.
@@ -184,6 +188,15 @@ bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& t
 // where cuts are legal and which rows cross them; `wanted` stages at most (>= 2), balanced by an estimate of each record's
 // vector instructions.  cuts empty = the program runs as one stage (why says why).
 StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& prog, int nRows, int wanted);
+
+// where a staged program's flag rows, packet ring and scratch lie in LDS, and how many samples lie between two barriers (the
+// largest group of 8, 4, 2, 1 - at most maxGroup - whose ring of 4 * group buffers fits the budget); false: not even one fits
+struct StageLds {
+    std::vector<uint32_t> cutOff;   // byte offset of cut c's rows inside a buffer
+    uint32_t bufStride = 0, flagBase = 0, bufBase = 0, scratchBytes = 0, bytes = 0;
+    int group = 1;
+};
+bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* out);
 
 // what the template needs per stage (fx_interp_gfx950.S, KA_STAGES): 32 bytes each
 struct StageDescriptor {

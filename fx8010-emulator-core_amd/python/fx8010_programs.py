@@ -202,6 +202,36 @@ def config5_dane(pairs=4):
     return text
 
 
+def wide_chains(width=12):
+    """Not a BASELINE configuration: `width` parallel one-pole chains advancing side by side - width + 1 rows cross every cut
+    of a pipelined program (wide packets: short rings, tests/test_gpu_stages.py, tools/stage_probe.py)."""
+    W = width
+    return ("input in 0\noutput out 0\ncontrol k = 0.25\n" + "".join("static a%d\n" % i for i in range(W))
+            + "".join("static s%d_%d\n" % (i, j) for i in range(W) for j in range(6))
+            + "".join("macs a%d, in, in, 0.%02d\n" % (i, i + 1) for i in range(W))
+            + "".join("interp s%d_%d, s%d_%d, k, a%d\nmacs a%d, s%d_%d, in, 0.05\n" % (i, j, i, j, i, i, i, j) for j in range(6) for i in range(W))
+            + "macs out, 0, a0, 1.0\n" + "".join("macs out, out, a%d, 0.1\n" % i for i in range(1, W)) + "end")
+
+
+def mixed_stages(sections=3):
+    """Not a BASELINE configuration: a delay line with feedback and noise (stage 0), filter sections, a SKIP with its shadow and a
+    LOG / EXP pair per section - everything a stage can hold (tests/test_gpu_stages.py, tools/stage_probe.py)."""
+    L = ["itramsize 11 ", "input in 0", "output out 0", "control k = 0.25", "static noise", "static rd", "static a", "static t", "static u", "static w"]
+    L += ["static s%d" % i for i in range(10 * sections)]
+    L += ["idelay read, rd, at, 0", "macs a, in, rd, 0.5", "macs a, a, noise, 0.125", "idelay write, a, at, 0"]
+    L += ["interp s0, s0, k, a", "macs t, s0, a, 0.05"]
+    for q in range(sections):
+        b = 10 * q
+        L += ["interp s%d, s%d, k, t\nmacs t, s%d, a, 0.05" % (b + i, b + i, b + i) for i in range(1, 4)]
+        L += ["macs u, t, 0, 0", "skip ccr, ccr, 6, 2", "macs t, t, 0.5, 0.5", "macs out, out, t, 0.1", "log w, u, 3, 0", "exp u, w, 5, 0"]
+        L += ["interp s%d, s%d, k, t\nmacs t, s%d, u, 0.05" % (b + i, b + i, b + i) for i in range(4, 10)]
+    L += ["macs out, out, t, 0.5", "end"]
+    return "\n".join(L)
+
+
+# programs of tools/stage_probe.py and of the stage tests that are no BASELINE configuration
+PROBE_PROGRAMS = {"wide12": lambda: wide_chains(12), "wide4": lambda: wide_chains(4), "mixed_stages": mixed_stages}
+
 # programs that need an option of the library (FX_OPT_*) before loading
 CONFIG_OPTIONS = {"config5_dane": 1}
 

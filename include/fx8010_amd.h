@@ -249,6 +249,8 @@ enum {
     FXB_INFO_CODE_CACHED = 28,     /* generated code objects the handle holds (the one in force included) */
     FXB_INFO_XLATE_CODE_HASH = 30, /* fingerprint (63 bits) of the code object in force, 0 when the program is not translated: what a profile of a
                                       launch is a profile of (fxp_code_hash computes the same without a device) */
+    FXB_INFO_STAGE_TRIALS = 31,    /* launches whose time went into the choice of the stage count (options the cost model cannot tell apart are timed
+                                      on the caller's own blocks; FX_STAGES_TUNE=0 turns that off, FX_STAGES=n pins the count) */
     FXB_INFO_XLATE_BACKGROUND_BUILDS = 29 /* translations on the handle's builder thread (ahead of time: the variant with the declared controls in
                                       rows, code for another class of block lengths); FX_BUILDER=0 in the environment turns the thread off */
 };

@@ -87,11 +87,7 @@ def test_every_block_length(gpu, stages, k, group, monkeypatch):
 
 
 def wide_packet_program(W):
-    return ("input in 0\noutput out 0\ncontrol k = 0.25\n" + "".join("static a%d\n" % i for i in range(W))
-            + "".join("static s%d_%d\n" % (i, j) for i in range(W) for j in range(6))
-            + "".join("macs a%d, in, in, 0.%02d\n" % (i, i + 1) for i in range(W))
-            + "".join("interp s%d_%d, s%d_%d, k, a%d\nmacs a%d, s%d_%d, in, 0.05\n" % (i, j, i, j, i, i, i, j) for j in range(6) for i in range(W))
-            + "macs out, 0, a0, 1.0\n" + "".join("macs out, out, a%d, 0.1\n" % i for i in range(1, W)) + "end")
+    return progs.wide_chains(W)
 
 
 @pytest.mark.parametrize("width", [4, 12])
@@ -170,6 +166,45 @@ def test_default_policy_across_batch_sizes(gpu, stages, program, N):
     print("policy: %s N=%d -> %d stage(s), LDS %d B per workgroup" % (program, N, b.info("waves_per_wg"), b.info("lds_bytes_per_wg")))
 
 
+def test_the_stage_count_follows_the_planners_costs(gpu, stages):
+    """round 3 chose 8 / 4 / 1 stages from the number of wavefronts alone, calibrated on the filter chain: twelve parallel chains
+    (13 rows per packet) at 32 768 instances were asked for 8 stages, whose ring does not fit the LDS two workgroups share, and
+    ran unstaged at 5.1e12 instead of 8.0e12 in four.  The choice now comes from the planner's costs per stage and the LDS each
+    count needs (Batch::rankStages; tools/stage_policy_probe.sh measures it against pinned counts)"""
+    stages(None)
+    for program, N, want in (("wide12", 32768, 4), ("wide12", 98304, 2), ("config2", 4096, 8), ("config2", 262144, 1)):
+        text = (progs.CONFIGS.get(program) or progs.PROBE_PROGRAMS[program])()
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        b.process_block(progs.stimulus(N, 300))
+        assert b.info("waves_per_wg") == want, (program, N, b.info("waves_per_wg"))
+
+
+def test_close_options_are_timed_on_the_callers_blocks(gpu, stages):
+    """at 32 768 instances the cost model puts the filter chain in four and in eight stages within 20 % of each other: both are
+    generated (the second one on the builder thread) and timed on the caller's own launches, three each, before one is kept
+    (200-sample blocks: the 3 (K - 1) steps of filling and draining bring the plain program within reach as well - it is tried too).
+    Every option computes the same words: all blocks are the oracle's, the state carries across every change of code"""
+    stages(None)
+    text = progs.config2()
+    N, S, blocks = 32768, 200, 18   # (26 MB per block: below the size from which host blocks go through the device in overlapping pieces)
+    x = progs.stimulus(N, S * blocks)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    ys, waves = [], []
+    for k in range(blocks):
+        ys.append(b.process_block(x[k * S:(k + 1) * S]))
+        waves.append(b.info("waves_per_wg"))
+    assert b.info("stage_trials") >= 6, (b.info("stage_trials"), waves)
+    assert set(waves) >= {4, 8} and len(set(waves[-6:])) == 1, waves   # both were tried (and whatever else the model could not rule out), one was kept
+    assert b.info("xlate_builds") == 1 and b.info("xlate_background_builds") >= 1
+    cuts = [k * S for k in range(blocks + 1)]
+    picks = [0, 63, 64, 4095, 4096, N // 2, N - 65, N - 1] + [int(v) for v in np.linspace(0, N - 1, 40)]
+    compare_sampled(b, text, x, cuts, ys, sorted(set(picks)), ["t", "s0", "s30", "out", "ccr"])
+    assert b.ood_flags() == 0
+    assert b.instruction_counter() == N * 64 * S * blocks
+
+
 def test_code_follows_the_block_length(gpu, stages, monkeypatch):
     """staged code is generated for a class of block lengths (long steps for long blocks, a barrier per sample and at most four
     stages for blocks of a few dozen samples); a caller that changes its block length for good gets new code after a few
@@ -227,10 +262,12 @@ def test_returning_to_a_block_length_is_a_swap(gpu, stages, monkeypatch, builder
         waves.append(b.info("waves_per_wg"))
     assert b.info("xlate_builds") <= (1 if builder else 3), (b.info("xlate_builds"), b.info("xlate_background_builds"))
     assert b.info("code_cache_hits") >= (10 if builder else 17)
-    if not builder:   # (the builder thread delivers when it is done: a few blocks later than this)
+    if not builder:   # (the builder thread delivers when it is done, and stage counts the cost model cannot tell apart are timed first)
         assert waves[4] == 4 and waves[9] == 8, waves   # by the end of each run its own code is in force
         assert waves[10] == 4 and waves[15] == 8        # ... and from the second round on at a run's first block
-    assert waves[-10] == 4 and waves[-6] == 4 and waves[-5] == 8 and waves[-1] == 8, waves
+        assert waves[-10] == 4 and waves[-6] == 4 and waves[-5] == 8 and waves[-1] == 8, waves
+    else:
+        assert waves[-10] == waves[-6] and waves[-5] == waves[-1] and waves[-1] >= waves[-6] >= 2, waves   # each class has settled on its stage count
     for n in (0, 63, 64, N - 1):
         o = Oracle(1)
         assert o.load_text(progs.config2())
