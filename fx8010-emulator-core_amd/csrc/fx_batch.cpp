@@ -826,6 +826,9 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
         c.stageOptions = tmpl ? rankStages(steadyRecords, lastRecords, xprog, c.low.nRows, blockClass, kAsmWavesPerSimd[c.variant]) : std::vector<StageOption>();
         int wantStages = in.stagePick > 0 ? in.stagePick : (c.stageOptions.empty() ? 1 : c.stageOptions.front().wanted);
         c.stagePick = wantStages;
+        // (the wavefronts of a workgroup must be resident together: a CU holds 4 SIMDs x the build's wavefronts per SIMD - a pinned
+        // FX_STAGES=16 in the 256-register build would be a launch that cannot start)
+        wantStages = std::min(wantStages, 4 * kAsmWavesPerSimd[c.variant]);
         // Measured with config2 at 4 096 instances (profiles/r03b_stage_blocks.txt): a block of 32 samples takes 27 us unstaged, 32 us
         // in 8 stages with a barrier every 8 samples (3 x 7 steps of 8 samples to fill and drain) and 21 us in 4 stages with a
         // barrier per sample; 128 samples 69 / 48 / 40 us (8 stages, every 2 samples); from 256 samples on the long steps win

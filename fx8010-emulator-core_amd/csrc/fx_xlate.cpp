@@ -525,6 +525,10 @@ struct LutGuessConstants {
 };
 const LutGuessConstants kLutGuess;
 
+// (defined with the stage planner below) register-file rows a record reads and writes
+struct Access { uint32_t reads[3]; int nReads = 0; int write = -1; bool ccr = false, tram = false, noise = false; };
+Access accessOf(const MicroOp& r);
+
 class Translator {
   public:
     // exactReturns == nullptr: the exact stream (NaN passes every saturation).  Otherwise the fast stream, which
@@ -654,6 +658,37 @@ class Translator {
         if (fast_ && !cleanHead && !leaveIfTainted((*exactReturns_)[syncIndex(0)])) { if (err) *err = err_; return false; }
 
         // ---- the program
+        // Results nobody reads: a row written again, unconditionally, before any instruction of the same sample reads it (the
+        // end of the sample counts as a reader: state, packets, the next sample).  The canonical case is the DANE idiom for
+        // "test a value": `macs tmp, x, 0, 0` + `skip ccr, ccr, <cond>, n` - tmp is written once per test and never read; the
+        // instruction is there for its CCR, which the SKIP's predicate takes straight from x (one()).
+        deadWrite_.assign(records.size(), 0);
+        {
+            bool shadow = false;
+            std::vector<uint8_t> shadowed(records.size(), 0);
+            for (size_t i = 0; i < records.size(); ++i) {
+                if (records[i].w[0] == AS_PRED) shadow = true;
+                else if (records[i].w[0] == AS_UNPRED) shadow = false;
+                shadowed[i] = shadow;
+            }
+            for (size_t i = 0; i < records.size() && records[i].w[0] != AS_ENDSAMPLE; ++i) {
+                const uint32_t slot = records[i].w[0];
+                if (slot < AS_MACS || slot >= (uint32_t)kAsmSlots || shadowed[i]) continue;
+                const Access a = accessOf(records[i]);
+                if (a.write <= 0) continue;   // (row 0 is the CCR)
+                for (size_t j = i + 1; j < records.size(); ++j) {
+                    if (records[j].w[0] == AS_ENDSAMPLE) break;
+                    const Access b = accessOf(records[j]);
+                    bool reads = false;
+                    for (int k = 0; k < b.nReads; ++k) reads = reads || (int)b.reads[k] == a.write;
+                    if (reads || ((b.tram || b.noise) && b.write == a.write)) break;
+                    if (b.write == a.write && !shadowed[j] && !b.tram && !b.noise) { deadWrite_[i] = 1; break; }
+                }
+            }
+            for (int r : prog_.latchRows)   // (an output latch is stored as PCM every sample)
+                for (size_t i = 0; i < records.size(); ++i)
+                    if (deadWrite_[i] && (int)records[i].w[5] == r) deadWrite_[i] = 0;
+        }
         products_.assign((size_t)(fast_ ? prog_.cseEntries : 0), Product());
         for (size_t k = 0; k < products_.size(); ++k) {
             products_[k].vP64 = prog_.cseBase + 2 * (int)k;
@@ -2336,6 +2371,29 @@ class Translator {
             // a CCR write that the stream itself overwrites before anything can read it is dead (the last-sample
             // stream marks every write live; only the final one is state)
             const uint32_t ccr = (rel & 1u) && !ccrDeadAfter(index_) ? 1u : 0u;
+            // a result nobody reads (deadWrite_): nothing to compute in the fast stream - unless its CCR is wanted, and then, for
+            // the test idiom `macs tmp, x, 0, 0` in front of a SKIP, the SKIP's predicate comes straight from x: 0 + x differs from
+            // x only for x = -0, which no CCR value tells from +0 (ccrPredicate: every compare treats them alike), and with x of
+            // the bounded class the saturation is the identity.  (The exact stream computes everything: a wave is there because
+            // some value left its class.)
+            if (fast_ && deadWrite_[index_]) {
+                // (the rows the record names are waited for all the same: both streams keep their sync points at the same records)
+                if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
+                if (!ccr) { ++stats_.inlined; ++stats_.deadResults; return true; }
+                size_t j = index_ + 1;
+                while (j < records_->size() && (*records_)[j].w[0] == AS_NOP) ++j;
+                float want;
+                int32_t count;
+                int vA;
+                if (family == 0 && kind == 6u && r.w[3] == 0u && bound(r.w[2], false) <= 1.0 && j < records_->size() &&
+                    uniformSkip((*records_)[j], &want, &count) && ccrDeadAfter(j) && row(r.w[2], &vA)) {
+                    plainMode();
+                    ++stats_.inlined;
+                    ++stats_.deadResults;
+                    ccrOrSkip(vA);
+                    return true;
+                }
+            }
             if (!ccr) {
                 if (!touch(r, !(kind & 1u), !(kind & 2u), !(kind & 4u), true)) return false;
                 ++stats_.inlined;
@@ -2404,6 +2462,7 @@ class Translator {
     std::vector<std::pair<uint32_t, int>> pool_;  // uniform constants kept in SGPRs for the whole loop: (bits, SGPR)
     std::vector<Deferred> deferred_;
     std::vector<Product> products_;
+    std::vector<uint8_t> deadWrite_;   // per record: its result is overwritten before anything reads it
     bool deferredFailed_ = false;
     const std::vector<MicroOp>* records_ = nullptr;
     size_t consumed_ = (size_t)-1;   // record already translated together with its predecessor
@@ -2872,7 +2931,6 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
 // ---- stage pipelining (fx_xlate.hpp StageInfo) ---------------------------------------------------------------------
 namespace {
 // register-file rows a record reads and writes (uniform operands are not rows; the X word of LOG / EXP is a table)
-struct Access { uint32_t reads[3]; int nReads = 0; int write = -1; bool ccr = false, tram = false, noise = false; };
 Access accessOf(const MicroOp& r) {
     Access a;
     const uint32_t slot = r.w[0];

@@ -160,6 +160,7 @@ struct XlateStats {
     int unitMultipliers = 0;  // multiplications by +-1.0 that were not emitted
     int reusedProducts = 0;   // products of a uniform multiplier and a row taken from the product cache
     int fusedZeroAdds = 0;    // "R = 0 + X * c", |c| > 0.5, emitted as one fma (bit-identical, see fx_xlate.cpp zeroPlusScaled)
+    int deadResults = 0; // instructions whose result nothing reads (only their CCR, if anything, is computed)
     int unsaturated = 0; // saturating instructions whose result provably lies in [-1, 1]: no v_med3 in the fast stream
     bool nonFiniteImmediate = false;  // a NaN / Inf among the uniform operands: no fast stream for this program
 };
