@@ -210,6 +210,18 @@ public:
         if (fxb_process_block_dev(h_, dIn, dOut, nSamples, stream) < 0) throw std::runtime_error(std::string("FX8010Batch::processDevice: ") + fxb_last_error(h_));
     }
     void sync() { fxb_sync(h_); }
+    // the whole batch's DSP state (the reference: plain members, include/FX8010.h:162-217, 288-291) as one image, laid out by global
+    // instance: it loads into any batch of the same size with the same program, whatever its partition into shards
+    std::vector<unsigned char> saveState() {
+        const int64_t bytes = fxb_state_size(h_);
+        if (bytes < 0) throw std::runtime_error(std::string("FX8010Batch::saveState: ") + fxb_last_error(h_));
+        std::vector<unsigned char> image((size_t)bytes);
+        if (fxb_save_state(h_, image.data(), bytes) < 0) throw std::runtime_error(std::string("FX8010Batch::saveState: ") + fxb_last_error(h_));
+        return image;
+    }
+    void loadState(const std::vector<unsigned char>& image) {
+        if (fxb_load_state(h_, image.data(), (int64_t)image.size()) < 0) throw std::runtime_error(std::string("FX8010Batch::loadState: ") + fxb_last_error(h_));
+    }
     int64_t getInstructionCounter() { return fxb_instruction_counter(h_); }
     int64_t getInstructionCounter(int64_t instance) { return fxb_instruction_counter_i(h_, instance); }
     float lastKernelMs() { return fxb_last_kernel_ms(h_); }
