@@ -75,6 +75,8 @@ def _worker(rank, world, port, n_total, n_samples, text, result_path):
     d.barrier()
     elapsed = shard.reduce_scalar(d, 1.0 + rank, "max")          # bench.py: MAX over ranks of the timed region
     total = shard.reduce_scalar(d, executed, "sum")               # bench.py: executed instructions of the whole job
+    per_rank = shard.gather_scalars(d, 10.0 + rank)               # bench.py: every device's own kernel time (per_gpu_kernel_ms)
+    assert per_rank == [10.0 + r for r in range(world)]
     gathered = [None] * world
     d.all_gather_object(gathered, (first, y))
     if rank == 0:
@@ -102,3 +104,4 @@ def test_two_ranks_reproduce_one(tmp_path, world):
         executed += o.instruction_counter()
     elapsed, total = [float(v) for v in open(path + ".txt").read().split()]
     assert elapsed == 2.0 and total == float(executed)
+    assert shard.gather_scalars(None, 3.5) == [3.5]   # a single process: its own time

@@ -116,6 +116,21 @@ def test_hardware_instruction_counters_are_of_this_code():
         assert abs(hw[key] - count) < 0.5, (key, hw[key], count)
 
 
+def test_code_fingerprint_tells_code_objects_apart():
+    """fxp_code_hash (= FXB_INFO_XLATE_CODE_HASH of a batch in the same situation): equal for equal inputs, different for another
+    program, another VGPR build, another stage count, non-temporal delay-line accesses"""
+    def h(name, *a, **k):
+        fe = A.FrontEnd(1)
+        assert fe.load_text((P.CONFIGS.get(name) or P.PROBE_PROGRAMS[name])())
+        return fe.code_hash(*a, **k)
+    base = h("config5", 128)
+    assert base == h("config5", 128) and 0 < base < 2 ** 63
+    others = {h("config5", 168), h("config5", 128, 1, True), h("config4", 128), h("config2", 128), h("config2", 128, 8), h("config2", 128, 4)}
+    assert base not in others and len(others) == 6
+    with pytest.raises(RuntimeError):
+        h("config5", 64)   # 59 rows do not fit the 64-register build
+
+
 def test_committed_counter_passes_name_the_code_generated_today():
     """every profiles/*_pmc_valu.json that carries the fingerprint of the code object it was collected on (bench.code_hash, since
     round 4) - the unstaged streams of config3 / 4 / 5 and config2's eight stages - against the fingerprint of what the
