@@ -1221,9 +1221,11 @@ int Batch::processWithTrackFallback(const float* dIn, float* dOut, int nSamples,
 void Batch::noteBlockLength(int nSamples) {
     if (nSamples <= 0) return;
     const int cls = stageBlockClass(nSamples);
-    if (wantedClass_ < 0 || c_.key.empty()) {   // the first block after a load (or after a failed build): lowDirty_ is set anyway
+    if (wantedClass_ < 0 || c_.key.empty()) {   // the first block after a load (or after a failed build)
         wantedClass_ = cls;
         otherClassBlocks_ = 0;
+        // (code that an fxb_info call had generated before the first block is for the shortest class)
+        if (!c_.key.empty() && c_.classMatters && c_.blockClass != cls) lowDirty_ = true;
         return;
     }
     if (cls == wantedClass_) { otherClassBlocks_ = 0; return; }

@@ -599,3 +599,44 @@ def test_state_snapshot_round_trip_and_repartition(gpu, name):
     assert small.load_text(text)
     with pytest.raises(RuntimeError):
         small.load_state(img)
+
+
+@pytest.mark.parametrize("tier", ["asm", "asm_lds", 1, 2, 4])
+def test_snapshot_and_delay_memory_on_the_other_tiers(gpu, monkeypatch, tier):
+    """the state image and the delay-memory reads do not depend on the tier that runs the program: the interpreter (VGPR and LDS
+    register file) and the HIP C++ kernel with 1 / 2 / 4 instances per lane, whose delay memory is tiled [wavefront][slot][64 x K] -
+    an image saved under one tier loads under another"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    if isinstance(tier, str):
+        monkeypatch.setenv("FX_KERNEL", tier)
+    else:
+        monkeypatch.setenv("FX_INST_PER_LANE", str(tier))
+    text = ("itramsize 37 \nxtramsize 100 \nstatic rd\nstatic xd\nstatic a\nstatic noise\ninput in 0\noutput out 0\ncontrol fb = 0.5\n"
+            "idelay read, rd, at, 0\nxdelay read, xd, at, 0\nmacs a, in, rd, fb\nmacs a, a, noise, 0.0625\nidelay write, a, at, 0\n"
+            "interp out, out, 0.25, xd\nxdelay write, a, at, 3\nend")
+    N, S = 200, 150
+    x = progs.stimulus(N, S + 40)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    b.set_register_i("fb", 77, 0.25)
+    b.process_block(x[:S])
+    img = b.save_state()
+    for n in (0, 63, 64, 77, 130, N - 1):
+        o = Oracle(1)
+        assert o.load_text(text)
+        if n == 77:
+            o.set_register("fb", 0.25)
+        o.process_block(x[:S, n].copy())
+        assert np.array_equal(bits(b.get_tram_i(0, n, 64)), bits(o.tram(0, 64))), (tier, n)
+        assert np.array_equal(bits(b.get_tram_i(1, n, 128)), bits(o.tram(1, 128))), (tier, n)
+        assert b.get_cursors_i(n) == o.cursors(), (tier, n)
+    ya = b.process_block(x[S:])
+    monkeypatch.delenv("FX_KERNEL", raising=False)       # the image goes to a handle on the default tier
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    c = gpu.Batch(N, 1, 0)
+    assert c.load_text(text)
+    c.load_state(img)
+    assert np.array_equal(bits(c.process_block(x[S:])), bits(ya)), tier
+    assert c.get_register_i("fb", 77) == np.float32(0.25) and c.get_register_i("fb", 78) == np.float32(0.5)
+    assert np.array_equal(c.save_state(), b.save_state())

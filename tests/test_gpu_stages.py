@@ -286,6 +286,11 @@ def test_small_batches_are_staged_by_default(gpu, stages):
     assert b.load_text(progs.config2())
     b.process_block(progs.stimulus(300, 300))
     assert b.info("waves_per_wg") == 8          # 5 wavefronts of instances: eight stages each
+    asked = gpu.Batch(300, 1, 0)
+    assert asked.load_text(progs.config2())
+    assert asked.info("kernel") >= 9            # a question before the first block generates code - for the shortest class of blocks
+    asked.process_block(progs.stimulus(300, 300))
+    assert asked.info("waves_per_wg") == 8      # ... the first block brings its own class
     short = gpu.Batch(300, 1, 0)
     assert short.load_text(progs.config2())
     short.process_block(progs.stimulus(300, 8))
