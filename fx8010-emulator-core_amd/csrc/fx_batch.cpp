@@ -543,7 +543,13 @@ void Batch::noteLaunchTime() {
             lowDirty_ = true;
             return;
         }
-        waiting = waiting || buildPending(key);   // (neither there nor on its way: the builder could not make it - out of the race)
+        if (buildFailed(key)) continue;   // (the builder could not make it: out of the race)
+        if (!buildPending(key)) {         // (e.g. the set of registers with rows has changed since the options were asked for)
+            BuildInputs in = buildInputs(key, cls, false);
+            in.stagePick = t.options[k].wanted;
+            requestBuild(std::move(in));
+        }
+        waiting = waiting || buildPending(key);
     }
     if (waiting) return;
     size_t bestK = cur;
@@ -647,6 +653,13 @@ bool Batch::buildPending(const std::string& key) {
     return false;
 }
 
+bool Batch::buildFailed(const std::string& key) {
+    if (!builder_) return true;
+    std::lock_guard<std::mutex> lock(builder_->mu);
+    for (const std::string& k : builder_->failed) if (k == key) return true;
+    return false;
+}
+
 // true: the builder has (or had) this key in hand and is done with it now
 bool Batch::waitBuild(const std::string& key) {
     if (!builder_) return false;
@@ -687,7 +700,6 @@ void Batch::drainBuilder(bool stop) {
 
 void Batch::prebuildControlVariant() {
     if (controlMode_ || c_.key.empty() || !c_.useXlate || !builderWanted()) return;
-    if (c_.blockClass >= 0 && c_.blockClass < 3 && tune_[c_.blockClass].init && !tune_[c_.blockClass].done) return;   // (stage counts are still on trial: once one is kept)
     std::vector<uint8_t> forced = laneForced();
     bool any = false;
     for (const std::string& name : prog_.controls) {
@@ -698,10 +710,18 @@ void Batch::prebuildControlVariant() {
     }
     if (!any) return;
     const int blockClass = keyClass();
-    BuildInputs in = buildInputs(codeKeyFor(forced, blockClass, false, pickFor(blockClass)), blockClass, false);
-    if (cachedCode(in.key)) return;
-    in.forced = forced;
-    requestBuild(std::move(in));
+    // ... for the stage count in force and for every one still on trial: a slider may move while the trials run
+    std::vector<int> picks{pickFor(blockClass)};
+    if (blockClass >= 0 && blockClass < 3 && tune_[blockClass].init && !tune_[blockClass].done)
+        for (const StageOption& o : tune_[blockClass].options)
+            if (std::find(picks.begin(), picks.end(), o.wanted) == picks.end()) picks.push_back(o.wanted);
+    for (int pick : picks) {
+        BuildInputs in = buildInputs(codeKeyFor(forced, blockClass, false, pick), blockClass, false);
+        if (cachedCode(in.key)) continue;
+        in.forced = forced;
+        in.stagePick = pick;
+        requestBuild(std::move(in));
+    }
 }
 
 Batch::BuildInputs Batch::buildInputs(const std::string& key, int blockClass, bool defer) const {
@@ -1497,6 +1517,26 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
     e = hipStreamSynchronize(copyOut_);
     if (e == hipSuccess) e = hipStreamSynchronize(stream_);
     return e == hipSuccess ? 0 : hipFail(e, "pipelined host block");
+}
+
+// Generate the code a stream of `nSamples`-sample blocks will run, now - a real-time caller does this after loading, before the
+// stream starts, instead of paying for the translation in its first block.  wait: also until the builder thread has finished
+// what it was asked for (the variant with the controls in rows, other stage counts on trial).
+int Batch::prepare(int nSamples, bool wait) {
+    (void)hipSetDevice(device_);
+    if (nSamples < 1) return fail(FX_E_ARG, "prepare: n_samples >= 1");
+    pendingSamples_ = nSamples;
+    noteBlockLength(nSamples);
+    int rc = ensureLowered();
+    if (rc != 0) return rc;
+    everLowered_ = true;
+    if (wait && builder_) {
+        std::unique_lock<std::mutex> lock(builder_->mu);
+        builder_->cv.wait(lock, [&] { return builder_->running.empty() && builder_->jobs.empty(); });
+        lock.unlock();
+        collectBuilt();
+    }
+    return 0;
 }
 
 int Batch::sync() {

@@ -43,6 +43,7 @@ public:
     int processHost(const float* in, float* out, int nSamples, int64_t pitch = 0);  // synchronous; pitch: instances per host PCM row (0 = n)
     int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
     int sync();
+    int prepare(int nSamples, bool wait);   // generate the code for blocks of this length now (and wait for the builder thread)
 
     // State snapshot (the reference keeps all DSP state in plain members, include/FX8010.h:162-217, 288-291: registers, output
     // latches, delay memory and its four positions, the LFSR words, the instruction counter).  The image is laid out by GLOBAL
@@ -174,6 +175,7 @@ private:
     void requestBuild(BuildInputs&& in);
     void collectBuilt();                         // what the builder has finished -> cache_
     bool buildPending(const std::string& key);
+    bool buildFailed(const std::string& key);
     bool waitBuild(const std::string& key);
     void drainBuilder(bool stop);
     void prebuildControlVariant();

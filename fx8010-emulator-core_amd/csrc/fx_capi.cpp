@@ -189,6 +189,7 @@ int fxb_process_block_dev_shards(fxb_handle* h, const float* const* d_in, float*
     return h ? guardCode(&h->batch.front(), [&] { return h->batch.processDeviceShards(d_in, d_out, n); }) : FX_E_ARG;
 }
 int fxb_sync(fxb_handle* h) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.sync(); }) : FX_E_ARG; }
+int fxb_prepare(fxb_handle* h, int n_samples, int wait) { return h ? guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.prepare(n_samples, wait != 0); }) : FX_E_ARG; }
 int64_t fxb_state_size(fxb_handle* h) { return h ? guard(&h->batch.front(), (int64_t)FX_E_PROGRAM, [&] { return h->batch.stateBytes(); }) : FX_E_ARG; }
 int fxb_save_state(fxb_handle* h, void* buf, int64_t cap) { return h ? guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.saveState(buf, cap); }) : FX_E_ARG; }
 int fxb_load_state(fxb_handle* h, const void* buf, int64_t bytes) { return h ? guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.loadState(buf, bytes); }) : FX_E_ARG; }

@@ -303,6 +303,10 @@ int Sharded::getCursorsAt(int64_t inst, int32_t out4[4]) {
     if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
     return runOn(k, [&](Batch& b) { return b.getCursorsAt(inst - shards_[(size_t)k]->first, out4); });
 }
+int Sharded::prepare(int nSamples, bool wait) {
+    lastError_.clear();
+    return fan([&](int, Batch& b) { return b.prepare(nSamples, wait); });
+}
 float Sharded::lastKernelMsOf(int k) {
     float ms = -1.0f;
     runOn(k, [&](Batch& b) { ms = b.lastKernelMs(); return 0; });

@@ -65,6 +65,7 @@ public:
     // single shard only: the caller's stream
     int processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream);
     int sync();
+    int prepare(int nSamples, bool wait);
 
     // state snapshot of the whole batch, laid out by global instance (fx_batch.hpp SnapshotHeader): an image saved from one
     // partition loads into any other with the same program and instance count

@@ -210,6 +210,10 @@ public:
         if (fxb_process_block_dev(h_, dIn, dOut, nSamples, stream) < 0) throw std::runtime_error(std::string("FX8010Batch::processDevice: ") + fxb_last_error(h_));
     }
     void sync() { fxb_sync(h_); }
+    // generate the code for blocks of nSamples samples now, not in the first process call (callers with a deadline per block)
+    void prepare(int nSamples, bool wait = true) {
+        if (fxb_prepare(h_, nSamples, wait ? 1 : 0) < 0) throw std::runtime_error(std::string("FX8010Batch::prepare: ") + fxb_last_error(h_));
+    }
     // the whole batch's DSP state (the reference: plain members, include/FX8010.h:162-217, 288-291) as one image, laid out by global
     // instance: it loads into any batch of the same size with the same program, whatever its partition into shards
     std::vector<unsigned char> saveState() {

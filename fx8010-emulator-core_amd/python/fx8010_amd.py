@@ -32,7 +32,7 @@ SYMBOLS = [
     "fx_instruction_counter", "fx_error_count", "fx_error_desc", "fx_error_row", "fx_control_count", "fx_control_at",
     "fx_meta_get", "fx_set_option", "fxb_set_option", "fxp_set_option", "fx_set_channels", "fx_get_channels", "fx_ready", "fx_last_error", "fx_last_create_error",
     "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_shard_kernel_ms", "fxb_shard_plan", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
-    "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_state_size", "fxb_save_state", "fxb_load_state", "fxb_get_tram_i", "fxb_get_cursors_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
+    "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_prepare", "fxb_state_size", "fxb_save_state", "fxb_load_state", "fxb_get_tram_i", "fxb_get_cursors_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
     "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error",
     "fxb_last_kernel_ms", "fxb_info", "fxb_device_count", "fxb_version",
@@ -73,7 +73,7 @@ def load():
     sig("fxb_shard_count", i32, vp); sig("fxb_shard_info", i32, vp, i32, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64))
     sig("fxb_shard_plan", i32, i64, i32, C.POINTER(i64), C.POINTER(i64))
     sig("fxb_shard_kernel_ms", f32, vp, i32)
-    sig("fxb_state_size", i64, vp); sig("fxb_save_state", i32, vp, vp, i64); sig("fxb_load_state", i32, vp, vp, i64)
+    sig("fxb_prepare", i32, vp, i32, i32); sig("fxb_state_size", i64, vp); sig("fxb_save_state", i32, vp, vp, i64); sig("fxb_load_state", i32, vp, vp, i64)
     sig("fxb_get_tram_i", i32, vp, i32, i64, vp, i32); sig("fxb_get_cursors_i", i32, vp, i64, C.POINTER(C.c_int32))
     sig("fxb_process_block_dev_shards", i32, vp, C.POINTER(vp), C.POINTER(vp), i32)
     sig("fxb_load_file", i32, vp, cp); sig("fxb_load_text", i32, vp, cp)
@@ -336,6 +336,10 @@ class Batch(_Reports):
 
     def seed_noise_i(self, inst, x1, x2):
         return self._check(self._lib.fxb_seed_noise_i(self._h, inst, x1, x2), "seed_noise_i")
+
+    def prepare(self, n_samples, wait=True):
+        """generate the code for blocks of n_samples samples now (and wait for the builder thread's follow-ups)"""
+        return self._check(self._lib.fxb_prepare(self._h, int(n_samples), 1 if wait else 0), "prepare")
 
     def save_state(self):
         """the whole batch's state as one image (numpy uint8): registers, latches, delay memory, positions, LFSR, counters"""

@@ -640,3 +640,32 @@ def test_snapshot_and_delay_memory_on_the_other_tiers(gpu, monkeypatch, tier):
     assert np.array_equal(bits(c.process_block(x[S:])), bits(ya)), tier
     assert c.get_register_i("fb", 77) == np.float32(0.25) and c.get_register_i("fb", 78) == np.float32(0.5)
     assert np.array_equal(c.save_state(), b.save_state())
+
+
+def test_prepare_moves_the_translation_out_of_the_first_block(gpu, monkeypatch):
+    """fxb_prepare(h, n_samples, wait): the code for a stream of n_samples-sample blocks is generated when the caller says so -
+    after loading, before the stream starts - and the follow-ups of a first build are waited for: the first block and the first
+    touch of a slider then find their code (a real-time caller's deadline: 667 us per 32-sample block, reference
+    include/FX8010.h:38)"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_STAGES", raising=False)
+    text = progs.config2()
+    N = 300
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    b.prepare(32)
+    builds, background = b.info("xlate_builds"), b.info("xlate_background_builds")
+    assert builds == 1 and background >= 1       # the code of 32-sample blocks; the control-row variant (and stage counts on trial) behind it
+    x = progs.stimulus(N, 32 * 12)
+    o = Oracle(1)
+    assert o.load_text(text)
+    for k in range(12):
+        if k == 5:
+            b.set_register("cutoff", 0.25)       # the first touch of a slider
+            o.set_register("cutoff", 0.25)
+        y = b.process_block(x[32 * k:32 * (k + 1)])
+        assert np.array_equal(bits(o.process_block(x[32 * k:32 * (k + 1), 7].copy())), bits(y[:, 7])), k
+    assert b.info("xlate_builds") == 1           # nothing was translated on the caller's thread after prepare
+    with pytest.raises(RuntimeError):
+        gpu.Batch(N, 1, 0).prepare(32)           # nothing loaded
