@@ -55,7 +55,7 @@ def run(seed, verbose=False):
         print(text)
         print("N", N, "check", check, "names", names)
     for step in range(30):
-        op = rng.integers(0, 13)
+        op = rng.integers(0, 15)
         if verbose:
             for n in check:
                 bad = [(r, "%08x" % b.get_register_bits_i(r, n), "%08x" % oracles[n].get_register_bits(r)) for r in names + ["ccr"]
@@ -63,6 +63,22 @@ def run(seed, verbose=False):
                 if bad or b.instruction_counter_i(n) != oracles[n].instruction_counter():
                     print("  BEFORE step", step, "instance", n, "differs:", bad, "ctr", b.instruction_counter_i(n), oracles[n].instruction_counter())
             print("step", step, "op", int(op), "kernel", b.info("kernel"))
+        if op == 13:
+            # the whole state through an image into a NEW handle (fxb_save_state / fxb_load_state), which carries on: registers, delay
+            # memory, positions, LFSR, counters, per-instance rows - and whatever the host side has to re-learn about them
+            img = b.save_state()
+            nb = A.Batch(N, 1, devices=[0] * shards) if shards > 1 and (N + 63) // 64 >= shards else A.Batch(N, 1, 0)
+            if not nb.load_text(text):
+                print("RELOAD seed %d step %d" % (seed, step))
+                return False
+            nb.load_state(img)
+            b = nb
+            if verbose:
+                print("  state image -> new handle")
+            continue
+        if op == 14:
+            b.prepare(int(rng.choice([1, 8, 40, 300])), bool(rng.integers(0, 2)))
+            continue
         if op == 12:
             # control tracks: schedules of register values applied inside the next block (fxb_set_register_track), the oracle
             # gets the same values through set_register between its samples
