@@ -723,6 +723,15 @@ class Translator {
 
         // ---- PCM out, next sample
         plainMode();
+        {
+            // diagnostics: FX_XLATE_LOOPPAD=n / FX_XLATE_LOOPPAD_SLOW=n put n independent instructions (plain / 4-clock class, on a
+            // spare register) into every sample of every stream - does a stage's loop pay for issue slots or for the latency of
+            // its dependent chain?  (tools/stage_pad_probe.sh)
+            static const int pad = std::getenv("FX_XLATE_LOOPPAD") ? std::atoi(std::getenv("FX_XLATE_LOOPPAD")) : 0;
+            static const int padSlow = std::getenv("FX_XLATE_LOOPPAD_SLOW") ? std::atoi(std::getenv("FX_XLATE_LOOPPAD_SLOW")) : 0;
+            for (int k = 0; k < pad; ++k) e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 31, vreg(31), 31);
+            for (int k = 0; k < padSlow; ++k) e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(31), vreg(31));
+        }
         if (!staged || usesSkipCounter) e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
         if (staged) {
             // hand this sample's live rows to the next stage; ONE barrier per step on every path through a sample (all
