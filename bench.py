@@ -509,7 +509,8 @@ def main():
             # the other single-GPU configurations of BASELINE.json at their instance counts, and ALL of configs[4]
             # (2 097 152 instances, 64 GiB of xTRAM) on this one GPU; fewer launches each, same block length
             extra = {}
-            plan = [("config2", 4096, 60, 256), ("config3", 65536, 10, 256), ("config4", 262144, 6, 256), ("config5_full_1gpu", 2097152, 4, 64)]
+            # (enough launches for the clock sampler to see the chip at its working clock: config2's launch takes 0.6 ms)
+            plan = [("config2", 4096, 400, 256), ("config3", 65536, 40, 256), ("config4", 262144, 8, 256), ("config5_full_1gpu", 2097152, 4, 64)]
             for name, n, k, pn in plan:
                 cfg = "config5" if name.startswith("config5") else name
                 try:
