@@ -306,3 +306,43 @@ def test_delay_line_fuzz(gpu, dane, monkeypatch):
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
     monkeypatch.setattr(sys, "argv", ["fuzz_tram.py", "5000", "150"] + (["dane"] if dane else []))
     assert fuzz_tram.main() == 0
+
+
+@pytest.mark.gpu
+def test_gpu_state_image_under_the_dane_model(gpu, monkeypatch):
+    """fxb_save_state / fxb_load_state with the opt-in delay-line model in force: the per-sample address counters, the tap registers
+    (&name) and the delay memory travel with the image - the chorus (per-instance, modulated taps) is stopped in the middle of a
+    run and carries on in a new handle and in a two-shard handle exactly like the batch that was never stopped"""
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    n, s = 150, 1500
+    x = progs.stimulus(n, s + 300)
+    depth = np.linspace(0.0, 0.0012, n).astype(np.float32)
+    speed = np.linspace(0.05, 0.6, n).astype(np.float32)
+
+    def make(**kw):
+        b = gpu.Batch(n, 1, **kw)
+        for opt in (gpu.OPT_TRAM_DANE, gpu.OPT_TRAM_ADDR_SHIFT, gpu.OPT_TRAM_INTERP):
+            b.set_option(opt)
+        assert b.load_text(CHORUS), b.errors()
+        return b
+
+    a = make(device=0)
+    a.set_register_array("depth", depth)
+    a.set_register_array("speed", speed)
+    a.process_block(x[:s])
+    img = a.save_state()
+    ya = a.process_block(x[s:])
+    for kw in ({"device": 0}, {"devices": [0, 0]}):
+        b = make(**kw)
+        b.load_state(img)
+        assert np.array_equal(bits(b.process_block(x[s:])), bits(ya)), kw
+        assert b.instruction_counter() == a.instruction_counter() and b.ood_flags() == 0
+    o = Oracle(1)
+    for opt in (OPT_DANE, OPT_SHIFT, OPT_INTERP):
+        o.set_option(opt)
+    assert o.load_text(CHORUS)
+    o.set_register("depth", float(depth[99]))
+    o.set_register("speed", float(speed[99]))
+    ref = o.process_block(x[:, 99].copy())
+    assert np.array_equal(bits(ref[s:]), bits(ya[:, 99]))
