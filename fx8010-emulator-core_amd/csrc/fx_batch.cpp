@@ -517,7 +517,11 @@ void Batch::noteLaunchTime() {
     if (cls < 0 || cls >= 3) return;
     Tuner& t = tune_[cls];
     if (!t.init || t.done) return;
-    if (lastLaunchTimed_ && launched_ && hipEventQuery(ev1_) == hipSuccess) {
+    // (hipErrorNotReady is an answer, not a failure: it must not stay behind as the thread's "last error" for the launch
+    // helpers that ask hipGetLastError() after their kernel)
+    const hipError_t ready = (lastLaunchTimed_ && launched_) ? hipEventQuery(ev1_) : hipErrorNotReady;
+    if (ready != hipSuccess) (void)hipGetLastError();
+    if (ready == hipSuccess) {
         lastLaunchTimed_ = false;
         float ms = -1.0f;
         if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess && ms > 0.0f && lastLaunchSamples_ >= kTuneMinSamples)

@@ -205,6 +205,41 @@ def test_close_options_are_timed_on_the_callers_blocks(gpu, stages):
     assert b.instruction_counter() == N * 64 * S * blocks
 
 
+def test_trials_with_launches_queued_behind_each_other(gpu, stages):
+    """a caller that keeps launches queued (device-resident PCM, no sync per block: bench.py's way): the tuner only sees the time
+    of a launch that has finished when the next one is made - an unfinished one is skipped, and asking for it must leave nothing
+    behind that the helpers launched in between (a register fill, the counter reduction) could mistake for an error of theirs"""
+    import torch
+    stages(None)
+    text = progs.config2()
+    N, S, blocks = 32768, 200, 24
+    x = progs.stimulus(N, S * blocks)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    torch.cuda.synchronize()
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    for k in range(blocks):
+        if k == 9:
+            assert b.set_register("cutoff", 0.2) == 0           # (a row fill between queued launches)
+        if k == 15:
+            assert b.instruction_counter() == N * 64 * S * 15  # (a reduction; it waits for the launches before it)
+        if k in (6, 18):
+            b.sync()                                            # now and then the caller does wait: those launches can be timed
+        b.process_block_dev(xd[k * S:(k + 1) * S].data_ptr(), yd[k * S:(k + 1) * S].data_ptr(), S)
+    b.sync()
+    y = yd.cpu().numpy()
+    for n in (0, 63, 64, N // 2, N - 1):
+        o = Oracle(1)
+        assert o.load_text(text)
+        r1 = o.process_block(x[:9 * S, n].copy())
+        o.set_register("cutoff", 0.2)
+        r2 = o.process_block(x[9 * S:, n].copy())
+        assert np.array_equal(np.concatenate([r1, r2]).view(np.uint32), np.ascontiguousarray(y[:, n]).view(np.uint32)), n
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+    assert b.ood_flags() == 0 and b.info("kernel") >= 9
+
+
 def test_code_follows_the_block_length(gpu, stages, monkeypatch):
     """staged code is generated for a class of block lengths (long steps for long blocks, a barrier per sample and at most four
     stages for blocks of a few dozen samples); a caller that changes its block length for good gets new code after a few
