@@ -491,7 +491,7 @@ void Batch::adoptStageOptions() {
     t.pick = c_.stagePick;
     // (built for "the cheapest": from now on the code goes by the stage count it was built for)
     c_.key = codeKeyFor(laneForced(), cls, c_.deferred, t.pick);
-    static const bool tuneOff = std::getenv("FX_STAGES_TUNE") && std::atoi(std::getenv("FX_STAGES_TUNE")) == 0;
+    const bool tuneOff = std::getenv("FX_STAGES_TUNE") && std::atoi(std::getenv("FX_STAGES_TUNE")) == 0;
     if (c_.stageOptions.empty() || std::getenv("FX_STAGES")) { t.done = true; return; }
     const double best = c_.stageOptions.front().predicted;
     for (const StageOption& o : c_.stageOptions)

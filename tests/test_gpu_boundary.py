@@ -650,6 +650,8 @@ def test_prepare_moves_the_translation_out_of_the_first_block(gpu, monkeypatch):
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
     monkeypatch.delenv("FX_STAGES", raising=False)
+    monkeypatch.delenv("FX_BUILDER", raising=False)
+    monkeypatch.delenv("FX_STAGES_TUNE", raising=False)
     text = progs.config2()
     N = 300
     b = gpu.Batch(N, 1, 0)

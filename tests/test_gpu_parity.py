@@ -562,6 +562,7 @@ def test_moving_controls_become_rows_once(gpu, monkeypatch, builder):
     without that thread (FX_BUILDER=0) it is ONE re-translation on the caller's.  Results are the reference's throughout."""
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_BUILDER", raising=False)
     if not builder:
         monkeypatch.setenv("FX_BUILDER", "0")
     text = HDR + "control mix = 0.25\ncontrol unused = 0.5\nmacs a, a, vol, in\ninterp b, b, vol, a\nmacs out, b, a, mix\nend"

@@ -19,6 +19,8 @@ def stages(monkeypatch):
     def pin(k):
         monkeypatch.delenv("FX_KERNEL", raising=False)
         monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+        monkeypatch.delenv("FX_BUILDER", raising=False)        # (tests that want the caller's thread only say so themselves)
+        monkeypatch.delenv("FX_STAGES_TUNE", raising=False)
         if k is None:
             monkeypatch.delenv("FX_STAGES", raising=False)
         else:
