@@ -30,7 +30,7 @@ def env_world():
 def init_process_group(backend, device=None):
     """Initialise torch.distributed when WORLD_SIZE > 1; returns the module or None."""
     rank, local, world = env_world()
-    if world <= 1:
+    if world <= 1 and os.environ.get("FX_FORCE_DIST") != "1":   # (FX_FORCE_DIST=1: a one-rank group - the RCCL code path on a one-GPU box)
         return None
     import torch
     import torch.distributed as dist

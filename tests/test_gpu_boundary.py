@@ -671,3 +671,23 @@ def test_prepare_moves_the_translation_out_of_the_first_block(gpu, monkeypatch):
     assert b.info("xlate_builds") == 1           # nothing was translated on the caller's thread after prepare
     with pytest.raises(RuntimeError):
         gpu.Batch(N, 1, 0).prepare(32)           # nothing loaded
+
+
+def test_bench_through_rccl_with_one_rank(gpu, tmp_path):
+    """the multi-GPU launch of bench.py as the driver makes it (torch.distributed.run, backend nccl = RCCL, barriers and the
+    MAX / SUM / all-gather of times and counters on the device) - with ONE rank, which is what a one-GPU box can run: the
+    process-group code path that the 2 / 4 / 8-GPU runs take, not the single-process shortcut"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "config3", "--instances", "4096", "--samples", "256",
+                        "--parity-instances", "8", "--cpu-seconds", "0", "--no-extras"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["parity"]["parity_ok"] and d["value"] > 0
+    assert len(d["roofline"]["per_gpu_kernel_ms"]) == 1 and d["roofline"]["per_gpu_kernel_ms"][0] > 0
