@@ -199,6 +199,21 @@ def main():
             longc.append(c)
     out["configs_long.json"] = longc
 
+    # 6a'. the program shapes the stage planner is calibrated and tested with (twelve parallel chains: 13-row packets; a delay
+    # line with feedback and noise, SKIP shadows and LOG / EXP pairs): small batches run them as pipelines of stages, and these
+    # are the reference's own words for them
+    probe = []
+    for name in ("wide12", "mixed_stages"):
+        text = progs.PROBE_PROGRAMS[name]()
+        for inst in (0, 777):
+            x = progs.stimulus(1, 384, first_instance=inst)[:, 0].copy()
+            c = run_case("%s_inst%d" % (name, inst), text, x, regs=("ccr", "out"))
+            del c["program"]
+            c["config"] = name
+            c["instance"] = inst
+            probe.append(c)
+    out["configs_probe.json"] = probe
+
     # 6b. non-finite values: what the x86 build of the reference does with NaN (either sign, payloads, signalling) and
     # Inf coming in through the PCM input, with NaNs made by the arithmetic itself (Inf * 0, Inf - Inf: the x86 default
     # NaN is NEGATIVE, 0xFFC00000), through saturating and non-saturating instructions, TRAM and the fp64 path

@@ -107,6 +107,14 @@ def test_config_programs(gpu, tier):
         run_case(gpu, dict(case), text=text)
 
 
+def test_stage_planner_programs(gpu, tier):
+    """configs_probe.json: the reference's own words for the program shapes the stage planner is calibrated with - at 67
+    instances the default tier runs them as pipelines of stages (13-row packets; a delay line, SKIP shadows and LOG / EXP inside
+    stages)"""
+    for case in load("configs_probe.json"):
+        run_case(gpu, dict(case), text=progs.PROBE_PROGRAMS[case["config"]]())
+
+
 def test_delay_lines_past_the_first_read_back(gpu, tier):
     """configs_long.json: config3 / config5 over 2304 samples of the REFERENCE's own output - config5's 8192-slot line hands
     back its first written word at sample 2048 (four reads + four writes per sample, cursors per executed TRAM instruction,

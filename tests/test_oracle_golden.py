@@ -100,6 +100,16 @@ def test_config_programs_against_reference():
         assert o.ood_flags() == 0
 
 
+def test_stage_planner_programs_against_reference():
+    """configs_probe.json: the program shapes of tools/stage_policy_probe.sh (parallel chains, delay line + SKIP + LOG / EXP)"""
+    for case in load("configs_probe.json"):
+        case = dict(case)
+        text = progs.PROBE_PROGRAMS[case["config"]]()
+        x = progs.stimulus(1, case["shape"][0], first_instance=case["instance"])[:, 0]
+        assert np.array_equal(x.view(np.uint32), f32(case["input"]).view(np.uint32)), "stimulus generator drifted"
+        assert run_oracle(case, text=text).ood_flags() == 0
+
+
 def test_delay_lines_past_the_first_read_back_against_reference():
     """configs_long.json: config3 / config5 over 2304 samples - the reference's cursors advance per executed TRAM instruction
     (source/FX8010.cpp:909-967), so config5's 8192-slot line hands back its first written word at sample 2048 (config3 at 1000
