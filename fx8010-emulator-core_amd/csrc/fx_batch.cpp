@@ -262,6 +262,7 @@ bool Batch::laneResident(int reg) const {
 // runs as a pipeline of stages over the wavefronts of a workgroup (fx_xlate.hpp StageInfo).  Beyond two wavefronts of instances
 // per SIMD the plain program has always been the faster one.  FX_STAGES pins the number asked for (1 = never).
 bool Batch::stagingPossible() const {
+    if (stagingOff_) return false;
     if (const char* knob = std::getenv("FX_STAGES")) return std::atoi(knob) >= 2;
     return (n_ + 63) / 64 < 2048;
 }
@@ -280,6 +281,7 @@ bool Batch::stagingPossible() const {
 std::vector<Batch::StageOption> Batch::rankStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
                                                   const XlateProgram& xprog, int nRows, int blockClass, int wavesPerSimdCap) const {
     std::vector<StageOption> out;
+    if (stagingOff_) { out.push_back(StageOption()); return out; }
     if (const char* knob = std::getenv("FX_STAGES")) {
         StageOption o;
         o.wanted = std::max(1, std::min(16, std::atoi(knob)));
@@ -1370,6 +1372,14 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
         }
     }
     if (e == hipSuccess && !untimed_) e = hipEventRecord(ev1_, s);
+    if (e != hipSuccess && c_.useXlate && c_.stages > 1 && !stagingOff_) {
+        // a workgroup of several wavefronts that the device will not start (registers x wavefronts beyond a CU, LDS): the plain
+        // program runs everywhere - no stages for this handle from now on, and this block again
+        (void)hipGetLastError();
+        stagingOff_ = true;
+        lowDirty_ = true;
+        return processDevice(dIn, dOut, nSamples, stream);
+    }
     if (e != hipSuccess) return hipFail(e, "launch fx_step_block");
     launched_ = !untimed_;  // (an untimed launch is synchronised by its caller before anything else happens)
     timed_ = !untimed_;

@@ -208,6 +208,7 @@ private:
 
     // ---- how many stages (rankStages: the planner's costs; noteLaunchTime: options the model cannot tell apart are measured)
     bool stagingPossible() const;
+    bool stagingOff_ = false;                    // a staged launch failed to start on this device: the plain program from then on
     std::vector<StageOption> rankStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& xprog,
                                         int nRows, int blockClass, int wavesPerSimdCap) const;
     static constexpr double kTuneBand = 1.6;     // options predicted within this factor of the cheapest are tried
