@@ -320,6 +320,13 @@ class Emitter {
         if (text_) line("ds_read2_b32 v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], v" + std::to_string(vaddr) +
              (dword0 ? " offset0:" + std::to_string(dword0) : "") + " offset1:" + std::to_string(dword1));
     }
+    void dsWrite2B32(int vaddr, int vdata0, int vdata1, uint32_t dword0, uint32_t dword1) {
+        w_.push_back(0xd8000000u | (0x0eu << 17) | (dword1 << 8) | dword0);
+        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata0 << 8) | ((uint32_t)vdata1 << 16));
+        ++count_;
+        if (text_) line("ds_write2_b32 v" + std::to_string(vaddr) + ", v" + std::to_string(vdata0) + ", v" + std::to_string(vdata1) +
+             (dword0 ? " offset0:" + std::to_string(dword0) : "") + " offset1:" + std::to_string(dword1));
+    }
     void dsReadB32(int vdst, int vaddr, uint32_t offset) {
         w_.push_back(0xd8000000u | (0x36u << 17) | (offset & 0xffffu));
         w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
@@ -622,7 +629,7 @@ class Translator {
             // the rows the previous stage handed over for this sample were read into spare registers one step ago; the
             // next sample's are requested now and land behind this step's work (StageInfo).  (Younger than that request:
             // the packet written at the end of the last step, which the next barrier's wait covers.)
-            e_.waitLgkm((int)G.sendRows.size());
+            e_.waitLgkm(packetOps(G.sendRows.size(), G.sendOff - G.ptrBias, -1));
             for (size_t i = 0; i < G.recvRows.size(); ++i) {
                 int v;
                 if (!row((uint32_t)G.recvRows[i], &v)) { if (err) *err = err_; return false; }
@@ -738,11 +745,15 @@ class Translator {
             // wavefronts of the workgroup execute the same number of them).  The wait in front of it covers LAST step's writes
             // and this step's request - everything but the writes just issued.
             // (an exact stream's packets may hold non-finite values: its flag row tells the next stage, before the packets do)
-            if (!fast_ && G.index + 1 < G.count) e_.dsWriteB32(kVLane4, kVClassMask, G.flagBase + 256u * (uint32_t)G.index);
-            for (size_t i = 0; i < G.sendRows.size(); ++i) {
-                int v;
-                if (!row((uint32_t)G.sendRows[i], &v)) { if (err) *err = err_; return false; }
-                e_.dsWriteB32(kVRing, v, G.bufBase + G.sendOff + 256u * (uint32_t)i);
+            if (!fast_ && G.index + 1 < G.count) flagAccess(false, kVClassMask, G.flagBase + 256u * (uint32_t)G.index, 5);
+            {
+                std::vector<int> regs;
+                for (size_t i = 0; i < G.sendRows.size(); ++i) {
+                    int v;
+                    if (!row((uint32_t)G.sendRows[i], &v)) { if (err) *err = err_; return false; }
+                    regs.push_back(v);
+                }
+                packetIo(false, regs, G.sendOff - G.ptrBias);
             }
             ringStep(kVRing);
         }
@@ -753,13 +764,13 @@ class Translator {
             if (G.group > 1) {
                 e_.sop2(SOP2_SUB_U32, "s_sub_u32", sreg(kSGroupLeft), sreg(kSGroupLeft), imm32(1));   // SCC = borrow: this was the group's last sample
                 Emitter::Fixup within = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
-                if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
+                if (!G.sendRows.empty()) e_.waitLgkm(packetOps(G.sendRows.size(), G.sendOff - G.ptrBias, -1));
                 e_.barrier();
                 e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupLeft), imm32((uint32_t)G.group - 1u));
                 if (!isLast_ && !stageFlagCheck(1)) { if (err) *err = err_; return false; }
                 e_.bind(within);
             } else {
-                if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
+                if (!G.sendRows.empty()) e_.waitLgkm(packetOps(G.sendRows.size(), G.sendOff - G.ptrBias, -1));
                 e_.barrier();
                 if (!isLast_ && !stageFlagCheck(1)) { if (err) *err = err_; return false; }
             }
@@ -787,7 +798,7 @@ class Translator {
             Emitter::Fixup within = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
             // the group's barrier: ONE per `group` samples in every wavefront of the workgroup (they all count from 0).  The
             // wait in front of it covers the packets of the previous samples - everything but the writes just issued
-            if (!G.sendRows.empty()) e_.waitLgkm((int)G.sendRows.size());
+            if (!G.sendRows.empty()) e_.waitLgkm(packetOps(G.sendRows.size(), G.sendOff - G.ptrBias, -1));
             e_.barrier();
             e_.sop1(SOP1_MOV_B32, "s_mov_b32", sreg(kSGroupSamples), imm32((uint32_t)G.group));
             if (!stageFlagCheck(1)) { if (err) *err = err_; return false; }
@@ -847,11 +858,11 @@ class Translator {
                 // this stage's flag row: clean so far (the next stage first reads it behind its last barrier in front of its first
                 // sample - behind this wavefront's first barrier, whichever that is)
                 e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), imm32(0));
-                e_.dsWriteB32(kVLane4, 2, G.flagBase + 256u * (uint32_t)G.index);
+                flagAccess(false, 2, G.flagBase + 256u * (uint32_t)G.index, 3);
                 e_.waitLgkm0();
             }
             // (the ring has 4 * group buffers: fewer than stages when the LDS budget allows only a group of one or two)
-            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVRing, imm32(((uint32_t)G.index % (4u * (uint32_t)G.group)) * G.bufStride), kVLane4);
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", kVRing, imm32(((uint32_t)G.index % (4u * (uint32_t)G.group)) * G.bufStride + G.ptrBias), kVLane4);
             for (int k = 0; k + 1 < kStageDepth * G.index; ++k) e_.barrier();
             if (G.index > 0) {
                 if (!G.recvRows.empty()) stageRequest();
@@ -961,7 +972,7 @@ class Translator {
         const StageInfo& G = prog_.stage;
         if (G.index == 0) return true;
         if (!fast_) { returns_[syncIndex(key)] = base_ + (uint32_t)e_.bytes(); return true; }
-        e_.dsReadB32(2, kVLane4, G.flagBase + 256u * (uint32_t)(G.index - 1));
+        flagAccess(true, 2, G.flagBase + 256u * (uint32_t)(G.index - 1), 3);
         e_.waitLgkm0();
         e_.vopc(VOPC_CMP_NE_U32, "v_cmp_ne_u32_e32", imm32(0), 2);
         e_.sop2(SOP2_OR_B64, "s_or_b64", sreg64(kSTaint), sreg64(kSTaint), named(106, "vcc"));
@@ -972,7 +983,48 @@ class Translator {
     // its sample s + 1 (from the cut in front of it) share one buffer index, s + k + 1 - one pointer, stepped once per sample.
     void stageRequest() {
         const StageInfo& G = prog_.stage;
-        for (size_t i = 0; i < G.recvRows.size(); ++i) e_.dsReadB32(G.recvTmp + (int)i, kVRing, G.bufBase + G.recvOff + 256u * (uint32_t)i);
+        std::vector<int> regs;
+        for (size_t i = 0; i < G.recvRows.size(); ++i) regs.push_back(G.recvTmp + (int)i);
+        packetIo(true, regs, G.recvOff - G.ptrBias);
+    }
+    // The rows of a packet, regs[i] <-> LDS row at kVRing + bufBase + rel + 256 i.  Two neighbouring rows go in ONE ds_read2_b32 /
+    // ds_write2_b32 where both dword offsets fit its 8-bit fields (the ring at LDS address 0: StageInfo::ptrBias) - a read2's
+    // destination is a register pair, even-aligned on gfx950.  packetOps: how many instructions that makes (the counted
+    // s_waitcnt lgkmcnt of the protocol count instructions, not rows).
+    static bool pairable(uint32_t byteOff) { return (byteOff & 3u) == 0 && byteOff / 4u + 64u <= 255u; }
+    int packetOps(size_t rows, uint32_t rel, int firstReg) const {   // firstReg: of a read's consecutive destination registers, -1 for writes
+        const StageInfo& G = prog_.stage;
+        int ops = 0;
+        for (size_t i = 0; i < rows;) {
+            const uint32_t off = G.bufBase + rel + 256u * (uint32_t)i;
+            const bool two = i + 1 < rows && pairable(off) && (firstReg < 0 || ((firstReg + (int)i) & 1) == 0);
+            i += two ? 2 : 1;
+            ++ops;
+        }
+        return ops;
+    }
+    void packetIo(bool load, const std::vector<int>& regs, uint32_t rel) {
+        const StageInfo& G = prog_.stage;
+        for (size_t i = 0; i < regs.size();) {
+            const uint32_t off = G.bufBase + rel + 256u * (uint32_t)i;
+            const bool two = i + 1 < regs.size() && pairable(off) && (!load || ((regs[i] & 1) == 0 && regs[i + 1] == regs[i] + 1));
+            if (two && load) e_.dsRead2B32(regs[i], kVRing, off / 4u, off / 4u + 64u);
+            else if (two) e_.dsWrite2B32(kVRing, regs[i], regs[i + 1], off / 4u, off / 4u + 64u);
+            else if (load) e_.dsReadB32(regs[i], kVRing, off);
+            else e_.dsWriteB32(kVRing, regs[i], off);
+            i += two ? 2 : 1;
+        }
+    }
+    // a flag row (lane * 4 + offset): behind a ring at address 0 the offset can be beyond the 16 bits of a DS instruction
+    void flagAccess(bool load, int vreg_, uint32_t offset, int vtmp) {
+        int addr = kVLane4;
+        if (offset > 0xffffu) {
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", vtmp, imm32(offset), kVLane4);
+            addr = vtmp;
+            offset = 0;
+        }
+        if (load) e_.dsReadB32(vreg_, addr, offset);
+        else e_.dsWriteB32(addr, vreg_, offset);
     }
     // PCM input in bursts of eight samples (StageInfo::inRing).  inputBurst(first, initial): loads of samples s + first ..
     // s + first + 7 (s = the current sample, s3) into the "next" half, each only if it exists; the initial one is waited for.
@@ -3306,18 +3358,31 @@ bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t
     uint32_t pow2 = 256u;
     while (pow2 < bufStride) pow2 <<= 1;
     L->bufStride = pow2;
-    L->flagBase = (tableBytes + 255u) & ~255u;
-    L->bufBase = L->flagBase + 256u * (uint32_t)K;
-    L->scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0), behind the ring
+    L->scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0)
     int group = kStageGroupMax;
     while (group > 1 && group > maxGroup) group /= 2;
     if (const char* knob = std::getenv("FX_STAGES_GROUP")) {   // tests: a shorter ring than the LDS would allow (1, 2, 4)
         const int g = std::atoi(knob);
         if (g == 1 || g == 2 || g == 4) group = g;
     }
-    while (group > 1 && L->bufBase + 4u * (uint32_t)group * L->bufStride + L->scratchBytes > ldsBudget) group /= 2;
+    // without tables the ring lies at address 0 (the pointer's and-mask needs no base: StageInfo::ptrBias), flag rows and scratch
+    // behind it; with tables: [tables][flags][ring][scratch]
+    static const bool pairOff = std::getenv("FX_XLATE_LDS2") && std::atoi(std::getenv("FX_XLATE_LDS2")) == 0;   // diagnostics
+    L->ringFirst = tableBytes == 0 && !pairOff;
+    const uint32_t fixed = ((tableBytes + 255u) & ~255u) + 256u * (uint32_t)K + L->scratchBytes;
+    while (group > 1 && fixed + 4u * (uint32_t)group * L->bufStride > ldsBudget) group /= 2;
     L->group = group;
-    L->bytes = L->bufBase + 4u * (uint32_t)group * L->bufStride + L->scratchBytes;
+    const uint32_t ring = 4u * (uint32_t)group * L->bufStride;
+    if (L->ringFirst) {
+        L->bufBase = 0;
+        L->flagBase = ring;
+        L->scratchOff = ring + 256u * (uint32_t)K;
+    } else {
+        L->flagBase = (tableBytes + 255u) & ~255u;
+        L->bufBase = L->flagBase + 256u * (uint32_t)K;
+        L->scratchOff = L->bufBase + ring;
+    }
+    L->bytes = fixed + ring;
     return !(L->bufBase + L->bufStride > 0xff00u || L->bytes > std::min(ldsBudget, 160u * 1024u));
 }
 
@@ -3331,7 +3396,7 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     StageLds L;
     if (!stageLdsLayout(program, plan, ldsBudget, maxGroup, &L)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
     const std::vector<uint32_t>& cutOff = L.cutOff;
-    const uint32_t bufStride = L.bufStride, flagBase = L.flagBase, bufBase = L.bufBase, scratchBytes = L.scratchBytes;
+    const uint32_t bufStride = L.bufStride, flagBase = L.flagBase, bufBase = L.bufBase;
     const int group = L.group;
     std::vector<std::vector<uint32_t>> code((size_t)K * 4 + 1);
     std::vector<std::string> listing((size_t)K * 4 + 1);
@@ -3366,6 +3431,7 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
         p.stage.group = group;
         if (k > 0) { p.stage.recvRows = plan.live[(size_t)k - 1]; p.stage.recvOff = cutOff[(size_t)k - 1]; }
         if (k + 1 < K) { p.stage.sendRows = plan.live[(size_t)k]; p.stage.sendOff = cutOff[(size_t)k]; }
+        p.stage.ptrBias = L.ringFirst ? (k > 0 ? p.stage.recvOff : p.stage.sendOff) : 0u;
         p.stage.storeMask = 0;
         for (size_t c = 0; c < plan.pcmStage.size(); ++c)
             if (plan.pcmStage[c] == k) p.stage.storeMask |= 1u << c;
@@ -3416,8 +3482,8 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
     }
     // the run-once code: tables of the whole program, the hoist decision of stage 0
     out->initOff = 0;
-    out->ldsBytes = bufBase + 4u * (uint32_t)group * bufStride + scratchBytes;
-    for (StageDescriptor& d : out->stageDesc) d.scratchOff = bufBase + 4u * (uint32_t)group * bufStride;
+    out->ldsBytes = L.bytes;
+    for (StageDescriptor& d : out->stageDesc) d.scratchOff = L.scratchOff;
     {
         XlateProgram initProg = program;
         initProg.hoist = stage0Hoist;

@@ -87,6 +87,11 @@ struct StageInfo {
     uint32_t recvOff = 0, sendOff = 0;    // LDS byte offset of those packets inside a buffer (row i at +256 i)
     uint32_t bufBase = 0, bufStride = 0;  // the 4 * group buffers: bufBase + (sample mod (4 * group)) * bufStride (stride a power of two)
     uint32_t flagBase = 0;                // LDS rows [stage][lane]: non-zero = that stage runs its exact stream (its packets may hold non-finite values)
+    // A stage's ring pointer (kVRing) is lane * 4 + ptrBias + buffer * bufStride, and its packet accesses are offsets from there.
+    // Where the ring lies at LDS address 0 (programs without LOG / EXP tables in LDS: stageLdsLayout), ptrBias = the byte offset
+    // of the stage's received rows inside a buffer (stage 0: of the rows it sends): the first rows of a packet are then within
+    // the 255-dword reach of ds_read2_b32 / ds_write2_b32 and go two per instruction.
+    uint32_t ptrBias = 0;
     uint32_t storeMask = ~0u;             // channels whose PCM output this stage stores
     int group = 1;                        // samples between two barriers (a power of two); the ring has 4 * group buffers
     // Latencies stay off the step (a step = the `group` samples between two barriers): stage k runs 3k steps behind stage 0.
@@ -194,8 +199,9 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
 // largest group of 8, 4, 2, 1 - at most maxGroup - whose ring of 4 * group buffers fits the budget); false: not even one fits
 struct StageLds {
     std::vector<uint32_t> cutOff;   // byte offset of cut c's rows inside a buffer
-    uint32_t bufStride = 0, flagBase = 0, bufBase = 0, scratchBytes = 0, bytes = 0;
+    uint32_t bufStride = 0, flagBase = 0, bufBase = 0, scratchBytes = 0, scratchOff = 0, bytes = 0;
     int group = 1;
+    bool ringFirst = false;         // [ring][flags][scratch] instead of [tables][flags][ring][scratch]
 };
 bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* out);
 
