@@ -19,8 +19,12 @@
  * says why; a failed launch returns a negative code and fxb_last_error() the text.
  *
  * Conventions: plain pointers and sizes only; the caller owns every buffer it passes; the
- * library owns the handle and all device state; a handle is not thread-safe, distinct
- * handles are independent.  Return codes: the reference's own where one exists (noted per
+ * library owns the handle and all device state; a handle is not thread-safe - one thread at a
+ * time, as with the reference's objects (include/FX8010.h:162-217: plain members, no lock); calls
+ * that reach a multi-device handle from two threads are serialised, not made independent - and
+ * distinct handles are independent.  A handle may own a builder thread of its own (code generated
+ * ahead of time, FXB_INFO_XLATE_BACKGROUND_BUILDS); the environment's FX_* knobs are read when
+ * code is generated: do not change the environment while a handle exists.  Return codes: the reference's own where one exists (noted per
  * function), otherwise 0 = ok and <0 = FX_E_*.
  */
 #ifndef FX8010_AMD_H
