@@ -268,7 +268,9 @@ class ClockSampler:
             return None, None
         self._stop.set()
         self._thread.join()
-        samples = self.samples[1:] if len(self.samples) >= 3 else self.samples   # (the first reading still shows the clock of the idle chip)
+        # (the first readings still show the clock of the idle chip ramping up: the first fifth of a short run's samples is left out)
+        skip = max(1, len(self.samples) // 5) if len(self.samples) >= 3 else 0
+        samples = self.samples[skip:]
         f = [a for a, _ in samples if a]
         w = [b for _, b in samples if b]
         return (round(sum(f) / len(f) / 1e6, 1) if f else None), (round(sum(w) / len(w) / 1e6, 1) if w else None)
