@@ -25,10 +25,6 @@ bool asmEligible(const Lowered& low, std::string* why) {
     auto no = [&](const char* w) { if (why) *why = w; return false; };
     if (low.instPerLane != 1) return no("more than one instance per lane");
     if (low.multipass) return no("END can be skipped (multi-pass program)");
-    if (low.tramDane)  // the translated tier generates the opt-in DANE taps inline when their positions are uniform; the interpreter has no handlers for it
-        for (const MicroOp& m : low.steady)
-            if (handlerOf(m) >= H_TRAM_IR && handlerOf(m) <= H_TRAM_XW && !has(m, F_UY) && !has(m, F_TRAM_SHIFT))
-                return no("DANE delay-line tap with a per-instance position in whole samples (HIP C++ kernel)");
     if (low.rowPitch != 1 && (size_t)low.nRows * 256 > 64 * 1024) return no("register file above 64 KiB of LDS");
     if (low.rowPitch == 1 && low.nRows > kAsmVgprRows[ASM_V256]) return no("register file above 224 VGPR rows");
     for (const MicroOp& m : low.steady) {
@@ -87,7 +83,7 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
         r.w[4] = m.w[4];
         r.w[5] = m.w[1];               // destination row
         r.w[6] = kind | (ccr << 3);    // flags of the generic handlers
-        if (has(m, F_TRAM_DANE)) r.w[6] |= 16u | (has(m, F_TRAM_SHIFT) ? 32u : 0u) | (has(m, F_TRAM_INTERP) ? 64u : 0u);  // (translated tier only)
+        if (has(m, F_TRAM_DANE)) r.w[6] |= 16u | (has(m, F_TRAM_SHIFT) ? 32u : 0u) | (has(m, F_TRAM_INTERP) ? 64u : 0u);  // (opt-in DANE taps)
         uint32_t slot = AS_NOP;
         switch (h) {
             case H_MACS:

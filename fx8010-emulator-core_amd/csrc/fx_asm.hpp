@@ -38,7 +38,7 @@ struct AsmArgs {
     const uint32_t* tracks;  // translated programs with control tracks: the block's TrackEvent list + values (fx_xlate.hpp), else nullptr
     const uint32_t* stages;  // translated programs cut into stages: StageDescriptor[nStages] (fx_xlate.hpp), else nullptr
     int nStages;             // wavefronts per workgroup (0 / 1: the whole program in one)
-    int pad0;
+    int tramDane;            // interpreter builds: the opt-in DANE delay-line model is in force (the address counters step once per sample period)
 };
 static_assert(offsetof(AsmArgs, lut) == 0x40, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, nLoad) == 0x58, "AsmArgs layout");
@@ -52,6 +52,7 @@ static_assert(offsetof(AsmArgs, lutX1Off) == 0xb0, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, tracks) == 0xb8, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, stages) == 0xc0, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, nStages) == 0xc8, "AsmArgs layout");
+static_assert(offsetof(AsmArgs, tramDane) == 0xcc, "AsmArgs layout");
 static_assert(sizeof(AsmArgs) == 0xd0, "AsmArgs layout");
 
 // handler slots of fx_interp_gfx950.S (fx_interp_table.inc)

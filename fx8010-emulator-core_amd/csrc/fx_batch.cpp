@@ -121,7 +121,6 @@ int Batch::afterLoad(bool ok) {
     laneWritten_.resize(prog_.regs.size(), 0);
     for (size_t r = old; r < prog_.regs.size(); ++r) hostValue_[r] = prog_.regs[r].value;
     lowDirty_ = true;
-    daneHipOnly_ = false;
     // code generated for the program as it was is of no use any more (registers and instructions accumulate over loads)
     clearCodeCache();
     ++loadGen_;
@@ -353,7 +352,7 @@ std::string Batch::codeKey(int blockClass, bool defer) const { return codeKeyFor
 std::string Batch::codeKeyFor(const std::vector<uint8_t>& forced, int blockClass, bool defer, int pick) const {
     std::string k;
     auto word = [&](int64_t v) { k.append(reinterpret_cast<const char*>(&v), 8); };
-    word(loadGen_); word((int64_t)prog_.options); word(blockClass); word(pick); word(defer ? 1 : 0); word(daneHipOnly_ ? 1 : 0);
+    word(loadGen_); word((int64_t)prog_.options); word(blockClass); word(pick); word(defer ? 1 : 0);
     word(((iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0) && instPerLane_ != 1) ? instPerLane_ : 0);   // delay lines tiled for K instances per lane pin the HIP C++ kernel
     for (const char* name : {"FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_STAGES_GROUP"}) {
         const char* v = std::getenv(name);
@@ -468,10 +467,6 @@ int Batch::ensureLowered() {
     }
     std::string err;
     const int rc = buildCodeInto(c_, buildInputs(key, blockClass, defer), false, &err);
-    if (rc == FX_E_RETRY_) {   // (a DANE-model program the translator could not take: the HIP C++ kernel from now on)
-        stashCode();
-        return ensureLowered();
-    }
     if (rc != 0) return fail(rc, err);
     lowDirty_ = false;
     adoptStageOptions();
@@ -757,7 +752,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
     bool asmOk = false;
     const bool tramPinned = iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0;
     const char* forceHip = std::getenv("FX_KERNEL");
-    const bool wantAsm = !(forceHip && std::strcmp(forceHip, "hip") == 0) && !std::getenv("FX_INST_PER_LANE") && !daneHipOnly_;
+    const bool wantAsm = !(forceHip && std::strcmp(forceHip, "hip") == 0) && !std::getenv("FX_INST_PER_LANE");
     if (wantAsm && (!tramPinned || instPerLane_ == 1)) {
         // first choice: register file in VGPRs (row pitch 1 = plain indices), else in LDS
         const bool tryVgpr = !(forceHip && std::strcmp(forceHip, "asm_lds") == 0);
@@ -795,11 +790,6 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
             fresh = lowerProgram(prog_, in.hostValue, in.forced, 1, false);
             asmOk = fresh.error.empty() && asmEligible(fresh, &c.asmWhyNot);
             c.variant = ASM_LDS;
-        }
-        // the opt-in DANE delay-line model exists as generated code (translated tier) and in the HIP C++ kernel only
-        if (asmOk && fresh.tramDane && (c.variant == ASM_LDS || (forceHip && std::strncmp(forceHip, "asm", 3) == 0))) {
-            asmOk = false;
-            c.asmWhyNot = "opt-in DANE delay-line model: no interpreter handlers";
         }
     } else {
         c.asmWhyNot = "disabled by FX_KERNEL / FX_INST_PER_LANE";
@@ -900,11 +890,6 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
             c.stageStoreRows = image.stageStoreRows;
             c.useXlate = true;
         }
-    }
-    if (c.useAsm && !c.useXlate && c.low.tramDane) {  // (translation failed: e.g. code larger than the hole) -> HIP C++ kernel
-        if (offline) return fail(FX_E_NOTREADY, "offline build: the translation failed");
-        daneHipOnly_ = true;   // (part of the key: the next round of ensureLowered builds for the HIP C++ kernel)
-        return FX_E_RETRY_;
     }
     if (offline && !c.useXlate) return fail(FX_E_NOTREADY, "offline build: the translation failed (" + c.xlateWhyNot + ")");
     if (c.useAsm && !c.useXlate) {
@@ -1353,6 +1338,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             g.cursorRow = stateLayout_.cursorBase; g.noiseRow = stateLayout_.noiseBase;
             g.oodRow = a.oodRow; g.countLo = a.countLo; g.countHi = a.countHi; g.staticCount = a.staticCount;
             g.lutX1Off = kLutX1Off * 8;
+            g.tramDane = (c_.low.tramDane && (c_.low.usesITram || c_.low.usesXTram)) ? 1 : 0;   // (like the other tiers: counters step where the program has taps)
             if (c_.useXlate) {
                 // code streams are named by their byte offset from the kernel entry: {fast, exact} per argument
                 g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)c_.steady);

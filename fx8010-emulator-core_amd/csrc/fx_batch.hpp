@@ -197,7 +197,6 @@ private:
         int stagePick = 0;                       // stages to ask the planner for; 0: the cheapest by its costs (rankStages)
     };
     BuildInputs buildInputs(const std::string& key, int blockClass, bool defer) const;
-    static constexpr int FX_E_RETRY_ = -1000;    // internal: build again (the key has changed)
     int buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::string* err);
     int wantedClass_ = -1;                       // block-length class the code should be for (sticky: see processDevice)
     bool readByProgram(int reg) const;
@@ -240,7 +239,6 @@ private:
     int controlHeat_ = 0;
     int pendingSamples_ = 0;  // block length of the call that triggered the lowering
     bool everLowered_ = false;
-    bool daneHipOnly_ = false;  // a DANE-model program that the translator could not take: HIP C++ kernel from now on
     double* dLut_ = nullptr;
     // control tracks (fx_xlate.hpp TrackEvent): registers the generated loop can re-load by itself, and what is armed
     struct PendingTrack { int period = 0, steps = 0; bool perInstance = false; std::vector<float> values; };

@@ -97,7 +97,7 @@ struct Lowered {
     int nShadowed = 0, nCcrLive = 0;
     int tramOpsPerSample = 0;
     bool multipass = false;
-    bool tramDane = false;        // the opt-in DANE delay-line model is in force (only the HIP C++ kernel implements it)
+    bool tramDane = false;        // the opt-in DANE delay-line model is in force
     bool usesNoise = false, usesITram = false, usesXTram = false, usesLut = false;
     int iSlots = 0, xSlots = 0;  // TRAM slots to allocate per instance
     std::string error;            // non-empty: cannot be lowered

@@ -86,6 +86,7 @@
 	.set KA_TRACKS,   0xb8      // translated programs: control tracks of this block (fx_batch.hpp TrackHeader[3] + values), 0 = none
 	.set KA_STAGES,   0xc0      // translated programs cut into stages (fx_xlate.hpp StageDescriptor[nStages], 32 bytes each), 0 = none
 	.set KA_NSTAGES,  0xc8      // wavefronts per workgroup = stages of the program (0 or 1: one wavefront runs all of it)
+	.set KA_TRAMDANE, 0xcc      // interpreter builds: 1 = the opt-in DANE delay-line model (address counters step once per sample period)
 	.set KA_SIZE,     0xd0
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
@@ -108,6 +109,7 @@
 //  s[52:55] latch row offsets  s56 iSize  s57 xSize  s[58:59] lanes with instance < N  s60 state row pitch (nPad*4)
 //  s61 byte offset of x1[] in the LUT blob  s62-s67 temporaries  s68 bytes per channel-sample (N*4)
 //  s[72:73] row table  s74 nLoad  s75 nStore  s76 cursor state row  s77 LFSR state row
+//  s70 (interpreter builds) opt-in DANE delay-line model in force
 
 	.text
 	.globl	KNAME
@@ -248,6 +250,7 @@ KNAME:
 	s_mov_b32 s54, 0
 #else
 	s_load_dwordx8  s[48:55], s[0:1], KA_INOFF            // inOff[4] latchOff[4]
+	s_load_dword    s70, s[0:1], KA_TRAMDANE
 #endif
 	s_load_dwordx4  s[64:67], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
 	s_load_dwordx2  s[76:77], s[0:1], KA_CURSORROW      // cursorRow noiseRow
@@ -691,6 +694,27 @@ h_endsample_d:
 	s_addc_u32 s13, s13, 0
 	s_add_u32 s14, s14, s45
 	s_addc_u32 s15, s15, 0
+	// opt-in DANE delay-line model (fx_kernel.hip daneStep): both address counters step down once per sample period, every lane
+	s_cmp_eq_u32 s70, 0
+	s_cbranch_scc1 .Le_counters
+	s_cmp_lt_i32 s56, 1
+	s_cbranch_scc1 .Le_xcounter
+	s_sub_i32 s62, s56, 1
+	v_cmp_ge_i32 vcc, 0, v16
+	v_subrev_u32 v5, 1, v16
+	v_mov_b32 v6, s62
+	s_nop 1
+	v_cndmask_b32 v16, v5, v6, vcc
+.Le_xcounter:
+	s_cmp_lt_i32 s57, 1
+	s_cbranch_scc1 .Le_counters
+	s_sub_i32 s62, s57, 1
+	v_cmp_ge_i32 vcc, 0, v18
+	v_subrev_u32 v5, 1, v18
+	v_mov_b32 v6, s62
+	s_nop 1
+	v_cndmask_b32 v18, v5, v6, vcc
+.Le_counters:
 	s_add_u32 s3, s3, 1
 	s_cmp_lt_i32 s3, s9
 	s_waitcnt vmcnt(0)

@@ -475,7 +475,7 @@ enum : uint32_t {
     SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
     SOP2_ADD_U32 = 0, SOP2_SUB_U32 = 1, SOP2_ADDC_U32 = 4,
     SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
-    VOP2_ASHRREV_I32 = 0x11, VOP1_FLOOR_F32 = 0x1f, VOP1_CVT_F32_I32 = 5, VOPC_CMP_EQ_U32_ = 0xca,
+    VOP2_ASHRREV_I32 = 0x11, VOP1_FLOOR_F32 = 0x1f, VOP1_CVT_F32_I32 = 5, VOPC_CMP_EQ_U32_ = 0xca, VOPC_CMP_GT_I32 = 0xc4,
 };
 
 // register conventions shared with fx_interp_gfx950.S
@@ -784,7 +784,7 @@ class Translator {
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(q + 1), sreg(q + 1), imm32(0));
         }
         if (!staged || ring) e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSample), sreg(kSSample), imm32(1));   // (a later stage counts down instead)
-        if (prog_.tramDane && prog_.uniformCursors) daneStep();
+        if (prog_.tramDane) { if (prog_.uniformCursors) daneStep(); else daneStepPerLane(); }
         if (oneCounter) {
             // s7 counts the samples up to the next event - the group's barrier or the end of the steady stream, whichever
             // comes first (s5 = what it was loaded with, s8 = samples of the group, s6 = steady samples still to run when it
@@ -1497,6 +1497,20 @@ class Translator {
         }
     }
 
+    // ... and where a tap's position is a per-instance value in whole samples the taps are the interpreter's handlers (called as
+    // subroutines, their DANE path: fx_interp_handlers.inc) and the counters are the lanes' own, v16 / v18: v <= 0 ? size - 1 : v - 1
+    void daneStepPerLane() {
+        for (int t = 0; t < 2; ++t) {
+            const int32_t size = t == 0 ? prog_.iSize : prog_.xSize;
+            if (size < 1) continue;
+            const int counter = kVCursor + 2 * t;
+            e_.vopc(VOPC_CMP_GT_I32, "v_cmp_gt_i32_e32", imm32(1), counter);
+            e_.vop2(VOP2_ADD_U32, "v_add_u32_e32", 5, imm32(0xffffffffu), counter);
+            e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(6), imm32((uint32_t)(size - 1)));
+            e_.sopp(SOPP_NOP, "s_nop", 0, true);
+            e_.vop2(VOP2_CNDMASK, "v_cndmask_b32_e32", counter, vreg(5), 6, ", vcc");
+        }
+    }
     // the low 11 bits of a uniform DANE address (FX_OPT_TRAM_INTERP: the weight of the next sample)
     static int32_t daneFraction(uint32_t bits) {
         float f;

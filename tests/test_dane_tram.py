@@ -149,11 +149,12 @@ end"""
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["default", "hip"])
+@pytest.mark.parametrize("kernel", ["default", "hip", "asm", "asm_lds", "asm_v256"])
 def test_gpu_interpolated_and_modulated_taps(gpu, kernel, monkeypatch):
     """FX_OPT_TRAM_INTERP on the device: taps with a fixed fractional position (two scalar slots per tap) and the chorus, whose
-    tap position is computed per instance and per sample - generated code gathers it per lane (fp32 modulo, exact below 2^23) -
-    against the oracle, on the translated tier and on the HIP C++ kernel"""
+    tap position is computed per instance and per sample - generated code gathers it per lane (fp32 modulo, exact below 2^23),
+    the interpreter's TRAM handlers take the per-lane path for every tap (fp64 modulo) - against the oracle, on the translated
+    tier, on the interpreter (register file in VGPRs and in LDS) and on the HIP C++ kernel"""
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
     monkeypatch.delenv("FX_KERNEL", raising=False)
     if kernel != "default":
@@ -174,7 +175,8 @@ def test_gpu_interpolated_and_modulated_taps(gpu, kernel, monkeypatch):
             b.set_register_array("depth", depth)
             b.set_register_array("speed", speed)
         y = np.concatenate([b.process_block(x[:1000]), b.process_block(x[1000:1001]), b.process_block(x[1001:])], axis=0)
-        assert (b.info("kernel") >= 9) == (kernel == "default"), (kernel, b.info("kernel"))
+        k = b.info("kernel")
+        assert {"default": k >= 9, "hip": k == 0, "asm": 2 <= k <= 8, "asm_lds": k == 1, "asm_v256": k == 8}[kernel], (kernel, k)
         assert b.ood_flags() == 0
         for inst in (0, 63, 64, 99, n - 1):
             o = Oracle(1)
@@ -212,8 +214,9 @@ def test_gpu_matches_the_oracle_in_the_dane_model(gpu, text, shift, monkeypatch)
     ys = [b.process_block(x[:1000]), b.process_block(x[1000:])]
     y = np.concatenate(ys, axis=0)
     # static taps are generated inline by the translator, and so are per-instance positions given as DANE addresses (the modulated
-    # chorus with the address shift: gathered per lane); per-instance positions in whole samples run on the HIP C++ kernel
-    assert (b.info("kernel") >= 9) == (text is TWO_TAPS or shift)
+    # chorus with the address shift: gathered per lane); with per-instance positions in whole samples the translated program calls
+    # the interpreter's tap handlers (fp64 modulo per lane) and steps the lanes' own counters
+    assert b.info("kernel") >= 9
     assert b.ood_flags() == 0
     for inst in (0, 63, 64, 99, n - 1):
         o = Oracle(1)
@@ -229,6 +232,52 @@ def test_gpu_matches_the_oracle_in_the_dane_model(gpu, text, shift, monkeypatch)
         assert b.instruction_counter_i(inst) == o.instruction_counter()
         for r in ("out", "ccr") + (("&rd1", "lfo") if text is CHORUS else ("&r1", "w")):
             assert b.get_register_bits_i(r, inst) == o.get_register_bits(r), (inst, r)
+
+
+EXTREME_POSITIONS = np.array([0.0, 1.0, -1.0, 63.0, 64.0, 65.0, -64.0, -65.0, 8388609.0, -8388609.0, 2147483520.0, -2147483648.0, 3.0e9,
+                              -3.0e9, 1.0e30, np.inf, -np.inf, np.nan, -5.5, 5.999, 0.99, -0.99, 1.0e-40, 499.0, 500.0, 12345678.0], dtype=np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [False, True], ids=["sample_positions", "dane_addresses"])
+@pytest.mark.parametrize("kernel", ["default", "hip", "asm", "asm_lds"])
+def test_gpu_tap_positions_at_the_edges_of_the_modulo(gpu, kernel, shift, monkeypatch):
+    """per-instance tap positions, read and write, on both lines: multiples of the line length, negative, beyond 2^23 (where an
+    fp32 modulo would no longer be exact), at the ends of int32 and beyond (cvttss2si gives 0x80000000), non-finite - the slot is
+    the C `(long)(counter + position) % size` of the oracle everywhere (interpreter: fp64 quotient by a refined reciprocal)"""
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    if kernel != "default":
+        monkeypatch.setenv("FX_KERNEL", kernel)
+    n, s = 130, 700
+    x = progs.stimulus(n, s)
+    pos = np.resize(EXTREME_POSITIONS, n).astype(np.float32)
+    if shift:   # DANE addresses: value * 2^31 >> 11; keep the interesting ones interesting
+        pos = np.where(np.isfinite(pos) & (np.abs(pos) < 3.0e6), pos * np.float32(2.0 ** -20), pos).astype(np.float32)
+    b = gpu.Batch(n, 1, 0)
+    b.set_option(gpu.OPT_TRAM_DANE)
+    if shift:
+        b.set_option(gpu.OPT_TRAM_ADDR_SHIFT)
+        b.set_option(gpu.OPT_TRAM_INTERP)
+    assert b.load_text(TWO_TAPS), b.errors()
+    for reg, roll in (("&r1", 0), ("&r2", 3), ("&xr", 7), ("&w", 11)):
+        b.set_register_array(reg, np.roll(pos, roll))
+    y = np.concatenate([b.process_block(x[:300]), b.process_block(x[300:])], axis=0)
+    k = b.info("kernel")
+    assert {"default": k >= 9, "hip": k == 0, "asm": 2 <= k <= 8, "asm_lds": k == 1}[kernel], (kernel, k)
+    for inst in range(0, n, 1 if kernel in ("asm", "asm_lds") else 3):
+        o = Oracle(1)
+        o.set_option(OPT_DANE)
+        if shift:
+            o.set_option(OPT_SHIFT)
+            o.set_option(OPT_INTERP)
+        assert o.load_text(TWO_TAPS)
+        for reg, roll in (("&r1", 0), ("&r2", 3), ("&xr", 7), ("&w", 11)):
+            o.set_register(reg, float(np.roll(pos, roll)[inst]))
+        ref = o.process_block(x[:, inst].copy())
+        assert np.array_equal(bits(ref), bits(y[:, inst])), (kernel, inst)
+        assert b.instruction_counter_i(inst) == o.instruction_counter()
+        assert b.get_cursors_i(inst) == o.cursors(), inst
 
 
 @pytest.mark.gpu
@@ -293,18 +342,22 @@ def test_static_multi_tap_line_translated_with_reads_a_sample_ahead(gpu, monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dane", [False, True], ids=["reference_model", "dane_model"])
-def test_delay_line_fuzz(gpu, dane, monkeypatch):
-    """tools/fuzz_tram.py, 150 programs per model: programs that start with a group of TRAM reads (issued a sample ahead by the
-    translated tier) on tiny lines - an early read meeting a later write of the same slot is the norm there -, balanced and
-    unbalanced read/write counts, offsets, several short blocks"""
+@pytest.mark.parametrize("mode, kernel", [("", None), ("dane", None), ("dane", "asm"), ("dane", "asm_lds"), ("dane_lanes", None), ("dane_lanes", "asm"),
+                                          ("dane_lanes", "asm_lds"), ("dane_lanes", "hip"), ("dane_shift", None), ("dane_shift", "asm"), ("dane_shift", "hip")])
+def test_delay_line_fuzz(gpu, mode, kernel, monkeypatch):
+    """tools/fuzz_tram.py, 150 programs per model and tier: programs that start with a group of TRAM reads (issued a sample ahead by
+    the translated tier) on tiny lines - an early read meeting a later write of the same slot is the norm there -, balanced and
+    unbalanced read/write counts, offsets, several short blocks; in the DANE model also with per-instance tap positions (whole
+    samples: negative, multiples of the line, beyond int32, non-finite; DANE addresses with interpolated reads)"""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_tram
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
-    monkeypatch.setattr(sys, "argv", ["fuzz_tram.py", "5000", "150"] + (["dane"] if dane else []))
+    if kernel:
+        monkeypatch.setenv("FX_KERNEL", kernel)
+    monkeypatch.setattr(sys, "argv", ["fuzz_tram.py", "5000", "150"] + ([mode] if mode else []))
     assert fuzz_tram.main() == 0
 
 

@@ -24,7 +24,7 @@ def _asan_runtime():
 
 @pytest.mark.parametrize("variant", ["O0", "O3", "clang", "asan"])
 def test_fixtures_pass_on_every_build(variants, variant):
-    env = dict(os.environ, FXORACLE_SO=os.path.join(variants, "libfxoracle_%s.so" % variant))
+    env = dict(os.environ, FXORACLE_SO=os.path.join(variants, "libfxoracle_%s.so" % variant), FXORACLE_LIVE_CASES="60")
     if variant == "asan":
         rt = _asan_runtime()
         if rt is None:

@@ -1,7 +1,13 @@
 """Live differential test: the C restatement against the compiled reference (oracle/_ref), on
 randomly generated in-domain programs.  Runs wherever oracle/_ref/libfxref.so exists."""
+import os
+
 import numpy as np
 import pytest
+
+# programs per generator run live against the compiled reference; the compiler-variant runs of test_oracle_variants.py (four more
+# passes over this file, one of them under AddressSanitizer) take a fifth of them
+LIVE_CASES = int(os.environ.get("FXORACLE_LIVE_CASES", "300"))
 
 import fx8010_programs as progs
 from pyoracle import Oracle, Reference
@@ -38,7 +44,7 @@ def random_program(rng, n_instr):
     return "\n".join(L)
 
 
-@pytest.mark.parametrize("seed", range(300))
+@pytest.mark.parametrize("seed", range(LIVE_CASES))
 def test_random_programs(seed):
     rng = np.random.default_rng(1000 + seed)
     text = random_program(rng, int(rng.integers(5, 60)))
@@ -54,7 +60,7 @@ def test_random_programs(seed):
             assert o.get_register_bits(reg) == r.get_register_bits(reg), (reg, text)
 
 
-@pytest.mark.parametrize("seed", range(300))
+@pytest.mark.parametrize("seed", range(LIVE_CASES))
 def test_random_programs_with_nonfinite_input(seed):
     """NaN (either sign, payloads, signalling) and Inf words sprinkled over the input: which payload survives each instruction is
     the x86 operand order the restatement spells out (sse_pick32/64); strict bit compare against the compiled reference."""
@@ -86,7 +92,7 @@ def test_stereo_input_quirk_against_reference():
     assert np.array_equal(o.process_block(x).view(np.uint32), r.process_block(x).view(np.uint32))
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(max(LIVE_CASES // 5, 1)))
 def test_the_fuzzers_programs_against_reference(seed):
     """the program generators of the GPU fuzzers (tools/stress_fuzz.py: all opcodes, delay lines, SKIP shadows, LOG / EXP with
     uniform and per-lane operands, literals as destinations) - what the GPU path is compared with the restatement on - through the

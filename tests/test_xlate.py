@@ -246,6 +246,18 @@ def test_dane_model_listing_reassembles_and_has_no_cursor_advance():
     assert listing.count("s_sub_i32 s82, s82, 1") == 1     # one step of the xTRAM counter per sample, nothing per instruction
     fe2 = A.FrontEnd(1)
     assert not fe2.load_text(P.CONFIGS["config5_dane"]().replace("at, 1187", "at, &d0"))  # without the option: reference syntax only
+    # a tap whose position is a per-instance value in whole samples: the taps are the interpreter's handlers (their DANE path),
+    # called as subroutines, and the counters step per lane
+    chorus = ("itramsize 2880 \ninput in 0\noutput out 0\nstatic rd1\nstatic lfo = 0.25\ncontrol depth = 0.4\nidelay write, in, at, 0\n"
+              "idelay read, rd1, at, 1439\nmacs lfo, lfo, 0.01, 0.3\nmacs &rd1, 0.5, lfo, depth\nmacs out, 0, rd1, 0.5\nend")
+    fe3 = A.FrontEnd(1)
+    fe3.set_option(A.OPT_TRAM_DANE)
+    assert fe3.load_text(chorus), fe3.errors()
+    for stream in (0, 1, 2, 3):
+        code, listing = fe3.translate(0, stream)
+        assert assemble(listing) == code
+        assert listing.count("v_cmp_gt_i32_e32 vcc, 1, v16") == 1 and "v_cmp_gt_i32_e32 vcc, 1, v18" not in listing   # (no xTRAM in this program)
+        assert "s_sub_i32 s80, s80, 1" not in listing
 
 
 def test_translate_reports_ineligible_programs():

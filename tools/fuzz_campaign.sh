@@ -30,6 +30,12 @@ run "stereo"                   timeout -k 10 900 python3 tools/fuzz_stereo.py 20
 run "delay lines"              timeout -k 10 900 python3 tools/fuzz_tram.py 2000000 $((3000*K))
 run "delay lines x3"           FX_FUZZ_SCALE=3 timeout -k 10 900 python3 tools/fuzz_tram.py 2100000 $((3000*K))
 run "delay lines DANE"         timeout -k 10 900 python3 tools/fuzz_tram.py 2200000 $((3000*K)) dane
+run "delay lines DANE lanes"   timeout -k 10 900 python3 tools/fuzz_tram.py 2300000 $((2000*K)) dane_lanes
+run "delay lines DANE shift"   timeout -k 10 900 python3 tools/fuzz_tram.py 2400000 $((2000*K)) dane_shift
+run "DANE interpreter"         FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_tram.py 2500000 $((1500*K)) dane_lanes
+run "DANE interpreter shift"   FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_tram.py 2600000 $((1500*K)) dane_shift
+run "DANE interpreter (LDS)"   FX_KERNEL=asm_lds timeout -k 10 900 python3 tools/fuzz_tram.py 2700000 $((1000*K)) dane_lanes
+run "DANE HIP kernel"          FX_KERNEL=hip timeout -k 10 900 python3 tools/fuzz_tram.py 2800000 $((1000*K)) dane_lanes
 run "product cache"            timeout -k 10 900 python3 tools/fuzz_cse.py 2000000 $((4000*K))
 run "product cache x3"         FX_FUZZ_SCALE=3 timeout -k 10 900 python3 tools/fuzz_cse.py 2100000 $((3000*K))
 run "at scale 65553 x3"        FX_FUZZ_SCALE=3 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/stress_fuzz.py $((400*K)) 65553
