@@ -29,7 +29,7 @@ bool asmEligible(const Lowered& low, std::string* why) {
     if (low.rowPitch == 1 && low.nRows > kAsmVgprRows[ASM_V256]) return no("register file above 224 VGPR rows");
     for (const MicroOp& m : low.steady) {
         const uint32_t h = handlerOf(m);
-        if ((h == H_LOG || h == H_EXP) && (!has(m, F_UX) || has(m, F_STATIC_OOD))) return no("LOG/EXP with a per-instance or out-of-range table");
+        if ((h == H_LOG || h == H_EXP) && has(m, F_STATIC_OOD)) return no("LOG/EXP with an out-of-range table");
     }
     return true;
 }
@@ -132,6 +132,13 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
             case H_LOG:
             case H_EXP: {
                 slot = AS_LUT;
+                if (!has(m, F_UX)) {
+                    // the table number is a per-instance value: X stays a row, the Y word (unused by the reference, FX8010.cpp:1114)
+                    // carries the byte offset of table 0 of the family
+                    r.w[4] = (uint32_t)((kLutSegOff + (size_t)(h == H_EXP ? 32 : 0) * 128) * 8);
+                    r.w[6] |= 4u;
+                    break;
+                }
                 r.w[3] = (uint32_t)((kLutSegOff + (size_t)m.w[5] * 128) * 8);  // this table's {slope, y1}[64]
                 // a uniform operand inside the table: the result is the same constant for every instance and sample - the
                 // reference's own arithmetic (linearInterpolate, source/FX8010.cpp:283-296), once, here; R = that constant

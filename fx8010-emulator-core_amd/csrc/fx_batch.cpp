@@ -818,6 +818,9 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
     c.useXlate = false;
     c.stages = 1;
     c.deferred = false;
+    c.xlateWhyNot.clear();
+    if (c.useAsm && forceHip && std::strncmp(forceHip, "asm", 3) == 0) c.xlateWhyNot = "the interpreter is pinned by FX_KERNEL";
+    else if (c.useAsm && c.variant == ASM_LDS) c.xlateWhyNot = "register file in LDS (above 224 rows): no translation template";
     if (c.useAsm && c.variant != ASM_LDS && defer) {
         // controls are moving (a set_register within the last few blocks): a translation costs a module load
         // (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until the controls have been quiet
@@ -1746,6 +1749,18 @@ float Batch::lastKernelMs() {
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, ev0_, ev1_) != hipSuccess) return -1.0f;
     return ms;
+}
+
+// "translated to gfx950 code (fx_xlate_v128, 8 stages)" / "interpreter (fx_interp_v96): <why the translation failed>" / "HIP C++
+// kernel: <why not an assembly tier>" - of the code in force (before the first block: nothing has been lowered yet)
+std::string Batch::tierNote() const {
+    static const char* const regs[ASM_VARIANTS] = {"lds", "v64", "v72", "v80", "v96", "v128", "v168", "v256"};
+    if (!loaded_) return "no program loaded";
+    if (c_.key.empty() && !c_.useAsm && c_.low.steady.empty()) return "not lowered yet (the first block, fxb_prepare or an fxb_info query does it)";
+    if (c_.useAsm && c_.useXlate)
+        return std::string("translated to gfx950 code (fx_xlate_") + regs[c_.variant] + (c_.stages > 1 ? ", " + std::to_string(c_.stages) + " stages" : "") + ")";
+    if (c_.useAsm) return std::string("interpreter (fx_interp_") + regs[c_.variant] + "): " + (c_.xlateWhyNot.empty() ? "no translation asked for" : c_.xlateWhyNot);
+    return "HIP C++ kernel (" + std::to_string(c_.low.instPerLane) + " instance(s) per lane): " + (c_.asmWhyNot.empty() ? "no assembly tier asked for" : c_.asmWhyNot);
 }
 
 int64_t Batch::info(int what) {

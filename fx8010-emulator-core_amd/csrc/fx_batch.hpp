@@ -71,6 +71,7 @@ public:
     uint32_t oodFlags();
     float lastKernelMs();
     int64_t info(int what);
+    std::string tierNote() const;   // which tier runs the program as it stands, and why not a faster one (fxb_tier_note)
 
     const Program& program() const { return prog_; }
     int64_t instances() const { return n_; }

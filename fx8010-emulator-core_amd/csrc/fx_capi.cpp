@@ -211,6 +211,14 @@ int fxb_meta_get(fxb_handle* h, const char* key, char* buf, int buflen) { return
 int fxb_ready(fxb_handle* h) { return (h && h->batch.front().program().ready) ? 1 : 0; }
 const char* fxb_last_error(fxb_handle* h) { return h ? h->batch.lastError().c_str() : "null handle"; }
 float fxb_last_kernel_ms(fxb_handle* h) { return h ? guard(&h->batch.front(), -1.0f, [&] { return h->batch.lastKernelMs(); }) : -1.0f; }
+int fxb_tier_note(fxb_handle* h, char* buf, int buflen) {
+    if (!h) return FX_E_ARG;
+    return guard(&h->batch.front(), (int)FX_E_PROGRAM, [&] {
+        const std::string note = h->batch.front().tierNote();
+        if (buf && buflen > 0) std::snprintf(buf, (size_t)buflen, "%s", note.c_str());
+        return (int)note.size();
+    });
+}
 int64_t fxb_info(fxb_handle* h, int what) { return h ? guard(&h->batch.front(), (int64_t)-1, [&] { return h->batch.info(what); }) : -1; }
 
 

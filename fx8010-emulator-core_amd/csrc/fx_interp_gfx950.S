@@ -93,6 +93,7 @@
 	.set OOD_TRAM_READ_NEG, 1
 	.set OOD_TRAM_WRITE_OOB, 2
 	.set OOD_TRAM_SIZE0, 4
+	.set OOD_LUT_TABLE, 8
 	.set OOD_LUT_INDEX, 16
 
 // ---- VGPRs ----

@@ -574,7 +574,7 @@ class Translator {
                 if (slot == AS_ENDSAMPLE) break;
                 if (slot == AS_NOP || slot == AS_PRED || slot == AS_UNPRED || slot == AS_MOV || slot == AS_LIMIT || slot == AS_LIMITN) continue;
                 if (slot == AS_SKIP) { float w; int32_t c; if (!uniformSkip(r, &w, &c)) simple = false; continue; }
-                if (slot == AS_LUT) { if (r.w[6] & 1u) simple = false; continue; }
+                if (slot == AS_LUT) { if ((r.w[6] & 1u) || !(r.w[6] & 2u)) simple = false; continue; }
                 if (slot < AS_MACS || slot >= (uint32_t)kAsmSlots) { simple = false; continue; }
                 const uint32_t rel = slot - AS_MACS, family = rel / 16, kind = (rel % 16) / 2;
                 if (family != 3 || !(kind & 2u) || kind == 7u) continue;
@@ -2306,7 +2306,7 @@ class Translator {
             uint32_t kind, ccr;
             if (slot >= AS_MACS) { kind = ((slot - AS_MACS) % 16) / 2; ccr = (slot - AS_MACS) & 1u; }
             else { kind = rec[k].w[6] & 7u; ccr = (rec[k].w[6] >> 3) & 1u; }
-            if ((!(kind & 1u) && rec[k].w[2] == 0) || (!(kind & 2u) && rec[k].w[3] == 0 && slot != AS_LUT) || (!(kind & 4u) && rec[k].w[4] == 0)) return false;
+            if ((!(kind & 1u) && rec[k].w[2] == 0) || (!(kind & 2u) && rec[k].w[3] == 0) || (!(kind & 4u) && rec[k].w[4] == 0)) return false;
             if (ccr && !shadowed) return true;
         }
         return false;
@@ -2431,7 +2431,7 @@ class Translator {
             ++stats_.inlined;
             return true;
         }
-        if (slot == AS_LUT && !(r.w[6] & 1u)) {
+        if (slot == AS_LUT && !(r.w[6] & 1u) && (r.w[6] & 2u)) {   // (a per-instance table number: the handler)
             ++stats_.inlined;
             if (!lut(r)) return false;
             if (ccrLive) ccrFrom(vrow(r.w[5]));
@@ -2745,7 +2745,7 @@ HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroO
         else kind = r.w[6] & 7u;
         for (uint32_t row : rows) {
             if (!(kind & 1u) && r.w[2] == row) return true;
-            if (!(kind & 2u) && r.w[3] == row && slot != AS_LUT) return true;
+            if (!(kind & 2u) && r.w[3] == row) return true;
             if (!(kind & 4u) && r.w[4] == row) return true;
             if (r.w[5] == row) return true;
         }
@@ -2848,7 +2848,7 @@ XlateProgram xlateProgramOf(const std::vector<MicroOp>& steadyRecords, const std
     // LOG/EXP tables the inline code uses (per-lane operand): up to 4 of them go to LDS (1 KB each per wavefront, + 1 KB shared)
     for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords})
         for (const MicroOp& r : *recs)
-            if (r.w[0] == AS_LUT && !(r.w[6] & 1u) && std::find(p.lutTables.begin(), p.lutTables.end(), r.w[3]) == p.lutTables.end())
+            if (r.w[0] == AS_LUT && !(r.w[6] & 1u) && (r.w[6] & 2u) && std::find(p.lutTables.begin(), p.lutTables.end(), r.w[3]) == p.lutTables.end())
                 p.lutTables.push_back(r.w[3]);
     if (p.lutTables.size() > 4) p.lutTables.clear();
 
@@ -3029,7 +3029,8 @@ Access accessOf(const MicroOp& r) {
     }
     if (hot && kind == 7u) { a.write = (int)r.w[5]; a.ccr = (slot - AS_MACS) & 1u; return a; }  // folded on the host
     read(r.w[2], kind & 1u);
-    if (slot != AS_LUT && slot != AS_MOV) {
+    if (slot == AS_LUT) read(r.w[3], kind & 2u);   // (the table number: a row when it is a per-instance value)
+    else if (slot != AS_MOV) {
         read(r.w[3], kind & 2u);
         read(r.w[4], kind & 4u);
     }

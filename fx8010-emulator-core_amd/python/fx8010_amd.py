@@ -34,7 +34,7 @@ SYMBOLS = [
     "fxb_create", "fxb_create_sharded", "fxb_create_on_devices", "fxb_shard_count", "fxb_shard_info", "fxb_shard_kernel_ms", "fxb_shard_plan", "fxb_process_block_dev_shards", "fxb_destroy", "fxb_load_file", "fxb_load_text", "fxb_set_register", "fxb_set_register_i",
     "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_prepare", "fxb_state_size", "fxb_save_state", "fxb_load_state", "fxb_get_tram_i", "fxb_get_cursors_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
-    "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error",
+    "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error", "fxb_tier_note",
     "fxb_last_kernel_ms", "fxb_info", "fxb_device_count", "fxb_version",
     "fxp_create", "fxp_destroy", "fxp_load_file", "fxp_load_text", "fxp_num_registers", "fxp_register_name",
     "fxp_register_type", "fxp_register_ioindex", "fxp_register_value", "fxp_num_instructions", "fxp_instruction",
@@ -84,7 +84,7 @@ def load():
     sig("fxb_process_block", i32, vp, _f32p, _f32p, i32)
     sig("fxb_process_block_dev", i32, vp, vp, vp, i32, vp); sig("fxb_sync", i32, vp)
     sig("fxb_instruction_counter", i64, vp); sig("fxb_instruction_counter_i", i64, vp, i64)
-    sig("fxb_ood_flags", C.c_uint32, vp); sig("fxb_ready", i32, vp); sig("fxb_last_error", cp, vp)
+    sig("fxb_ood_flags", C.c_uint32, vp); sig("fxb_ready", i32, vp); sig("fxb_last_error", cp, vp); sig("fxb_tier_note", i32, vp, C.c_char_p, i32)
     sig("fxb_last_kernel_ms", f32, vp); sig("fxb_info", i64, vp, i32)
     sig("fxb_device_count", i32); sig("fxb_version", cp)
     for pfx in ("fx_", "fxb_", "fxp_"):
@@ -391,6 +391,12 @@ class Batch(_Reports):
 
     def ood_flags(self):
         return int(self._lib.fxb_ood_flags(self._h))
+
+    def tier_note(self):
+        """which tier runs the program as it stands, and why not a faster one"""
+        buf = C.create_string_buffer(512)
+        self._check(min(self._lib.fxb_tier_note(self._h, buf, 512), 0), "tier_note")
+        return buf.value.decode("latin-1")
 
     def last_kernel_ms(self):
         return float(self._lib.fxb_last_kernel_ms(self._h))

@@ -691,3 +691,31 @@ def test_bench_through_rccl_with_one_rank(gpu, tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["parity"]["parity_ok"] and d["value"] > 0
     assert len(d["roofline"]["per_gpu_kernel_ms"]) == 1 and d["roofline"]["per_gpu_kernel_ms"][0] > 0
+
+
+@pytest.mark.gpu
+def test_tier_note_says_which_tier_runs_and_why(gpu, monkeypatch):
+    """fxb_tier_note: the tier in force in words - and, below the translated tier, the reason: a host that finds
+    FXB_INFO_KERNEL < 9 can tell its user why (a SKIP that can jump over END is the reference's own multi-pass corner,
+    FX8010.cpp:1033,1243)"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_STAGES", raising=False)
+    x = progs.stimulus(70, 12)
+    b = gpu.Batch(70, 1, 0)
+    assert b.tier_note() == "no program loaded"
+    assert b.load_text(progs.CONFIGS["config2"]())
+    assert "not lowered yet" in b.tier_note()
+    b.process_block(x)
+    assert b.info("kernel") >= 9 and b.tier_note().startswith("translated to gfx950 code (fx_xlate_v"), b.tier_note()
+    if b.info("waves_per_wg") > 1:
+        assert "%d stages" % b.info("waves_per_wg") in b.tier_note()
+    multipass = gpu.Batch(70, 1, 0)
+    assert multipass.load_text("input in 0\noutput out 0\nstatic a\nmacs a, in, 0, 0\nmacs out, a, 0, 0\nskip ccr, ccr, 6, 1\nend")
+    multipass.process_block(x)
+    assert multipass.info("kernel") == 0 and multipass.tier_note().startswith("HIP C++ kernel (") and "END can be skipped" in multipass.tier_note(), multipass.tier_note()
+    monkeypatch.setenv("FX_KERNEL", "asm")
+    interp = gpu.Batch(70, 1, 0)
+    assert interp.load_text(progs.CONFIGS["config2"]())
+    interp.process_block(x)
+    assert 2 <= interp.info("kernel") <= 8 and interp.tier_note().startswith("interpreter (fx_interp_v"), interp.tier_note()

@@ -452,6 +452,56 @@ def test_log_of_the_input_inside_and_beyond_the_table(gpu, op, table, k):
     assert b.ood_flags() == 16
 
 
+def test_table_number_per_instance(gpu, k):
+    """LOG / EXP whose table number - the X operand, `(int32)X` (FX8010.cpp:1114,1121) - is a control with a different value on every
+    instance (N reference objects with N settings of a "drive" slider): every assembly tier takes the table from the lane's own
+    row (the translated program calls the interpreter's handler for these records, the rest of it stays generated code), and a
+    number outside 0..31 - negative, 32, NaN, beyond int32 - is flagged (8) on that instance only and reads the nearest table,
+    as the oracle defines it.  Also inside a SKIP shadow, and moving from block to block."""
+    text = (HDR + "control e = 3\ncontrol f = 7\nstatic t\nstatic u\nlog t, in, e, 0\nexp u, t, f, 0\nmacs a, in, 0, 0\nskip ccr, ccr, 6, 1\n"
+            "log u, a, f, 0\nmacs out, t, u, 0.5\nend")
+    N, S = 200, 24
+    x = progs.stimulus(N, S * 3)
+    rng = np.random.default_rng(31)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    oracles = []
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(text)
+        oracles.append(o)
+    wild = {3: -1.0, 64: 32.0, 65: 31.999, 70: float(np.float32(np.nan)), 71: 4.0e9, 72: -0.5, 130: 1.0e-30, 131: float(np.float32(np.inf)), 199: -3.0e9}
+    for blk in range(3):
+        e = rng.integers(0, 32, size=N).astype(np.float32) + rng.uniform(0.0, 0.99, size=N).astype(np.float32)
+        f = rng.integers(0, 32, size=N).astype(np.float32)
+        if blk == 1:
+            for n, v in wild.items():
+                (e if n % 2 else f)[n] = v
+        if blk < 2:      # (the third block: the values of the second stay)
+            assert b.set_register_array("e", e) == 0 and b.set_register_array("f", f) == 0
+            for n in range(N):
+                oracles[n].set_register("e", float(e[n]))
+                oracles[n].set_register("f", float(f[n]))
+        y = b.process_block(x[blk * S:(blk + 1) * S])
+        if blk == 0:
+            kern = b.info("kernel")
+            assert {"default": kern >= 9, "unstaged": kern >= 9, "xlate_v256": kern == 15, "asm": 2 <= kern <= 8, "asm_v256": kern == 8, "asm_lds": kern == 1}.get(k, kern == 0), (k, kern)
+        flagged = set()
+        for n in range(N):
+            ref = oracles[n].process_block(x[blk * S:(blk + 1) * S, n].copy())
+            assert np.array_equal(bits(ref), bits(y[:, n])), "block %d instance %d" % (blk, n)
+            assert b.instruction_counter_i(n) == oracles[n].instruction_counter()
+            for r in ("t", "u", "ccr"):
+                assert b.get_register_bits_i(r, n) == oracles[n].get_register_bits(r), (blk, n, r)
+            if oracles[n].ood_flags():
+                flagged.add(n)
+        if blk == 0:
+            assert not flagged and b.ood_flags() == 0
+        else:
+            assert flagged >= {3, 64, 70, 71, 131, 199} and not (flagged & {65, 130, 0, 1}), flagged
+            assert b.ood_flags() == 8
+
+
 @pytest.mark.parametrize("trigger", ["delay line hands back |x| > 1", "NaN on the input", "Inf on the input"])
 def test_leaving_the_fast_stream_at_the_head_of_a_sample(gpu, trigger, k):
     """A wave leaves the fast stream for the exact one at the *head* of a sample when the PCM input is non-finite or a

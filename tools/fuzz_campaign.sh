@@ -21,6 +21,10 @@ run "sweep 250 registers"      FX_FUZZ_REGS=250 timeout -k 10 900 python3 tools/
 run "sweep interpreter"        FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_sweep.py 2400000 $((2000*K))
 run "sweep interpreter (LDS)"  FX_KERNEL=asm_lds timeout -k 10 900 python3 tools/fuzz_sweep.py 2500000 $((1000*K))
 run "sweep HIP kernel"         FX_KERNEL=hip timeout -k 10 900 python3 tools/fuzz_sweep.py 2600000 $((2000*K))
+run "sweep per-instance operands"  FX_FUZZ_LANES=1 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/fuzz_sweep.py 2800000 $((3000*K))
+run "... interpreter"          FX_FUZZ_LANES=1 FX_FUZZ_OOD=1 FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_sweep.py 2900000 $((1500*K))
+run "... interpreter (LDS)"    FX_FUZZ_LANES=1 FX_FUZZ_OOD=1 FX_KERNEL=asm_lds timeout -k 10 900 python3 tools/fuzz_sweep.py 3000000 $((800*K))
+run "... HIP kernel"           FX_FUZZ_LANES=1 FX_FUZZ_OOD=1 FX_KERNEL=hip timeout -k 10 900 python3 tools/fuzz_sweep.py 3100000 $((800*K))
 run "api"                      timeout -k 10 900 python3 tools/fuzz_api.py 2000000 $((2500*K))
 run "api wild registers"       FX_FUZZ_WILD=1 timeout -k 10 900 python3 tools/fuzz_api.py 2100000 $((2000*K))
 run "api two shards"           FX_FUZZ_SHARDS=2 timeout -k 10 900 python3 tools/fuzz_api.py 2200000 $((1500*K))

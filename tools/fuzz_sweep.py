@@ -1,6 +1,10 @@
 """Wide differential fuzz of the default tier against the oracle (the GPU test suite runs 96 of these programs).
 
     python tools/fuzz_sweep.py [first_seed] [count]
+
+FX_FUZZ_LANES=1: registers the program only reads - literals and controls, the table numbers of LOG / EXP among them - get a value
+per instance before the first block (what fxb_set_register_array is for: N objects with N settings), table numbers now and then
+outside 0..31.
 """
 import os
 import sys
@@ -34,7 +38,7 @@ def main():
         hit = r.random(x.shape) < float(os.environ["FX_FUZZ_NAN"])
         x = x.copy()
         x[hit] = words[r.integers(0, words.size, size=int(hit.sum()))]
-    failures, kernels = [], {}
+    failures, kernels, reasons = [], {}, {}
     for seed in range(first, first + count):
         rng = np.random.default_rng(500000 + seed)
         gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
@@ -43,12 +47,43 @@ def main():
         b = A.Batch(N, 1, 0)
         if not b.load_text(text):
             continue
+        lanes = {}
+        if os.environ.get("FX_FUZZ_LANES"):
+            written, read, tables = set(), [], []
+            for ln in text.split("\n"):
+                tok = [t.strip() for t in ln.replace(",", " ").split()]
+                if len(tok) == 5 and tok[0] not in ("idelay", "xdelay", "skip"):
+                    written.add(tok[1])
+                    read += tok[2:5]
+                    if tok[0] in ("log", "exp"):
+                        tables.append(tok[3])
+            candidates = sorted({r for r in read if r not in written and r not in ("in", "ccr", "noise", "0")})
+            for name in sorted(set(tables)):
+                if name in written:
+                    continue
+                v = rng.integers(0, 32, size=N).astype(np.float32)
+                odd = rng.random(N) < 0.08
+                v[odd] = rng.choice(np.array([-1.0, 32.0, 31.5, 1.0e10, -0.25, np.nan], np.float32), size=int(odd.sum()))
+                lanes[name] = v
+            for name in candidates:
+                if name not in lanes and rng.random() < 0.3:
+                    lanes[name] = rng.uniform(-1.0, 1.0, size=N).astype(np.float32)
+            for name, v in lanes.items():
+                if b.set_register_array(name, v) != 0:
+                    lanes = None
+                    break
+            if lanes is None:
+                continue
         y1 = b.process_block(x)
         y2 = b.process_block(x)
         kernels[b.info("kernel")] = kernels.get(b.info("kernel"), 0) + 1
+        if b.info("kernel") < 9:
+            reasons[b.tier_note()] = reasons.get(b.tier_note(), 0) + 1
         for n in (0, 1, 37, 64, 69):
             o = Oracle(1)
             o.load_text(text)
+            for name, v in lanes.items():
+                o.set_register(name, float(v[n]))
             r1 = o.process_block(x[:, n].copy())
             r2 = o.process_block(x[:, n].copy())
             if o.ood_flags() and not os.environ.get("FX_FUZZ_OOD"):   # FX_FUZZ_OOD=1: out-of-domain behaviour is compared too
@@ -68,6 +103,8 @@ def main():
         # the default tier ran some programs on the interpreter: a translation failed (the batch falls back silently)
         print("NOTE: interpreter fallbacks in default mode:", {k: v for k, v in kernels.items() if 1 <= k <= 8})
         failures.append("interpreter fallback")
+    if reasons and not os.environ.get("FX_KERNEL"):
+        print("below the translated tier:", sorted(reasons.items(), key=lambda kv: -kv[1])[:4])
     print("fuzz sweep:", count, "programs, kernels", kernels, "failures", failures)
     return 1 if failures else 0
 
