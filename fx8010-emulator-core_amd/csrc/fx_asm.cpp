@@ -24,8 +24,7 @@ inline bool has(const MicroOp& m, uint32_t f) { return (m.w[0] & f) != 0; }
 bool asmEligible(const Lowered& low, std::string* why) {
     auto no = [&](const char* w) { if (why) *why = w; return false; };
     if (low.instPerLane != 1) return no("more than one instance per lane");
-    if (low.multipass) return no("END can be skipped (multi-pass program)");
-    if (low.rowPitch != 1 && (size_t)low.nRows * 256 > 64 * 1024) return no("register file above 64 KiB of LDS");
+    if (low.rowPitch != 1 && (size_t)low.nRows * 256 > 160 * 1024) return no("register file above the 160 KiB of LDS of a CU (640 rows)");
     if (low.rowPitch == 1 && low.nRows > kAsmVgprRows[ASM_V256]) return no("register file above 224 VGPR rows");
     for (const MicroOp& m : low.steady) {
         const uint32_t h = handlerOf(m);
@@ -165,7 +164,8 @@ std::vector<MicroOp> encodeAsmStream(const std::vector<MicroOp>& ops, const uint
             case H_TRAM_XR: slot = AS_TRAM_XR; break;
             case H_TRAM_XW: slot = AS_TRAM_XW; break;
             case H_NOISE: slot = AS_NOISE; break;
-            default: slot = AS_NOP; break;  // END (single pass) and NOP only count
+            case H_END: slot = has(m, F_SHADOW) ? AS_END : AS_NOP; break;  // (END in a shadow: a multi-pass program - the handler notes who has finished)
+            default: slot = AS_NOP; break;  // NOP only counts
         }
         setAddress(r, slot);
         out.push_back(r);

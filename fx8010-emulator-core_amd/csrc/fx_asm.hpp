@@ -38,7 +38,8 @@ struct AsmArgs {
     const uint32_t* tracks;  // translated programs with control tracks: the block's TrackEvent list + values (fx_xlate.hpp), else nullptr
     const uint32_t* stages;  // translated programs cut into stages: StageDescriptor[nStages] (fx_xlate.hpp), else nullptr
     int nStages;             // wavefronts per workgroup (0 / 1: the whole program in one)
-    int tramDane;            // interpreter builds: the opt-in DANE delay-line model is in force (the address counters step once per sample period)
+    int tramDane;            // interpreter builds, bit 0: the opt-in DANE delay-line model is in force (the address counters step once per sample
+                             // period); bit 1: multi-pass program (END lies in a SKIP shadow: the kernel runs passes until every lane has executed it)
 };
 static_assert(offsetof(AsmArgs, lut) == 0x40, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, nLoad) == 0x58, "AsmArgs layout");
@@ -59,7 +60,7 @@ static_assert(sizeof(AsmArgs) == 0xd0, "AsmArgs layout");
 enum AsmSlot : uint32_t {
     AS_ENDSAMPLE = 0, AS_NOP = 1, AS_PRED = 2, AS_UNPRED = 3, AS_MOV = 4, AS_MACW = 5, AS_MACWN = 6, AS_MACINTW = 7,
     AS_ANDXOR = 8, AS_TSTNEG = 9, AS_LIMIT = 10, AS_LIMITN = 11, AS_LUT = 12, AS_SKIP = 13, AS_TRAM_IR = 14,
-    AS_TRAM_IW = 15, AS_TRAM_XR = 16, AS_TRAM_XW = 17, AS_NOISE = 18,
+    AS_TRAM_IW = 15, AS_TRAM_XR = 16, AS_TRAM_XW = 17, AS_NOISE = 18, AS_END = 19 /* END inside a SKIP shadow (multi-pass programs) */,
     AS_MACS = 20, AS_MACSN = 36, AS_ACC3 = 52, AS_INTERP = 68  // + kind*2 + ccr, kind = UA | UX<<1 | UY<<2
 };
 

@@ -821,7 +821,10 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
     c.xlateWhyNot.clear();
     if (c.useAsm && forceHip && std::strncmp(forceHip, "asm", 3) == 0) c.xlateWhyNot = "the interpreter is pinned by FX_KERNEL";
     else if (c.useAsm && c.variant == ASM_LDS) c.xlateWhyNot = "register file in LDS (above 224 rows): no translation template";
-    if (c.useAsm && c.variant != ASM_LDS && defer) {
+    else if (c.useAsm && c.low.multipass) c.xlateWhyNot = "END can be skipped (multi-pass program): the interpreter runs the passes";
+    if (c.useAsm && c.low.multipass) {
+        // (generated code is one pass over the program; the interpreter's end-of-sample handler starts the next one)
+    } else if (c.useAsm && c.variant != ASM_LDS && defer) {
         // controls are moving (a set_register within the last few blocks): a translation costs a module load
         // (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until the controls have been quiet
         c.deferred = true;
@@ -1342,6 +1345,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             g.oodRow = a.oodRow; g.countLo = a.countLo; g.countHi = a.countHi; g.staticCount = a.staticCount;
             g.lutX1Off = kLutX1Off * 8;
             g.tramDane = (c_.low.tramDane && (c_.low.usesITram || c_.low.usesXTram)) ? 1 : 0;   // (like the other tiers: counters step where the program has taps)
+            if (c_.low.multipass) g.tramDane |= 2;
             if (c_.useXlate) {
                 // code streams are named by their byte offset from the kernel entry: {fast, exact} per argument
                 g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)c_.steady);

@@ -329,6 +329,7 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     if (!low.error.empty()) { h->err = low.error; return FX_E_PROGRAM; }
     std::string why;
     if (!fx::asmEligible(low, &why)) { h->err = "not eligible: " + why; return FX_E_PROGRAM; }
+    if (low.multipass) { h->err = "not eligible: END can be skipped (multi-pass program: the interpreter runs the passes)"; return FX_E_PROGRAM; }
     int v = fx::ASM_V64;
     while (v < fx::ASM_V256 && low.nRows > fx::kAsmVgprRows[v]) ++v;
     if (vgprs != 0) {
@@ -407,6 +408,7 @@ int64_t fxp_code_hash(fxp_handle* h, int vgprs, int stages, unsigned flags) {
         if (!low.error.empty()) { h->err = low.error; return FX_E_PROGRAM; }
         std::string why;
         if (!fx::asmEligible(low, &why)) { h->err = "not eligible: " + why; return FX_E_PROGRAM; }
+        if (low.multipass) { h->err = "not eligible: END can be skipped (multi-pass program: the interpreter runs the passes)"; return FX_E_PROGRAM; }
         int want = -1;
         for (int q = fx::ASM_V64; q < fx::ASM_VARIANTS; ++q)
             if (fx::kAsmVgprRows[q] + 32 == vgprs && low.nRows <= fx::kAsmVgprRows[q]) want = q;

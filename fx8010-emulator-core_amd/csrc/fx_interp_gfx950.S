@@ -86,7 +86,8 @@
 	.set KA_TRACKS,   0xb8      // translated programs: control tracks of this block (fx_batch.hpp TrackHeader[3] + values), 0 = none
 	.set KA_STAGES,   0xc0      // translated programs cut into stages (fx_xlate.hpp StageDescriptor[nStages], 32 bytes each), 0 = none
 	.set KA_NSTAGES,  0xc8      // wavefronts per workgroup = stages of the program (0 or 1: one wavefront runs all of it)
-	.set KA_TRAMDANE, 0xcc      // interpreter builds: 1 = the opt-in DANE delay-line model (address counters step once per sample period)
+	.set KA_TRAMDANE, 0xcc      // interpreter builds, bit 0: the opt-in DANE delay-line model (address counters step once per sample period);
+	                            //  bit 1: multi-pass program (END inside a SKIP shadow: lanes that skipped it run the program again)
 	.set KA_SIZE,     0xd0
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
@@ -94,6 +95,8 @@
 	.set OOD_TRAM_WRITE_OOB, 2
 	.set OOD_TRAM_SIZE0, 4
 	.set OOD_LUT_TABLE, 8
+	.set OOD_PASS_CAP, 32
+	.set PASS_CAP, 64           // passes of a multi-pass program per sample period (fx_kernel.hpp kPassCap, the oracle's PASS_CAP)
 	.set OOD_LUT_INDEX, 16
 
 // ---- VGPRs ----
@@ -110,7 +113,8 @@
 //  s[52:55] latch row offsets  s56 iSize  s57 xSize  s[58:59] lanes with instance < N  s60 state row pitch (nPad*4)
 //  s61 byte offset of x1[] in the LUT blob  s62-s67 temporaries  s68 bytes per channel-sample (N*4)
 //  s[72:73] row table  s74 nLoad  s75 nStore  s76 cursor state row  s77 LFSR state row
-//  s70 (interpreter builds) opt-in DANE delay-line model in force
+//  s70 (interpreter builds) bit 0 opt-in DANE delay-line model, bit 1 multi-pass program   s71 passes of this sample period
+//  s[96:97] (interpreter builds) lanes that run the passes of this sample period   s[98:99] lanes that have executed END in it
 
 	.text
 	.globl	KNAME
@@ -252,6 +256,9 @@ KNAME:
 #else
 	s_load_dwordx8  s[48:55], s[0:1], KA_INOFF            // inOff[4] latchOff[4]
 	s_load_dword    s70, s[0:1], KA_TRAMDANE
+	s_mov_b64 s[96:97], s[58:59]                          // every instance runs the first pass
+	s_mov_b64 s[98:99], 0
+	s_mov_b32 s71, 0
 #endif
 	s_load_dwordx4  s[64:67], s[0:1], KA_ISLOTS           // iSlots xSlots iSize xSize
 	s_load_dwordx2  s[76:77], s[0:1], KA_CURSORROW      // cursorRow noiseRow
@@ -663,6 +670,35 @@ h_endsample_a:
 h_endsample_b:
 h_endsample_c:
 h_endsample_d:
+	// A multi-pass program (FX8010.cpp:1033,1243: `do { ... } while (!isEND)` - every instruction lies in some SKIP's shadow, END
+	// included): the lanes that did not execute END run the program again with the skip count they have left, at most PASS_CAP
+	// passes per sample period (then: flagged, as the oracle and the HIP C++ kernel define it).
+	s_bitcmp1_b32 s70, 1
+	s_cbranch_scc0 .Le_single
+	s_andn2_b64 s[96:97], s[96:97], s[98:99]
+	s_add_u32 s71, s71, 1
+	s_cmp_eq_u64 s[96:97], 0
+	s_cbranch_scc1 .Le_passes_done
+	s_cmp_lt_u32 s71, PASS_CAP
+	s_cbranch_scc0 .Le_cap
+	s_waitcnt lgkmcnt(0)                                  // (the record prefetch of the pass that ends here may still be on its way into a window)
+	s_load_dwordx16 s[16:31], s[4:5], 0x0                 // records 0, 1
+	s_load_dwordx16 s[80:95], s[4:5], 0x40                // records 2, 3
+	s_mov_b32 s8, 128
+	s_waitcnt lgkmcnt(0)
+	s_setpc_b64 s[16:17]
+.Le_cap:
+#ifdef RF_VGPR
+	s_set_gpr_idx_off
+	s_nop 3
+#endif
+	s_mov_b64 exec, s[96:97]
+	v_or_b32 v22, OOD_PASS_CAP, v22
+.Le_passes_done:
+	s_mov_b64 s[96:97], s[58:59]
+	s_mov_b64 s[98:99], 0
+	s_mov_b32 s71, 0
+.Le_single:
 	s_mov_b64 exec, s[58:59]
 	LOADV v2, s52
 	s_mov_b64 s[62:63], s[14:15]
@@ -696,8 +732,8 @@ h_endsample_d:
 	s_add_u32 s14, s14, s45
 	s_addc_u32 s15, s15, 0
 	// opt-in DANE delay-line model (fx_kernel.hip daneStep): both address counters step down once per sample period, every lane
-	s_cmp_eq_u32 s70, 0
-	s_cbranch_scc1 .Le_counters
+	s_bitcmp1_b32 s70, 0
+	s_cbranch_scc0 .Le_counters
 	s_cmp_lt_i32 s56, 1
 	s_cbranch_scc1 .Le_xcounter
 	s_sub_i32 s62, s56, 1
@@ -943,7 +979,11 @@ PNAME:
 		.amdhsa_system_sgpr_workgroup_id_x 1
 		.amdhsa_system_vgpr_workitem_id 0
 		.amdhsa_next_free_vgpr NVGPR
+#ifdef XLATE
 		.amdhsa_next_free_sgpr 96
+#else
+		.amdhsa_next_free_sgpr 100
+#endif
 		.amdhsa_accum_offset NVGPR
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_round_mode_32 0

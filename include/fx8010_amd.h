@@ -265,9 +265,10 @@ enum {
 };
 int64_t fxb_info(fxb_handle* h, int what);
 /* Which tier runs the program as it stands, in words - "translated to gfx950 code (fx_xlate_v128, 8 stages)", "interpreter
- * (fx_interp_v96): <why the translation failed>", "HIP C++ kernel (1 instance(s) per lane): <why no assembly tier takes the
- * program>" (a SKIP that can jump over END, a register file beyond every build, a LOG / EXP table number outside 0..31 ...) - so
- * that a host that finds FXB_INFO_KERNEL below 9 can say why.  Copies at most buflen-1 characters, returns the note's length
+ * (fx_interp_v96): <why there is no translation>" (a SKIP that can jump over END: passes over the program; a register file above
+ * 224 rows; controls that keep moving ...), "HIP C++ kernel (1 instance(s) per lane): <why no assembly tier takes the program>"
+ * (a register file beyond every build, a literal LOG / EXP table number outside 0..31 ...) - so that a host that finds
+ * FXB_INFO_KERNEL below 9 can say why.  Copies at most buflen-1 characters, returns the note's length
  * (negative FX_E_*).  Of shard 0 for a multi-device handle (every shard runs the same code).  Nothing in the reference. */
 int fxb_tier_note(fxb_handle* h, char* buf, int buflen);
 

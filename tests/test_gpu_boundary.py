@@ -713,7 +713,11 @@ def test_tier_note_says_which_tier_runs_and_why(gpu, monkeypatch):
     multipass = gpu.Batch(70, 1, 0)
     assert multipass.load_text("input in 0\noutput out 0\nstatic a\nmacs a, in, 0, 0\nmacs out, a, 0, 0\nskip ccr, ccr, 6, 1\nend")
     multipass.process_block(x)
-    assert multipass.info("kernel") == 0 and multipass.tier_note().startswith("HIP C++ kernel (") and "END can be skipped" in multipass.tier_note(), multipass.tier_note()
+    assert 2 <= multipass.info("kernel") <= 8 and multipass.tier_note().startswith("interpreter (fx_interp_v") and "END can be skipped" in multipass.tier_note(), multipass.tier_note()
+    generic = gpu.Batch(70, 1, 0)
+    assert generic.load_text("input in 0\noutput out 0\nstatic a\nlog a, in, 40, 0\nmacs out, a, 0, 0\nend")   # table 40: outside the reference's table vector
+    generic.process_block(x)
+    assert generic.info("kernel") == 0 and generic.tier_note().startswith("HIP C++ kernel (") and "out-of-range table" in generic.tier_note(), generic.tier_note()
     monkeypatch.setenv("FX_KERNEL", "asm")
     interp = gpu.Batch(70, 1, 0)
     assert interp.load_text(progs.CONFIGS["config2"]())

@@ -77,7 +77,7 @@ def run_case(gpu, case, text=None, N=67, compare_registers=True, per_instance_se
 @pytest.mark.parametrize("fixture", ["opcodes.json", "known_answers.json", "slider.json", "feedback_delay.json"])
 def test_reference_vectors(gpu, tier, fixture):
     for case in load(fixture):
-        run_case(gpu, case)  # (skip_over_end is a multi-pass program: it runs on the HIP kernel whatever tier is asked)
+        run_case(gpu, case)  # (skip_over_end is a multi-pass program: the interpreter runs it where an assembly tier is asked, else the HIP C++ kernel)
 
 
 # Non-finite values, bit for bit (tests/golden/nonfinite.json, nan_collisions.json: what the x86 build of the reference

@@ -561,6 +561,55 @@ def test_skip_over_end_multipass(gpu, k):
     x = progs.stimulus(70, 50)
     b, _ = check_batch(gpu, text, x, regs=("a", "b", "out", "ccr"))
     assert b.info("multipass") == 1
+    # the interpreter runs the passes itself (its end-of-sample handler starts the next one for the lanes that skipped END);
+    # generated code is one pass, so the default choice is the interpreter too
+    kern = b.info("kernel")
+    assert {"asm_lds": kern == 1, "asm_v256": kern == 8}.get(k, (kern == 0) if isinstance(k, int) else 2 <= kern <= 8), (k, kern)
+
+
+def test_skip_counts_per_instance_and_passes_to_the_cap(gpu, k):
+    """a SKIP whose count is a per-instance value can skip anything, END included: a multi-pass program for the decoder.  Counts
+    0 .. 9 (whole passes are skipped with the count that is left), negative (exactly one instruction), NaN - and a program that
+    never reaches END on some instances: 64 passes per sample period, flag 32 on those instances only, like the oracle."""
+    text = HDR + "control n = 1\nstatic t\nmacs a, in, 0, 0\nskip ccr, ccr, 6, n\nmacs t, t, 0.125, 0.5\nmacs b, in, 0.5, 0.5\nmacs out, t, b, 0.5\nend"
+    N, S = 140, 20
+    x = progs.stimulus(N, S)
+    counts = np.resize(np.array([0, 1, 2, 3, 4, 5, 6, 7, 9, -1, -7, 2.9, np.nan, 13, 29], np.float32), N)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    assert b.set_register_array("n", counts) == 0
+    y = np.concatenate([b.process_block(x[:7]), b.process_block(x[7:])], axis=0)
+    assert b.info("multipass") == 1
+    flags = 0
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(text)
+        o.set_register("n", float(counts[n]))
+        ref = o.process_block(x[:, n].copy())
+        assert np.array_equal(bits(ref), bits(y[:, n])), "instance %d (count %r)" % (n, counts[n])
+        assert b.instruction_counter_i(n) == o.instruction_counter(), n
+        for r in ("t", "b", "a", "ccr"):
+            assert b.get_register_bits_i(r, n) == o.get_register_bits(r), (n, r)
+        flags |= o.ood_flags()
+    assert flags == 32 and b.ood_flags() == 32   # (a count of 4 covers exactly the rest of the program, END included, in every pass)
+    # never END: every pass executes the SKIP again, and a count of 2 covers the instruction behind it and END
+    forever = HDR + "control n = 2\nmacs a, -0.5, 0, 0\nskip ccr, ccr, 6, n\nmacs out, in, 0, 0\nend"
+    b2 = gpu.Batch(N, 1, 0)
+    assert b2.load_text(forever), b2.errors()
+    lanes = np.where(np.arange(N) % 3 == 0, 2.0, 1.0).astype(np.float32)     # 2: jumps over END in every pass; 1: skips one instruction
+    assert b2.set_register_array("n", lanes) == 0
+    y2 = b2.process_block(x[:4])
+    flagged = 0
+    for n in range(N):
+        o = Oracle(1)
+        assert o.load_text(forever)
+        o.set_register("n", float(lanes[n]))
+        ref = o.process_block(x[:4, n].copy())
+        assert np.array_equal(bits(ref), bits(y2[:, n])), n
+        assert b2.instruction_counter_i(n) == o.instruction_counter(), n
+        assert (o.ood_flags() == 32) == (n % 3 == 0), (n, o.ood_flags())
+        flagged += o.ood_flags() == 32
+    assert flagged and b2.ood_flags() == 32
 
 
 def test_stereo_and_input_channel_quirk(gpu, k):

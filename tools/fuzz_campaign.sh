@@ -18,6 +18,7 @@ run "sweep default"            timeout -k 10 900 python3 tools/fuzz_sweep.py 200
 run "sweep inputs x3 + ood"    FX_FUZZ_SCALE=3 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/fuzz_sweep.py 2100000 $((4000*K))
 run "sweep non-finite inputs"  FX_FUZZ_NAN=0.03 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/fuzz_sweep.py 2200000 $((4000*K))
 run "sweep 250 registers"      FX_FUZZ_REGS=250 timeout -k 10 900 python3 tools/fuzz_sweep.py 2300000 $((1500*K))
+run "sweep 700 registers"      FX_FUZZ_REGS=700 timeout -k 10 900 python3 tools/fuzz_sweep.py 3200000 $((600*K))
 run "sweep interpreter"        FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_sweep.py 2400000 $((2000*K))
 run "sweep interpreter (LDS)"  FX_KERNEL=asm_lds timeout -k 10 900 python3 tools/fuzz_sweep.py 2500000 $((1000*K))
 run "sweep HIP kernel"         FX_KERNEL=hip timeout -k 10 900 python3 tools/fuzz_sweep.py 2600000 $((2000*K))
