@@ -1155,3 +1155,58 @@ def test_product_cache_patterns(gpu, seed, monkeypatch):
     x = (rng.uniform(-1.0, 1.0, size=(S, N)) * rng.choice([1.0, 0.5, 1e-3], size=(1, N))).astype(np.float32)
     b, _ = check_batch(gpu, text, x, regs=("a", "b", "c", "t", "out", "ccr"))
     assert b.info("kernel") >= 9
+
+
+@pytest.mark.parametrize("kernel", ["default", "asm", "hip"])
+def test_maximum_delay_lines_wrap(gpu, kernel, monkeypatch):
+    """the largest lines the reference has room for - smallDelayBuffer[8192], largeDelayBuffer[1048576] (FX8010.h:210-211) - each
+    with a feedback loop through it, run past the first wrap of the large one (sample 1 048 576): 256 MiB of delay memory per
+    wavefront, three instances against the oracle, positions and the slots around the wrap compared directly"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    if kernel != "default":
+        monkeypatch.setenv("FX_KERNEL", kernel)
+    text = ("itramsize 8192 \nxtramsize 1048576 \ninput in 0\noutput out 0\nstatic rd\nstatic xd\nstatic a\nstatic b\n"
+            "idelay read, rd, at, 0\nxdelay read, xd, at, 0\nmacs a, in, rd, 0.5\nmacs b, in, xd, 0.25\nidelay write, a, at, 0\nxdelay write, b, at, 0\n"
+            "macs out, a, b, 0.5\nend")
+    N, S, piece = 70, 1048576 + 2048, 131072
+    rng = np.random.default_rng(4)
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    watch = (0, 37, 69)
+    oracles = {n: Oracle(1) for n in watch}
+    for o in oracles.values():
+        assert o.load_text(text)
+    for at in range(0, S, piece):
+        ns = min(piece, S - at)
+        x = rng.uniform(-0.9, 0.9, size=(ns, N)).astype(np.float32)
+        y = b.process_block(x)
+        for n, o in oracles.items():
+            ref = o.process_block(x[:, n].copy())
+            assert np.array_equal(bits(ref), bits(y[:, n])), (kernel, at, n)
+    assert b.ood_flags() == 0
+    for n, o in oracles.items():
+        assert b.get_cursors_i(n) == o.cursors() == [2048 % 8192, 2048 % 8192, 2048, 2048], (n, b.get_cursors_i(n), o.cursors())
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+        assert np.array_equal(bits(b.get_tram_i(1, n, 1048576)), bits(o.tram(1, 1048576))), n
+        assert np.array_equal(bits(b.get_tram_i(0, n, 8192)), bits(o.tram(0, 8192))), n
+
+
+def test_empty_blocks_and_single_instances(gpu, k):
+    """a block of no samples changes nothing (the reference's caller simply does not call process()); a batch of ONE instance is
+    one reference object; 63 / 64 / 65 instances: a wavefront one lane short, full, and one lane into the next"""
+    text = HDR + "itramsize 5 \nidelay read, rd, at, 0\nmacs a, in, rd, 0.5\nidelay write, a, at, 0\nmacs out, a, noise, 0.25\nend"
+    for N in (1, 63, 64, 65):
+        x = progs.stimulus(N, 24)
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        y0 = b.process_block(x[:0])
+        assert y0.shape == (0, N) and b.instruction_counter() == 0
+        y = np.concatenate([b.process_block(x[:9]), b.process_block(x[9:9]), b.process_block(x[9:])], axis=0)
+        for n in sorted({0, N // 2, N - 1}):
+            o = Oracle(1)
+            assert o.load_text(text)
+            ref = o.process_block(x[:, n].copy())
+            assert np.array_equal(bits(ref), bits(y[:, n])), (N, n)
+            assert b.instruction_counter_i(n) == o.instruction_counter() and b.get_cursors_i(n) == o.cursors()
+        assert b.instruction_counter() == N * 24 * 5
