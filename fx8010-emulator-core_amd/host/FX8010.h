@@ -229,6 +229,12 @@ public:
     int64_t getInstructionCounter() { return fxb_instruction_counter(h_); }
     int64_t getInstructionCounter(int64_t instance) { return fxb_instruction_counter_i(h_, instance); }
     float lastKernelMs() { return fxb_last_kernel_ms(h_); }
+    // which tier runs the program as it stands, and why not a faster one (text for the host's log)
+    std::string tierNote() {
+        char buf[512] = {0};
+        fxb_tier_note(h_, buf, (int)sizeof buf);
+        return buf;
+    }
     int64_t instances() const { return n_; }
     int channels() const { return ch_; }
     fxb_handle* handle() { return h_; }
