@@ -738,6 +738,10 @@ class Translator {
             static const int padSlow = std::getenv("FX_XLATE_LOOPPAD_SLOW") ? std::atoi(std::getenv("FX_XLATE_LOOPPAD_SLOW")) : 0;
             for (int k = 0; k < pad; ++k) e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 31, vreg(31), 31);
             for (int k = 0; k < padSlow; ++k) e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(31), vreg(31));
+            // ... FX_XLATE_LOOPPAD_SALU=n: n scalar instructions (does a wavefront's scalar work - delay-line addresses, loop
+            // control - cost the SIMD issue time, or do the other wavefronts' vector instructions go out beside it?)
+            static const int padScalar = std::getenv("FX_XLATE_LOOPPAD_SALU") ? std::atoi(std::getenv("FX_XLATE_LOOPPAD_SALU")) : 0;
+            for (int k = 0; k < padScalar; ++k) e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSTemp), imm32(1));
         }
         if (!staged || usesSkipCounter) e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
         if (staged) {

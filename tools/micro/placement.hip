@@ -66,6 +66,18 @@ int main() {
                    waves, wavesPerGroup, ms, (last - first) * 1e-5, busy / waves * 1e-5, 100.0 * busy / waves / (double)(last - first), perSimd.size(), perCu.size());
             for (auto& kv : histogram) printf("  %d x%d", kv.first, kv.second);
             printf("\n");
+            // per XCC: how long its waves ran (a launch that fills every slot once ends with its slowest wave: the spread between
+            // XCCs - each has a clock of its own under the board's power limit - is what a single-round launch loses against
+            // the mean; a launch of several rounds hands the faster XCCs more waves instead)
+            std::map<uint32_t, std::vector<double>> perXcc;
+            for (const Rec& r : h) perXcc[r.xcc & 15].push_back((double)(r.t1 - r.t0) * 1e-5);
+            printf("        per XCC, wave duration mean (min .. max) ms, waves:");
+            for (auto& kv : perXcc) {
+                double sum = 0, lo = 1e30, hi = 0;
+                for (double t : kv.second) { sum += t; lo = std::min(lo, t); hi = std::max(hi, t); }
+                printf("  [%u] %.2f (%.2f .. %.2f) x%zu", kv.first, sum / kv.second.size(), lo, hi, kv.second.size());
+            }
+            printf("\n");
         }
     return 0;
 }
