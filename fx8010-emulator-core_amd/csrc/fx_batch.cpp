@@ -354,7 +354,7 @@ std::string Batch::codeKeyFor(const std::vector<uint8_t>& forced, int blockClass
     auto word = [&](int64_t v) { k.append(reinterpret_cast<const char*>(&v), 8); };
     word(loadGen_); word((int64_t)prog_.options); word(blockClass); word(pick); word(defer ? 1 : 0);
     word(((iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0) && instPerLane_ != 1) ? instPerLane_ : 0);   // delay lines tiled for K instances per lane pin the HIP C++ kernel
-    for (const char* name : {"FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_STAGES_GROUP"}) {
+    for (const char* name : {"FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_STAGES_GROUP", "FX_XLATE_PRIO"}) {
         const char* v = std::getenv(name);
         k.append(v ? v : "");
         k.push_back('\0');
@@ -837,6 +837,14 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
         XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, c.low.nRows, c.low.inRow, c.low.latchRow, trackRows);
         // 256 bytes per wavefront and slot; the Infinity Cache holds 256 MiB
         xprog.tramStreaming = ((size_t)iSlotsAlloc_ + (size_t)xSlotsAlloc_) * (((size_t)n_ + 63) / 64) * 256 > ((size_t)512 << 20);
+        {
+            // wavefronts of a SIMD by turns at the top priority (fx_xlate.hpp prioritySlices): where the launch fills the build's
+            // wave slots once and a SIMD holds two or more (FX_XLATE_PRIO=0 / 1 in the environment: never / whenever unstaged)
+            const size_t waves = ((size_t)n_ + 63) / 64, simds = 1024;
+            const size_t perSimd = (waves + simds - 1) / simds;
+            const char* knob = std::getenv("FX_XLATE_PRIO");
+            xprog.prioritySlices = knob ? std::atoi(knob) != 0 : (waves >= 2 * simds && perSimd <= (size_t)kAsmWavesPerSimd[c.variant]);
+        }
         XlateImage image;
         const XlateTemplate* tmpl = nullptr;
         bool built = false;

@@ -349,6 +349,7 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     std::vector<int> trackRows;
     for (int r : h->tracked) trackRows.push_back(low.rowOfReg[(size_t)r]);
     fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow, trackRows);
+    if (const char* knob = std::getenv("FX_XLATE_PRIO")) xprog.prioritySlices = std::atoi(knob) != 0;   // (what a batch with that knob generates: tests)
     std::vector<std::vector<uint32_t>> stagedCode;
     std::vector<std::string> stagedText;
     if (stagesOut) *stagesOut = 1;
@@ -420,6 +421,7 @@ int64_t fxp_code_hash(fxp_handle* h, int vgprs, int stages, unsigned flags) {
         for (int r : h->tracked) trackRows.push_back(low.rowOfReg[(size_t)r]);
         fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow, trackRows);
         xprog.tramStreaming = (flags & 1u) != 0;
+        xprog.prioritySlices = (flags & 2u) != 0 && stages < 2;
         fx::XlateImage image;
         bool built = false;
         if (stages >= 2) {

@@ -376,6 +376,13 @@ class Emitter {
         ++count_;
         if (text_) line("s_set_gpr_idx_on s" + std::to_string(sreg) + ", gpr_idx(" + (mode == 1u ? "SRC0" : mode == 2u ? "SRC1" : "DST") + ")");
     }
+    // s_memrealtime s[sdata:sdata+1] (the 100 MHz clock; diagnostics)
+    void memRealTime(int sdata) {
+        w_.push_back(0xc0000000u | (0x25u << 18) | ((uint32_t)sdata << 6));
+        w_.push_back(0u);
+        ++count_;
+        if (text_) line("s_memrealtime s[" + std::to_string(sdata) + ":" + std::to_string(sdata + 1) + "]");
+    }
     void waitLgkm0() { waitLgkm(0); }
     // s_waitcnt lgkmcnt(n), the other counters left alone (n <= 15: bits 11:8)
     void waitLgkm(int n) {
@@ -406,6 +413,12 @@ class Emitter {
         else if (s0.hasLit) w_.push_back(s0.lit);
         ++count_;
         if (text_) line(std::string(name) + " " + s0.text + ", " + s1.text);
+    }
+    // SOPK with an SGPR destination (s_getreg_b32: simm16 = {size - 1, offset, register id})
+    void sopk(uint32_t op, const char* name, int sdst, uint32_t simm, const std::string& operandText) {
+        w_.push_back(0xb0000000u | (op << 23) | ((uint32_t)sdst << 16) | (simm & 0xffffu));
+        ++count_;
+        if (text_) line(std::string(name) + " s" + std::to_string(sdst) + ", " + operandText);
     }
     void sopp(uint32_t op, const char* name, uint32_t simm, bool showImm, const std::string& text = std::string()) {
         w_.push_back(0xbf800000u | (op << 16) | (simm & 0xffffu));
@@ -463,7 +476,7 @@ enum : uint32_t {
     VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
     VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_NE_U32 = 0xcd, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_LE_F32 = 0x43, VOPC_CMP_GT_U32 = 0xcc,
     SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6, SOPP_CBRANCH_VCCNZ = 7,
-    SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_MIN_U32 = 7, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c,
+    SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_MIN_U32 = 7, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c, SOP2_LSHR_B32 = 0x1e,
     SOPC_CMP_GT_I32 = 2, SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
     VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
     VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
@@ -472,7 +485,7 @@ enum : uint32_t {
     VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49, VOPC_CMP_NGT_F32 = 0x4b, VOPC_CMP_NLE_F32 = 0x4c,
     VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOP2_AND_B32 = 0x13, VOP2_XOR_B32 = 0x15, VOP2_LSHRREV_B32 = 0x10, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
     VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F32 = 0x1cb, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
-    SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d,
+    SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d, SOP1_FLBIT_I32_B32 = 0x12, SOP2_MAX_I32 = 8,
     SOP2_ADD_U32 = 0, SOP2_SUB_U32 = 1, SOP2_ADDC_U32 = 4,
     SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
     VOP2_ASHRREV_I32 = 0x11, VOP1_FLOOR_F32 = 0x1f, VOP1_CVT_F32_I32 = 5, VOPC_CMP_EQ_U32_ = 0xca, VOPC_CMP_GT_I32 = 0xc4,
@@ -510,6 +523,7 @@ constexpr int kSPrefetched = 94;                    // s94 = 1: the leading TRAM
 constexpr int kSEventNext = 28;                         // control tracks: the sample at which the next event of the block's list is due (0xFFFFFFFF: none left)
 constexpr int kSEventPtr = 26;                          // s[26:27]: address of that event's record (fx_xlate.hpp TrackEvent)
 constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
+constexpr int kSSliceShift = 8;                        // unstaged programs with time-sliced priorities: log2 of a slice in 100 MHz ticks (emitInit)
 constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
 constexpr int kVRing = 30;                          // staged programs: lane * 4 + the LDS buffer of this sample's packets (sent and requested, see stageRequest)
 // staged programs (s4..s8 are the template's dispatch scratch and the interpreter's fetch offset: free in generated code)
@@ -780,6 +794,19 @@ class Translator {
             }
         }
         if (storesPerSample > 0) pcmAccess(false, kSPcmOut, false);
+        {
+            // diagnostics (FX_XLATE_ENDSTAMP=1, wrong output): when does each wavefront finish?  The last sample's PCM output of the
+            // wavefront's first instance is replaced by the low word of the 100 MHz clock (tools/wave_end_probe.py)
+            static const bool stamp = std::getenv("FX_XLATE_ENDSTAMP") != nullptr;
+            if (stamp && isLast_ && !staged && storesPerSample > 0) {
+                e_.memRealTime(kSTemp);
+                e_.waitLgkm0();
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), sreg(kSTemp));
+                e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), imm32(1));
+                e_.global(GLOBAL_STORE_DWORD, false, 2, kVInstance4, kSPcmOut);
+                e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
+            }
+        }
         for (int q : {kSPcmIn, kSPcmOut}) {
             bool anyInput = false;
             for (int c = 0; c < channels; ++c) anyInput = anyInput || prog_.inRows[(size_t)c] >= 0;
@@ -788,6 +815,43 @@ class Translator {
             e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(q + 1), sreg(q + 1), imm32(0));
         }
         if (!staged || ring) e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSSample), sreg(kSSample), imm32(1));   // (a later stage counts down instead)
+        if (prog_.prioritySlices && !staged) {
+            // Time slices for the wavefronts of a SIMD.  The SIMD's arbiter serves its oldest wavefront first: in a launch that
+            // fills every slot once, the first wavefront of a SIMD runs as if alone, the others take what is left, and they
+            // finish one after the other (tools/wave_end_probe.py: 18 ms apart in a 31 ms launch of the headline shape) - for
+            // the last third of the launch the SIMD holds three, two, one wavefront and issues like a half-empty one.  So every
+            // fourth sample a wavefront reads the 100 MHz clock and takes the priority ((clock >> shift) + its wave-buffer
+            // slot) & 3: at any moment the (up to four) wavefronts of a SIMD hold different levels, each the top one for the
+            // same share of the time, and they reach the end together (spread 3 ms; config5 17.8 -> 19.8, config4 7.5 -> 9.2
+            // e12 instr/s).  shift (s8, from the run-once code: a slice is about 1/24 of the block) grows with the block.
+            e_.sop2(SOP2_AND_B32, "s_and_b32", sreg(kSTemp), sreg(kSSample), imm32(3));
+            e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp), imm32(0));
+            Emitter::Fixup due = e_.branchForward(SOPP_CBRANCH_SCC1, "s_cbranch_scc1");
+            defer(due, [this]() {
+                e_.cold(true);
+                e_.memRealTime(kSTemp);
+                e_.sopk(0x11, "s_getreg_b32", kSTemp + 2, (3u << 11) | 4u, "hwreg(HW_REG_HW_ID, 0, 4)");
+                e_.waitLgkm0();
+                e_.sop2(SOP2_LSHR_B32, "s_lshr_b32", sreg(kSTemp), sreg(kSTemp), sreg(kSSliceShift));
+                e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSTemp), sreg(kSTemp + 2));
+                e_.sop2(SOP2_AND_B32, "s_and_b32", sreg(kSTemp), sreg(kSTemp), imm32(3));
+                std::vector<Emitter::Fixup> out;
+                for (uint32_t level = 0; level < 4; ++level) {
+                    Emitter::Fixup next;
+                    if (level < 3) {
+                        e_.sopc(SOPC_CMP_EQ_U32, "s_cmp_eq_u32", sreg(kSTemp), imm32(level));
+                        next = e_.branchForward(SOPP_CBRANCH_SCC0, "s_cbranch_scc0");
+                    }
+                    e_.sopp(0x0f, "s_setprio", level, true);
+                    if (level < 3) {
+                        out.push_back(e_.branchForward(SOPP_BRANCH, "s_branch"));
+                        e_.bind(next);
+                    }
+                }
+                for (const Emitter::Fixup& f : out) e_.bind(f);
+                e_.cold(false);
+            });
+        }
         if (prog_.tramDane) { if (prog_.uniformCursors) daneStep(); else daneStepPerLane(); }
         if (oneCounter) {
             // s7 counts the samples up to the next event - the group's barrier or the end of the steady stream, whichever
@@ -2612,8 +2676,17 @@ inline uint32_t align64(uint32_t v) { return (v + 63u) & ~63u; }
 // s95 = 0, returns through s[24:25]):
 //  * the LOG/EXP tables the program uses -> LDS, lane g writing segment g of every array (layout: kLds*);
 //  * s95 = 1 when this launch may issue its leading TRAM reads one sample ahead (HoistPlan).
-void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string* listing) {
+void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string* listing, int sliceBias = -1) {
     Emitter e(code, listing);
+    if (sliceBias >= 0) {
+        // time-sliced priorities (Translator::run): a slice of 2^shift ticks of the 100 MHz clock is about 1/24 of the block -
+        // shift = floor(log2(samples of the block)) + sliceBias (= log2 of a sample period in ticks / 24, from the code's modelled
+        // issue time), kept between 2^10 (10 us) and 2^20 ticks
+        e.sop1(SOP1_FLBIT_I32_B32, "s_flbit_i32_b32", sreg(kSSliceShift), sreg(kSNumSamples));
+        e.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSSliceShift), imm32((uint32_t)(31 + sliceBias)), sreg(kSSliceShift));
+        e.sop2(SOP2_MAX_I32, "s_max_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32(10));
+        e.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32(20));
+    }
     if (!prog.lutTables.empty()) {
         e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 2, imm32(2), 0);  // v2 = lane * 4 (v0 = lane)
         e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(3), 0);  // v3 = lane * 8
@@ -2993,8 +3066,15 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     out->initOff = 0;
     out->ldsBytes = 0;
     code[4].clear();
-    if (!program.lutTables.empty() || program.hoist.leadCount > 0) {
-        emitInit(program, &code[4], listing ? &listing[4] : nullptr);
+    // time-sliced priorities: log2(ticks of a sample period / 24) from the modelled issue time of the steady stream on a SIMD
+    // with four wavefronts at 2.2 GHz (100 MHz ticks: / 22)
+    int sliceBias = -1;
+    if (program.prioritySlices) {
+        const double ticks = std::max(1.0, (double)stats[0].valuClocks * 4.0 / 22.0 / 24.0);
+        sliceBias = std::max(0, (int)std::lround(std::log2(ticks)));
+    }
+    if (!program.lutTables.empty() || program.hoist.leadCount > 0 || sliceBias >= 0) {
+        emitInit(program, &code[4], listing ? &listing[4] : nullptr, sliceBias);
         out->initOff = at;
         out->ldsBytes = program.lutTables.empty() ? 0 : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
         at += align64((uint32_t)code[4].size() * 4);

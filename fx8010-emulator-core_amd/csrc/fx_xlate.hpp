@@ -137,6 +137,10 @@ struct XlateProgram {
     // delay lines far larger than the caches (set by the batch from slots x instances): TRAM loads and stores carry the
     // non-temporal hint - every slot is written once and read once, a whole delay later (+2 % at the memory-bound probe)
     bool tramStreaming = false;
+    // unstaged programs: the wavefronts of a SIMD take turns at the top priority by the clock (fx_xlate.cpp Translator::run) - for
+    // launches that fill the wave slots once (two or more wavefronts per SIMD, no second round: the dispatcher's refills do the
+    // same job there, and better)
+    bool prioritySlices = false;
     // uniform constants kept in VGPRs above the register file for the whole launch: (bit pattern, VGPR), set by planXlate
     // (the constants of the LOG/EXP index guess, which must be VGPR sources to stay in the double-rate instruction class)
     std::vector<std::pair<uint32_t, int>> vconst;

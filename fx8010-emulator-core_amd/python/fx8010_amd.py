@@ -219,9 +219,10 @@ class FrontEnd(_Reports):
         self.stage_store = [int(v) for v in info[head + 1: head + 1 + int(info[head])]] if k > 1 else []   # per row: the stage that stores it
         return code.raw[:n], text.value.decode("ascii"), k, [int(v) for v in info[:head]]
 
-    def code_hash(self, vgprs, stages=1, tram_streaming=False):
-        """fingerprint of the code object a batch would load (fxb_info xlate_code_hash of a batch in that situation)"""
-        v = int(self._lib.fxp_code_hash(self._h, int(vgprs), int(stages), 1 if tram_streaming else 0))
+    def code_hash(self, vgprs, stages=1, tram_streaming=False, priority_slices=False):
+        """fingerprint of the code object a batch would load (fxb_info xlate_code_hash of a batch in that situation);
+        priority_slices: what a batch generates when its launch fills the build's wave slots once, two or more per SIMD"""
+        v = int(self._lib.fxp_code_hash(self._h, int(vgprs), int(stages), (1 if tram_streaming else 0) | (2 if priority_slices else 0)))
         if v < 0:
             raise RuntimeError("fxp_code_hash: %d %s" % (v, self.last_error()))
         return v

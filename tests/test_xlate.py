@@ -155,7 +155,10 @@ def test_committed_counter_passes_name_the_code_generated_today():
         assert fe.load_text(P.CONFIGS[config]())
         slots = {"config5": 8192, "config3": 1000, "tram_bound": 8192, "config5_dane": 8192}.get(config, 0)
         streaming = slots * ((b["instances"] + 63) // 64) * 256 > (512 << 20)   # (fx_batch.cpp: delay lines beyond the caches)
-        now = "%016x" % fe.code_hash(int(m.group(1)), b.get("stages") or 1, streaming)
+        waves = (b["instances"] + 63) // 64
+        resident = {64: 8, 72: 7, 80: 6, 96: 5, 128: 4, 168: 3, 256: 2}[int(m.group(1))]
+        slices = (b.get("stages") or 1) == 1 and waves >= 2048 and (waves + 1023) // 1024 <= resident   # (fx_batch.cpp: one round, two or more per SIMD)
+        now = "%016x" % fe.code_hash(int(m.group(1)), b.get("stages") or 1, streaming, slices)
         assert now == b["code_hash"], "%s was collected on other code than is generated today (%s vs %s): run tools/profile_configs.sh again" % (os.path.basename(f), b["code_hash"], now)
 
 
@@ -168,7 +171,7 @@ def branch_targets(listing):
     sizes = []
     for l in lines:
         op = l.split()[0]
-        eight = (op.endswith("_e64") or op in ("v_med3_f32", "v_med3_i32", "v_fma_f32", "v_fma_f64", "v_add_f64", "v_mul_f64") or op.startswith(("global_", "ds_"))
+        eight = (op.endswith("_e64") or op in ("v_med3_f32", "v_med3_i32", "v_fma_f32", "v_fma_f64", "v_add_f64", "v_mul_f64") or op.startswith(("global_", "ds_", "s_memrealtime"))
                  or re.search(r"0x[0-9a-f]+", l) is not None)
         sizes.append(8 if eight else 4)
     assert sum(sizes) == len(code), "instruction size model"
