@@ -844,6 +844,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
             const size_t perSimd = (waves + simds - 1) / simds;
             const char* knob = std::getenv("FX_XLATE_PRIO");
             xprog.prioritySlices = knob ? std::atoi(knob) != 0 : (waves >= 2 * simds && perSimd <= (size_t)kAsmWavesPerSimd[c.variant]);
+            c.prioritySlices = xprog.prioritySlices;
         }
         XlateImage image;
         const XlateTemplate* tmpl = nullptr;
@@ -1770,7 +1771,8 @@ std::string Batch::tierNote() const {
     if (!loaded_) return "no program loaded";
     if (c_.key.empty() && !c_.useAsm && c_.low.steady.empty()) return "not lowered yet (the first block, fxb_prepare or an fxb_info query does it)";
     if (c_.useAsm && c_.useXlate)
-        return std::string("translated to gfx950 code (fx_xlate_") + regs[c_.variant] + (c_.stages > 1 ? ", " + std::to_string(c_.stages) + " stages" : "") + ")";
+        return std::string("translated to gfx950 code (fx_xlate_") + regs[c_.variant] + (c_.stages > 1 ? ", " + std::to_string(c_.stages) + " stages" : "") +
+               (c_.stages <= 1 && c_.prioritySlices ? ", wavefronts of a SIMD by turns" : "") + ")";
     if (c_.useAsm) return std::string("interpreter (fx_interp_") + regs[c_.variant] + "): " + (c_.xlateWhyNot.empty() ? "no translation asked for" : c_.xlateWhyNot);
     return "HIP C++ kernel (" + std::to_string(c_.low.instPerLane) + " instance(s) per lane): " + (c_.asmWhyNot.empty() ? "no assembly tier asked for" : c_.asmWhyNot);
 }

@@ -156,6 +156,7 @@ private:
         int inlined = 0, called = 0, unsaturated = 0, valu = 0, valuSlow = 0, valuClocks = 0, vgprConstants = 0;
         std::vector<uint8_t> wildRow;
         std::string xlateWhyNot;
+        bool prioritySlices = false;   // generated code: the wavefronts of a SIMD take turns at the top priority (fx_xlate.hpp)
         bool deferred = false;          // the interpreter runs this one because controls were moving when it was built
         uint32_t* dStream = nullptr;    // records / row table / stage descriptors on the device
         size_t streamCap = 0;

@@ -2681,10 +2681,12 @@ void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string
     if (sliceBias >= 0) {
         // time-sliced priorities (Translator::run): a slice of 2^shift ticks of the 100 MHz clock is about 1/24 of the block -
         // shift = floor(log2(samples of the block)) + sliceBias (= log2 of a sample period in ticks / 24, from the code's modelled
-        // issue time), kept between 2^10 (10 us) and 2^20 ticks
+        // issue time), kept between 2^16 (0.66 ms: a wavefront looks at the clock every fourth sample, and a low-priority one is
+        // slow - shorter slices than that it misses; measured on blocks of 64 ... 512 samples) and 2^20 ticks
         e.sop1(SOP1_FLBIT_I32_B32, "s_flbit_i32_b32", sreg(kSSliceShift), sreg(kSNumSamples));
         e.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSSliceShift), imm32((uint32_t)(31 + sliceBias)), sreg(kSSliceShift));
-        e.sop2(SOP2_MAX_I32, "s_max_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32(10));
+        static const int minShift = std::getenv("FX_XLATE_PRIO_MINSHIFT") ? std::atoi(std::getenv("FX_XLATE_PRIO_MINSHIFT")) : 16;   // (diagnostics)
+        e.sop2(SOP2_MAX_I32, "s_max_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32((uint32_t)minShift));
         e.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32(20));
     }
     if (!prog.lutTables.empty()) {

@@ -723,3 +723,48 @@ def test_tier_note_says_which_tier_runs_and_why(gpu, monkeypatch):
     assert interp.load_text(progs.CONFIGS["config2"]())
     interp.process_block(x)
     assert 2 <= interp.info("kernel") <= 8 and interp.tier_note().startswith("interpreter (fx_interp_v"), interp.tier_note()
+
+
+@pytest.mark.gpu
+def test_wavefronts_of_a_simd_take_turns_only_where_a_launch_is_one_round(gpu, monkeypatch):
+    """generated code gives the wavefronts of a SIMD the top priority by turns (by the clock) where a launch fills the build's wave
+    slots once with two or more per SIMD - 131 072 instances: 2 048 wavefronts on 1 024 SIMDs - and not for a single wavefront
+    per SIMD or less; results are the same bits either way (priorities change who issues when, nothing else), here against the
+    oracle on sampled instances and against the same batch with the mode off"""
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    monkeypatch.delenv("FX_XLATE_PRIO", raising=False)
+    import torch
+    text = progs.CONFIGS["config3"]()
+    S = 40
+    small = gpu.Batch(4096, 1, 0)
+    assert small.load_text(text)
+    small.process_block(progs.stimulus(4096, 8))
+    assert "by turns" not in small.tier_note(), small.tier_note()
+    N = 131072
+    x = torch.empty((S, N), dtype=torch.float32, device="cuda").uniform_(-0.9, 0.9)
+    outs = []
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("FX_XLATE_PRIO", raising=False)
+        else:
+            monkeypatch.setenv("FX_XLATE_PRIO", mode)
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        y = torch.empty_like(x)
+        for at in (0, 17):   # two blocks: state carried over
+            n = 17 if at == 0 else S - 17
+            b.process_block_dev(x[at:at + n].data_ptr(), y[at:at + n].data_ptr(), n)
+        b.sync()
+        assert b.info("kernel") >= 9 and (("by turns" in b.tier_note()) == (mode is None)), b.tier_note()
+        outs.append(y.cpu().numpy())
+        if mode is None:
+            xh = x.cpu().numpy()
+            for inst in (0, 63, 64, 65535, 99999, N - 1):
+                o = Oracle(1)
+                assert o.load_text(text)
+                ref = o.process_block(xh[:, inst].copy())
+                assert np.array_equal(ref.view(np.uint32), np.ascontiguousarray(outs[0][:, inst]).view(np.uint32)), inst
+                assert b.instruction_counter_i(inst) == o.instruction_counter()
+        del b
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
