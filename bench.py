@@ -218,8 +218,9 @@ def kernel_name(batch):
         return "fx_interp_lds (gfx950 asm interpreter, LDS register file)"
     if kid <= 8:
         return "fx_interp_v%d (gfx950 asm interpreter, VGPR register file)" % vg[kid]
-    return ("fx_xlate_v%d (program translated to gfx950 code: %d records inline, %d handler calls, %d saturations elided, %d code bytes)"
-            % (vg[kid - 7], batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_unsaturated"), batch.info("xlate_code_bytes")))
+    turns = "; the wavefronts of a SIMD take turns at the top priority" if "by turns" in batch.tier_note() else ""
+    return ("fx_xlate_v%d (program translated to gfx950 code: %d records inline, %d handler calls, %d saturations elided, %d code bytes%s)"
+            % (vg[kid - 7], batch.info("xlate_inlined"), batch.info("xlate_called"), batch.info("xlate_unsaturated"), batch.info("xlate_code_bytes"), turns))
 
 
 class ClockSampler:

@@ -263,6 +263,29 @@ def test_dane_model_listing_reassembles_and_has_no_cursor_advance():
         assert "s_sub_i32 s80, s80, 1" not in listing
 
 
+@needs_llvm
+def test_priority_turns_listing_reassembles(monkeypatch):
+    """what a batch generates for a launch of one round (fx_batch.cpp: two or more wavefronts per SIMD, no second round): every
+    fourth sample the wavefront reads the 100 MHz clock and takes the priority ((clock >> s8) + wave-buffer slot) & 3; s8 comes from
+    the run-once code (log2 of the block length + log2 of the modelled sample period / 24, at least 16).  The new encodings
+    (s_memrealtime, s_getreg_b32, s_setprio, s_flbit_i32_b32, s_max_i32, s_lshr_b32) against llvm-mc; off by default here."""
+    fe = A.FrontEnd(1)
+    assert fe.load_text(P.CONFIGS["config5"]())
+    code0, listing0 = fe.translate(128, 0)
+    assert "s_setprio" not in listing0 and "s_memrealtime" not in listing0
+    monkeypatch.setenv("FX_XLATE_PRIO", "1")
+    for stream in (0, 1, 2, 3, 4):
+        code, listing = fe.translate(128, stream)
+        assert assemble(listing) == code, stream
+        if stream < 4:
+            assert listing.count("s_memrealtime s[62:63]") == 1 and [listing.count("s_setprio %d" % k) for k in range(4)] == [1, 1, 1, 1]
+            assert "s_getreg_b32 s64, hwreg(HW_REG_HW_ID, 0, 4)" in listing and "s_lshr_b32 s62, s62, s8" in listing
+        else:
+            assert listing.startswith("s_flbit_i32_b32 s8, s9\ns_sub_i32 s8, 36, s8\ns_max_i32 s8, s8, 16\ns_min_i32 s8, s8, 20\n"), listing[:120]
+    assert len(fe.translate(128, 0)[0]) > len(code0)
+    assert fe.code_hash(128, 1, False, True) != fe.code_hash(128, 1, False, False)
+
+
 def test_translate_reports_ineligible_programs():
     fe = A.FrontEnd(1)
     # SKIP over END: multi-pass program, runs on the HIP C++ kernel instead
