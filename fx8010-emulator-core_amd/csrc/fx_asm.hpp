@@ -39,7 +39,8 @@ struct AsmArgs {
     const uint32_t* stages;  // translated programs cut into stages: StageDescriptor[nStages] (fx_xlate.hpp), else nullptr
     int nStages;             // wavefronts per workgroup (0 / 1: the whole program in one)
     int tramDane;            // interpreter builds, bit 0: the opt-in DANE delay-line model is in force (the address counters step once per sample
-                             // period); bit 1: multi-pass program (END lies in a SKIP shadow: the kernel runs passes until every lane has executed it)
+                             // period); bit 1: multi-pass program (END lies in a SKIP shadow: the kernel runs passes until every lane has executed it);
+                             // bit 2: the wavefronts of a SIMD take turns at the top priority, 2^(bits 12:8) ticks of 10 ns each
 };
 static_assert(offsetof(AsmArgs, lut) == 0x40, "AsmArgs layout");
 static_assert(offsetof(AsmArgs, nLoad) == 0x58, "AsmArgs layout");

@@ -1355,6 +1355,18 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             g.lutX1Off = kLutX1Off * 8;
             g.tramDane = (c_.low.tramDane && (c_.low.usesITram || c_.low.usesXTram)) ? 1 : 0;   // (like the other tiers: counters step where the program has taps)
             if (c_.low.multipass) g.tramDane |= 2;
+            if (!c_.useXlate && c_.variant != ASM_LDS) {
+                // the interpreter's wavefronts take turns at the top priority like generated code's (fx_xlate.hpp prioritySlices):
+                // where the launch fills the build's wave slots once with two or more per SIMD; a turn = 1/24 of the block at
+                // about 20 us per sample and four wavefronts, between 0.66 and 10 ms
+                const size_t waves = ((size_t)n_ + 63) / 64, perSimd = (waves + 1023) / 1024;
+                const char* knob = std::getenv("FX_XLATE_PRIO");
+                if (knob ? std::atoi(knob) != 0 : (waves >= 2048 && perSimd <= (size_t)kAsmWavesPerSimd[c_.variant])) {
+                    int shift = 6;
+                    while ((1 << (shift - 6 + 1)) <= a.nSamples) ++shift;   // floor(log2(samples of the launch)) + 6
+                    g.tramDane |= 4 | (std::min(std::max(shift, 16), 20) << 8);
+                }
+            }
             if (c_.useXlate) {
                 // code streams are named by their byte offset from the kernel entry: {fast, exact} per argument
                 g.steady = reinterpret_cast<const uint32_t*>((uintptr_t)c_.steady);

@@ -87,7 +87,8 @@
 	.set KA_STAGES,   0xc0      // translated programs cut into stages (fx_xlate.hpp StageDescriptor[nStages], 32 bytes each), 0 = none
 	.set KA_NSTAGES,  0xc8      // wavefronts per workgroup = stages of the program (0 or 1: one wavefront runs all of it)
 	.set KA_TRAMDANE, 0xcc      // interpreter builds, bit 0: the opt-in DANE delay-line model (address counters step once per sample period);
-	                            //  bit 1: multi-pass program (END inside a SKIP shadow: lanes that skipped it run the program again)
+	                            //  bit 1: multi-pass program (END inside a SKIP shadow: lanes that skipped it run the program again);
+	                            //  bit 2: the wavefronts of a SIMD take turns at the top priority, turns of 2^(bits 12:8) ticks of 10 ns
 	.set KA_SIZE,     0xd0
 
 // ---- out-of-domain flag bits (fx_kernel.hpp) ----
@@ -752,6 +753,38 @@ h_endsample_d:
 	s_nop 1
 	v_cndmask_b32 v18, v5, v6, vcc
 .Le_counters:
+	// A launch that fills the wave slots once: the wavefronts of a SIMD take turns at the top priority (the arbiter serves the
+	// oldest first, and they would finish one after the other - DESIGN.md section 5).  Mode bit 2; every fourth sample the priority
+	// becomes ((100 MHz clock >> mode bits 12:8) + wave-buffer slot) & 3.
+	s_bitcmp1_b32 s70, 2
+	s_cbranch_scc0 .Le_noturn
+	s_and_b32 s62, s3, 3
+	s_cmp_eq_u32 s62, 3
+	s_cbranch_scc0 .Le_noturn
+	s_memrealtime s[62:63]
+	s_getreg_b32 s64, hwreg(HW_REG_HW_ID, 0, 4)
+	s_bfe_u32 s65, s70, 0x50008
+	s_waitcnt lgkmcnt(0)
+	s_lshr_b32 s62, s62, s65
+	s_add_u32 s62, s62, s64
+	s_and_b32 s62, s62, 3
+	s_cmp_eq_u32 s62, 0
+	s_cbranch_scc0 .Le_turn1
+	s_setprio 0
+	s_branch .Le_noturn
+.Le_turn1:
+	s_cmp_eq_u32 s62, 1
+	s_cbranch_scc0 .Le_turn2
+	s_setprio 1
+	s_branch .Le_noturn
+.Le_turn2:
+	s_cmp_eq_u32 s62, 2
+	s_cbranch_scc0 .Le_turn3
+	s_setprio 2
+	s_branch .Le_noturn
+.Le_turn3:
+	s_setprio 3
+.Le_noturn:
 	s_add_u32 s3, s3, 1
 	s_cmp_lt_i32 s3, s9
 	s_waitcnt vmcnt(0)
