@@ -843,7 +843,9 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
             const size_t waves = ((size_t)n_ + 63) / 64, simds = 1024;
             const size_t perSimd = (waves + simds - 1) / simds;
             const char* knob = std::getenv("FX_XLATE_PRIO");
-            xprog.prioritySlices = knob ? std::atoi(knob) != 0 : (waves >= 2 * simds && perSimd <= (size_t)kAsmWavesPerSimd[c.variant]);
+            // (four priority levels: with five wavefronts on a SIMD two of them share one - 327 680 instances on the 96-register build
+            // measured 4.5 % slower with the turns than without)
+            xprog.prioritySlices = knob ? std::atoi(knob) != 0 : (waves >= 2 * simds && perSimd <= (size_t)std::min(4, kAsmWavesPerSimd[c.variant]));
             c.prioritySlices = xprog.prioritySlices;
         }
         XlateImage image;
@@ -1361,7 +1363,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                 // about 20 us per sample and four wavefronts, between 0.66 and 10 ms
                 const size_t waves = ((size_t)n_ + 63) / 64, perSimd = (waves + 1023) / 1024;
                 const char* knob = std::getenv("FX_XLATE_PRIO");
-                if (knob ? std::atoi(knob) != 0 : (waves >= 2048 && perSimd <= (size_t)kAsmWavesPerSimd[c_.variant])) {
+                if (knob ? std::atoi(knob) != 0 : (waves >= 2048 && perSimd <= (size_t)std::min(4, kAsmWavesPerSimd[c_.variant]))) {
                     int shift = 6;
                     while ((1 << (shift - 6 + 1)) <= a.nSamples) ++shift;   // floor(log2(samples of the launch)) + 6
                     g.tramDane |= 4 | (std::min(std::max(shift, 16), 20) << 8);
