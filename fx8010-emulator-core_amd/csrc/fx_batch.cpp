@@ -776,6 +776,13 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
                 // bursts, and at most 4 wavefronts per SIMD will be resident anyway - the 128-register build costs nothing
                 if (stagingPossible())
                     while (v < ASM_V128) ++v;
+                // two or more wavefronts per SIMD: they take turns at the top priority (fx_xlate.hpp prioritySlices), which has
+                // four levels - and a fifth resident wavefront adds nothing to a SIMD that four keep issuing (measured: config5
+                // at 5 per SIMD on the 96-register build = at 4 per SIMD).  So at most four slots: the 128-register build or
+                // larger, for batches of any number of rounds (1 048 576 instances, 4 slots with turns against 5-8 without:
+                // config5 + 2.0 %, config4 + 2.4 %, the memory-bound probe and config3 unchanged).
+                if (((size_t)n_ + 63) / 64 >= 2048)
+                    while (v < ASM_V128) ++v;
                 const char* pin = forceHip ? std::strstr(forceHip, "_v") : nullptr;
                 if (pin && (std::strncmp(forceHip, "asm_v", 5) == 0 || std::strncmp(forceHip, "xlate_v", 7) == 0)) {
                     // diagnostics: pin a (large enough) build of the interpreter (asm_vNN) or of the translator (xlate_vNN)
@@ -838,14 +845,11 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
         // 256 bytes per wavefront and slot; the Infinity Cache holds 256 MiB
         xprog.tramStreaming = ((size_t)iSlotsAlloc_ + (size_t)xSlotsAlloc_) * (((size_t)n_ + 63) / 64) * 256 > ((size_t)512 << 20);
         {
-            // wavefronts of a SIMD by turns at the top priority (fx_xlate.hpp prioritySlices): where the launch fills the build's
-            // wave slots once and a SIMD holds two or more (FX_XLATE_PRIO=0 / 1 in the environment: never / whenever unstaged)
+            // wavefronts of a SIMD by turns at the top priority (fx_xlate.hpp prioritySlices): wherever a SIMD holds two or more
+            // (the build chosen above has at most four slots then; FX_XLATE_PRIO=0 / 1 in the environment: never / whenever unstaged)
             const size_t waves = ((size_t)n_ + 63) / 64, simds = 1024;
-            const size_t perSimd = (waves + simds - 1) / simds;
             const char* knob = std::getenv("FX_XLATE_PRIO");
-            // (four priority levels: with five wavefronts on a SIMD two of them share one - 327 680 instances on the 96-register build
-            // measured 4.5 % slower with the turns than without)
-            xprog.prioritySlices = knob ? std::atoi(knob) != 0 : (waves >= 2 * simds && perSimd <= (size_t)std::min(4, kAsmWavesPerSimd[c.variant]));
+            xprog.prioritySlices = knob ? std::atoi(knob) != 0 : (waves >= 2 * simds && kAsmWavesPerSimd[c.variant] <= 4);
             c.prioritySlices = xprog.prioritySlices;
         }
         XlateImage image;
@@ -1359,11 +1363,11 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             if (c_.low.multipass) g.tramDane |= 2;
             if (!c_.useXlate && c_.variant != ASM_LDS) {
                 // the interpreter's wavefronts take turns at the top priority like generated code's (fx_xlate.hpp prioritySlices):
-                // where the launch fills the build's wave slots once with two or more per SIMD; a turn = 1/24 of the block at
-                // about 20 us per sample and four wavefronts, between 0.66 and 10 ms
-                const size_t waves = ((size_t)n_ + 63) / 64, perSimd = (waves + 1023) / 1024;
+                // wherever a SIMD holds two or more (a build of at most four slots); a turn = 1/24 of the block at about 20 us
+                // per sample and four wavefronts, between 0.66 and 10 ms
+                const size_t waves = ((size_t)n_ + 63) / 64;
                 const char* knob = std::getenv("FX_XLATE_PRIO");
-                if (knob ? std::atoi(knob) != 0 : (waves >= 2048 && perSimd <= (size_t)std::min(4, kAsmWavesPerSimd[c_.variant]))) {
+                if (knob ? std::atoi(knob) != 0 : (waves >= 2048 && kAsmWavesPerSimd[c_.variant] <= 4)) {
                     int shift = 6;
                     while ((1 << (shift - 6 + 1)) <= a.nSamples) ++shift;   // floor(log2(samples of the launch)) + 6
                     g.tramDane |= 4 | (std::min(std::max(shift, 16), 20) << 8);

@@ -138,8 +138,7 @@ struct XlateProgram {
     // non-temporal hint - every slot is written once and read once, a whole delay later (+2 % at the memory-bound probe)
     bool tramStreaming = false;
     // unstaged programs: the wavefronts of a SIMD take turns at the top priority by the clock (fx_xlate.cpp Translator::run) - for
-    // launches that fill the wave slots once (two or more wavefronts per SIMD, no second round: the dispatcher's refills do the
-    // same job there, and better)
+    // batches of two or more wavefronts per SIMD, which run on a build of at most four wave slots (four priority levels)
     bool prioritySlices = false;
     // uniform constants kept in VGPRs above the register file for the whole launch: (bit pattern, VGPR), set by planXlate
     // (the constants of the LOG/EXP index guess, which must be VGPR sources to stay in the double-rate instruction class)

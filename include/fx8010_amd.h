@@ -326,8 +326,8 @@ int64_t fxp_translate_staged(fxp_handle* h, int vgprs, int stages, int stage, in
 /* Fingerprint (63 bits, >= 0; negative FX_E_*) of the code object a batch would load for this program with its registers' initial
  * values: the `vgprs` build (64 ... 256), cut into at most `stages` stages (1: not cut; the default LDS budget and step length
  * of a small batch with long blocks), flags bit 0 = delay lines larger than the caches (non-temporal TRAM accesses), bit 1 =
- * the wavefronts of a SIMD take turns at the top priority (what a batch generates when its launch fills the wave slots once with two
- * or more wavefronts per SIMD).  Equals
+ * the wavefronts of a SIMD take turns at the top priority (what a batch of two or more wavefronts per SIMD generates, on a build of
+ * at most four wave slots: 128 registers and up).  Equals
  * fxb_info(FXB_INFO_XLATE_CODE_HASH) of a batch in that situation: tests and bench.py use it to tell whether a committed profile
  * still describes the code that is generated today. */
 int64_t fxp_code_hash(fxp_handle* h, int vgprs, int stages, unsigned flags);

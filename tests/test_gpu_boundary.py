@@ -727,10 +727,10 @@ def test_tier_note_says_which_tier_runs_and_why(gpu, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["default", "asm"])
-def test_wavefronts_of_a_simd_take_turns_only_where_a_launch_is_one_round(gpu, kernel, monkeypatch):
-    """generated code gives the wavefronts of a SIMD the top priority by turns (by the clock) where a launch fills the build's wave
-    slots once with two or more per SIMD - 131 072 instances: 2 048 wavefronts on 1 024 SIMDs - and not for a single wavefront
-    per SIMD or less; results are the same bits either way (priorities change who issues when, nothing else), here against the
+def test_wavefronts_of_a_simd_take_turns(gpu, kernel, monkeypatch):
+    """generated code gives the wavefronts of a SIMD the top priority by turns (by the clock) wherever a SIMD holds two or more -
+    131 072 instances: 2 048 wavefronts on 1 024 SIMDs - and not for a single wavefront per SIMD or less; results are the same
+    bits either way (priorities change who issues when, nothing else), here against the
     oracle on sampled instances and against the same batch with the mode off"""
     monkeypatch.delenv("FX_KERNEL", raising=False)
     monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
