@@ -265,7 +265,7 @@ def test_dane_model_listing_reassembles_and_has_no_cursor_advance():
 
 @needs_llvm
 def test_priority_turns_listing_reassembles(monkeypatch):
-    """what a batch generates for a launch of one round (fx_batch.cpp: two or more wavefronts per SIMD, no second round): every
+    """what a batch of two or more wavefronts per SIMD generates (fx_batch.cpp; on a build of at most four wave slots): every
     fourth sample the wavefront reads the 100 MHz clock and takes the priority ((clock >> s8) + wave-buffer slot) & 3; s8 comes from
     the run-once code (log2 of the block length + log2 of the modelled sample period / 24, at least 16).  The new encodings
     (s_memrealtime, s_getreg_b32, s_setprio, s_flbit_i32_b32, s_max_i32, s_lshr_b32) against llvm-mc; off by default here."""
