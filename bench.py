@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — aggregate emulated DSP MIPS of the MI355X batch FX8010 interpreter.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config config5] [--samples S] [--instances M]
-                    [--sharded] [--no-extras] [--parity-instances P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak] [--config config5] [--samples S]
+                    [--instances M] [--sharded] [--no-extras] [--parity-instances P]
 
 One "step" = one pass of the hot path over one batch of synthetic PCM: fxb_process_block_dev()
-for S sample periods on this rank's M instances (inputs already resident in HBM).  The default
-workload is the per-GPU shard of BASELINE.json configs[4] — the configuration the north-star
-target (>= 1e12 emulated instr/s on 8 GPUs) is quoted on: 262 144 instances/GPU of the 512-instr
-reverb with an 8192-sample xTRAM, so that `--gpus 8` is exactly configs[4] (2 097 152 instances,
-weak scaling, no collective on the data path).  `--config config2|config3|config4` select the
-other single-GPU configurations with their BASELINE.json instance counts.
+for S sample periods on this rank's instances (inputs already resident in HBM).  The default
+workload is BASELINE.json configs[4] - the configuration the north-star target (>= 1e12 emulated
+instr/s on 8 GPUs) is quoted on: 2 097 152 instances of the 512-instr reverb with an 8192-sample
+xTRAM each (64 GiB of delay memory), "sharded across 8 MI355X".  That is a FIXED total, so the
+default is STRONG scaling: `--gpus N` splits the 2 097 152 instances into N contiguous ranges
+(fx8010_shard.shard_range; no collective on the data path) - all of them on the one GPU at N = 1,
+262 144 each at N = 8.  `--scaling weak` keeps 262 144 instances on every GPU instead (N = 8 is
+the same job either way).  `--config config2|config3|config4` select the single-GPU
+configurations with their BASELINE.json instance counts; `--instances M` overrides the count
+(strong: of the whole job, weak: per GPU).
 
 For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU); ranks
 only meet in the barriers around the timed region and in the MAX-reduction of the elapsed time.
@@ -22,7 +26,9 @@ Output: ONE JSON line (rank 0) with the contract fields plus
                 roofline.valu: the vector-ALU issue roofline that actually bounds this path
   cpu_baseline  the unmodified reference (oracle/_ref) timed on this box's host cores (N = 1 only)
   parity        instances of the timed run compared bit for bit with the CPU oracle after the timed region
-  extra         (N = 1, default workload only) the other single-GPU configurations and all of configs[4] on one GPU
+  extra         (N = 1, default workload only) the other single-GPU configurations, the 1/8 shard of configs[4]
+                (what every GPU of an 8-GPU job runs) and the reference's own real-time measure (32-sample blocks
+                against 666.667 us, tools/realtime_capacity.py)
 """
 import argparse
 import json
@@ -49,7 +55,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="config5", choices=["config2", "config3", "config4", "config5", "tram_bound", "config5_dane"])
     ap.add_argument("--samples", type=int, default=4096, help="sample periods per step (block length S; SURVEY 8d: 4096)")
-    ap.add_argument("--instances", type=int, default=0, help="instances per GPU (0 = BASELINE.json's count)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default): the config's instance count is the WHOLE job, split over the GPUs (configs[4]: 2 097 152 'sharded across 8'); "
+                         "weak: every GPU runs the config's per-GPU share (config5: 262 144) whatever their number")
+    ap.add_argument("--instances", type=int, default=0, help="instances (strong: of the whole job; weak: per GPU); 0 = BASELINE.json's count")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only); 0 disables")
     ap.add_argument("--parity-instances", type=int, default=1024, help="instances checked against the oracle after the timed region (0 disables)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations (they run by default for N=1, default workload)")
@@ -59,6 +68,21 @@ def parse():
                          "(build() does that wherever /root/reference exists; the .so is git-ignored and travels to the GPU box) - the policy; "
                          "'port' = oracle/libfxoracle.so, this repo's C restatement (also what a tree without the prebuilt reference falls back to, and says so)")
     return ap.parse_args()
+
+
+def plan_instances(config, scaling, instances, world, rank, progs, shard):
+    """Which instances rank `rank` of `world` owns: (first instance, count, instances of the whole job).
+    strong: BASELINE.json's total for the config (configs[4]: 2 097 152), contiguous balanced ranges (ragged totals: counts
+    differ by one); weak: the config's per-GPU share on every rank.  Pure: the CPU tests check the totals for N = 1, 2, 4, 8."""
+    if scaling == "strong":
+        total = int(instances) or progs.CONFIG_TOTAL_INSTANCES[config]
+        if total < world:
+            raise SystemExit("fewer instances (%d) than GPUs (%d)" % (total, world))
+        first, count = shard.shard_range(total, world, rank)
+        return first, count, total
+    per = int(instances) or progs.CONFIG_INSTANCES[config]
+    first, count = shard.weak_shard(per, rank)
+    return first, count, per * world
 
 
 def device_stimulus(torch, n_inst, n_samples, first_instance, device):
@@ -277,18 +301,19 @@ class ClockSampler:
         return (round(sum(f) / len(f) / 1e6, 1) if f else None), (round(sum(w) / len(w) / 1e6, 1) if w else None)
 
 
-def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warmup, devices, rank, dist, reduce_dev, parity_n):
-    """One configuration on this process's device(s).  Returns (fields for the JSON line, batch text)."""
+def run_workload(torch, fx8010_amd, progs, shard, config, n_local, first_instance, scaling, S, steps, warmup, devices, rank, dist, reduce_dev, parity_n):
+    """One configuration on this process's device(s): instances [first_instance, first_instance + n_local) of the job
+    (--sharded: split once more over this process's devices by the library).  Returns (fields for the JSON line, batch text)."""
     text = progs.CONFIGS[config]()
     P = progs.count_instructions(text)
     sharded = len(devices) > 1
-    batch = fx8010_amd.Batch(n_inst * len(devices), 1, devices=devices) if sharded else fx8010_amd.Batch(n_inst, 1, devices[0])
+    batch = fx8010_amd.Batch(n_local, 1, devices=devices) if sharded else fx8010_amd.Batch(n_local, 1, devices[0])
     option = getattr(progs, "CONFIG_OPTIONS", {}).get(config, 0)  # opt-in behaviour beyond the reference (config5_dane)
     if option:
         batch.set_option(option)
     if not batch.load_text(text):
         raise RuntimeError("program failed to load: %s" % batch.errors())
-    first_instance, _ = shard.weak_shard(n_inst, rank)  # weak scaling: every GPU owns n_inst instances
+    n_inst = batch.shards()[0][2]   # instances on this rank's (first) GPU: what its kernel launch processes
     xs, ys, streams = [], [], []
     for k, (dev_ord, first, count) in enumerate(batch.shards()):
         dev = torch.device("cuda", dev_ord)
@@ -347,6 +372,8 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
     per_gpu_elapsed_s = shard.gather_scalars(dist, elapsed, reduce_dev)
     elapsed = shard.reduce_scalar(dist, elapsed, "max", reduce_dev)        # slowest rank
     executed_all = shard.reduce_scalar(dist, executed, "sum", reduce_dev)  # whole job
+    n_job = int(round(shard.reduce_scalar(dist, n_local, "sum", reduce_dev)))
+    per_gpu_instances = [c for _, _, c in batch.shards()] if sharded else [int(round(v)) for v in shard.gather_scalars(dist, n_local, reduce_dev)]
 
     parity = None
     if rank == 0 and parity_n > 0:
@@ -358,7 +385,7 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
                     return ys[k][:, n - f].cpu().numpy()
             raise IndexError(n)
 
-        parity = parity_check(text, y_last, n_inst * len(devices), first_instance, S, warmup + steps, parity_n, option)
+        parity = parity_check(text, y_last, n_local, first_instance, S, warmup + steps, parity_n, option)
 
     res = None
     if rank == 0:
@@ -393,7 +420,7 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
                     "frac": round(per_s / peak, 4), "peak_nominal_2clk": round(peak_nominal / 1e9, 1), "frac_of_nominal_2clk_peak": round(per_s / peak_nominal, 4),
                     "code_hash": code_hash, "valu_per_wave_sample": valu_per_wave_sample, "waves_per_simd": round(waves * stages / float(SIMDS), 3),
                     "stages": stages,
-                    "valu_per_emulated_instr": round(valu_per_wave_sample / max(executed / float(steps * S * n_inst * n_dev), 1e-9), 3),
+                    "valu_per_emulated_instr": round(valu_per_wave_sample / max(executed / float(steps * S * n_local), 1e-9), 3),
                     "valu_4clock_class_per_wave_sample": batch.info("xlate_valu_slow"),
                     "issue_clocks_per_wave_sample": clocks, "clock_mhz": clock_mhz, "power_w": power_w,
                     "clocks_per_valu_per_simd": round(kernel_ms * 1e-3 * hz / (valu_per_wave_sample * max(waves / float(SIMDS), 1.0) * S), 3),
@@ -409,11 +436,12 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
             "value": round(mips, 1),
             "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 4),
             "config": {
-                "workload": "%s: %d instances/GPU x %d-instr program, block of %d samples, mono 48 kHz" % (config, n_inst, P, S),
+                "workload": "%s: %d instances in all (%s scaling: %s on this GPU) x %d-instr program, block of %d samples, mono 48 kHz"
+                            % (config, n_job, scaling, ("all of them" if n_inst == n_job else "%d" % n_inst), P, S),
                 "name": config, "instances_per_gpu": n_inst, "samples_per_step": S,
-                "instances_total": n_inst * max(n_dev, 1) * (dist.get_world_size() if dist is not None else 1),
+                "instances_total": n_job, "per_gpu_instances": per_gpu_instances,
                 "instr_per_sample_static": P,
-                "instr_per_sample_executed": round(executed / float(steps * S * n_inst * n_dev), 3),
+                "instr_per_sample_executed": round(executed / float(steps * S * n_local), 3),
                 "tram_ops_per_sample": tram_ops,
                 "lane_register_rows": rows,
                 "parity_domain_flags": ood,
@@ -435,6 +463,7 @@ def run_workload(torch, fx8010_amd, progs, shard, config, n_inst, S, steps, warm
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": "the interpreter is instruction-issue bound (>= 12 emulated instr per algorithmic HBM byte): see roofline.valu and DESIGN.md section 5",
                 "emulated_instr_per_s_per_gpu": round(executed / n_dev / (kernel_ms * 1e-3 * steps), 1),
+                "algorithmic_bytes_note": "instances on this GPU x (samples x (4 B PCM in + 4 B PCM out + 4 B per executed delay-line read / write) + 2 x 4 B x (register rows + 9) once per block)",
                 "valu": valu,
             },
         }
@@ -478,11 +507,15 @@ def main():
         dist = shard.init_process_group("gloo" if rehearsal else "nccl", dev)  # RCCL; None for a single process
         reduce_dev = "cpu" if rehearsal else dev
 
-    n_inst = args.instances or progs.CONFIG_INSTANCES[args.config]
-    S = args.samples
-    res, text = run_workload(torch, fx8010_amd, progs, shard, args.config, n_inst, S, args.steps, args.warmup, devices, rank, dist, reduce_dev,
-                             args.parity_instances)
     n_gpus = args.gpus if args.sharded else world
+    S = args.samples
+    if args.sharded:   # this process owns the whole job; the library splits it over its devices (fx_shard.cpp Sharded::plan)
+        first = 0
+        n_local = (args.instances or progs.CONFIG_TOTAL_INSTANCES[args.config]) if args.scaling == "strong" else (args.instances or progs.CONFIG_INSTANCES[args.config]) * n_gpus
+    else:
+        first, n_local, _ = plan_instances(args.config, args.scaling, args.instances, world, rank, progs, shard)
+    res, text = run_workload(torch, fx8010_amd, progs, shard, args.config, n_local, first, args.scaling, S, args.steps, args.warmup, devices, rank, dist,
+                             reduce_dev, args.parity_instances)
 
     if rank == 0:
         out = {
@@ -494,7 +527,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32+f64",  # the path computes in IEEE fp32 with fp64 for INTERP / LOG / EXP, as the reference does
             "data": "synthetic",
@@ -508,16 +541,17 @@ def main():
         single = n_gpus == 1
         if single and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(text, args.cpu_seconds, args.cpu_baseline)
-        if single and not args.no_extras and args.config == "config5" and not args.instances and S == 4096:
-            # the other single-GPU configurations of BASELINE.json at their instance counts, and ALL of configs[4]
-            # (2 097 152 instances, 64 GiB of xTRAM) on this one GPU; fewer launches each, same block length
+        if single and not args.no_extras and args.config == "config5" and args.scaling == "strong" and not args.instances and S == 4096:
+            # the other single-GPU configurations of BASELINE.json at their instance counts, and the 1/8 shard of configs[4]
+            # (262 144 instances: what every GPU of the 8-GPU job runs - the N = 8 point of the strong-scaling curve is 8 x this);
+            # fewer launches each, same block length
             extra = {}
             # (enough launches for the clock sampler to see the chip at its working clock: config2's launch takes 0.6 ms)
-            plan = [("config2", 4096, 400, 256), ("config3", 65536, 40, 256), ("config4", 262144, 8, 256), ("config5_full_1gpu", 2097152, 4, 64)]
+            plan = [("config2", 4096, 400, 256), ("config3", 65536, 40, 256), ("config4", 262144, 8, 256), ("config5_shard_1of8", 262144, 20, 256)]
             for name, n, k, pn in plan:
                 cfg = "config5" if name.startswith("config5") else name
                 try:
-                    r, _ = run_workload(torch, fx8010_amd, progs, shard, cfg, n, S, k, 1, devices, 0, None, "cpu", pn)
+                    r, _ = run_workload(torch, fx8010_amd, progs, shard, cfg, n, 0, "weak" if name.startswith("config5") else "strong", S, k, 1, devices, 0, None, "cpu", pn)
                     extra[name] = {"value": r["value"], "unit": "MIPS", "steps": k, "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
                                    "instr_per_sample_executed": r["config"]["instr_per_sample_executed"],
                                    "kernel_ms": r["roofline"]["kernel_ms"], "hbm_frac": r["roofline"]["frac"],

@@ -22,6 +22,7 @@
 #include <thread>
 
 #include "../../include/fx8010_amd.h"
+#include "fx_knobs.hpp"
 
 namespace fx {
 
@@ -34,7 +35,7 @@ constexpr size_t kScratchBytes = 1 << 16;
 inline uint32_t bitsOf(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 }  // namespace
 
-Batch::Batch(int64_t nInstances, int channels, int device) : prog_(channels) {
+Batch::Batch(int64_t nInstances, int channels, int device) : prog_(channels), knobs_(ReleaseKnobs::fromEnvironment()) {
     if (nInstances < 1) throw std::runtime_error("n_instances must be >= 1");
     if (channels < 1 || channels > kMaxChannels) throw std::runtime_error("num_channels must be 1..4");
     int count = 0;
@@ -74,6 +75,9 @@ Batch::~Batch() {
     (void)hipFree(dTracks_);
     (void)hipFree(dIn_);
     (void)hipFree(dOut_);
+#ifdef FX_DIAGNOSTICS
+    (void)hipFree(dStamps_);
+#endif
     if (hPinIn_) (void)hipHostFree(hPinIn_);
     if (hPinOut_) (void)hipHostFree(hPinOut_);
     for (int k = 0; k < kHostPieces; ++k) {
@@ -236,10 +240,7 @@ int Batch::ensureTram(const Lowered& low) {
 // Once TRAM has been allocated its [wave][slot][64][K] tiling pins K for the life of the batch.
 int Batch::chooseInstPerLane() const {
     if (iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0) return instPerLane_;
-    if (const char* env = std::getenv("FX_INST_PER_LANE")) {
-        const int k = std::atoi(env);
-        if (k == 1 || k == 2 || k == 4) return k;
-    }
+    if (knobs_.instPerLane) return knobs_.instPerLane;
     const Lowered probe = lowerProgram(prog_, hostValue_, laneForced(), 1);
     if (!probe.error.empty()) return 1;
     for (int k : {4, 2}) {
@@ -262,7 +263,7 @@ bool Batch::laneResident(int reg) const {
 // per SIMD the plain program has always been the faster one.  FX_STAGES pins the number asked for (1 = never).
 bool Batch::stagingPossible() const {
     if (stagingOff_) return false;
-    if (const char* knob = std::getenv("FX_STAGES")) return std::atoi(knob) >= 2;
+    if (knobs_.stages) return knobs_.stages >= 2;
     return (n_ + 63) / 64 < 2048;
 }
 
@@ -281,9 +282,9 @@ std::vector<Batch::StageOption> Batch::rankStages(const std::vector<MicroOp>& st
                                                   const XlateProgram& xprog, int nRows, int blockClass, int wavesPerSimdCap) const {
     std::vector<StageOption> out;
     if (stagingOff_) { out.push_back(StageOption()); return out; }
-    if (const char* knob = std::getenv("FX_STAGES")) {
+    if (knobs_.stages) {
         StageOption o;
-        o.wanted = std::max(1, std::min(16, std::atoi(knob)));
+        o.wanted = knobs_.stages;
         out.push_back(o);
         return out;
     }
@@ -311,7 +312,7 @@ std::vector<Batch::StageOption> Batch::rankStages(const std::vector<MicroOp>& st
         if (std::find(seen.begin(), seen.end(), k) != seen.end()) continue;
         seen.push_back(k);
         StageLds lds;
-        if (!stageLdsLayout(xprog, plan, ldsBudget, maxGroup, &lds)) continue;
+        if (!stageLdsLayout(xprog, plan, ldsBudget, maxGroup, &lds, knobs_.stagesGroup)) continue;
         int worst = 0, luts = 0, sum = 0;
         for (size_t s = 0; s < plan.stageCost.size(); ++s) {
             worst = std::max(worst, plan.stageCost[s]);
@@ -354,11 +355,7 @@ std::string Batch::codeKeyFor(const std::vector<uint8_t>& forced, int blockClass
     auto word = [&](int64_t v) { k.append(reinterpret_cast<const char*>(&v), 8); };
     word(loadGen_); word((int64_t)prog_.options); word(blockClass); word(pick); word(defer ? 1 : 0);
     word(((iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0) && instPerLane_ != 1) ? instPerLane_ : 0);   // delay lines tiled for K instances per lane pin the HIP C++ kernel
-    for (const char* name : {"FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_STAGES_GROUP", "FX_XLATE_PRIO"}) {
-        const char* v = std::getenv(name);
-        k.append(v ? v : "");
-        k.push_back('\0');
-    }
+    // (the release knobs are fixed for the life of the handle - fx_knobs.hpp ReleaseKnobs - and so not part of the key)
     for (size_t r = 0; r < hostValue_.size(); ++r) {
         const bool f = r < forced.size() && forced[r];
         const uint32_t w = f ? 0x7fc0f0f0u : bitsOf(hostValue_[r]);
@@ -435,9 +432,8 @@ bool Batch::deferWanted() const {
     // controls that are compiled into the code keep changing (a set_register within the last few blocks): a translation costs
     // a module load (~1-2 ms), a re-encode for the interpreter ~0.05 ms - interpret until they have been quiet.  (A block of
     // more than ~half a millisecond of translated code pays for its translation at once.)
-    const char* forceHip = std::getenv("FX_KERNEL");
     const double blockMs = (double)n_ * (double)pendingSamples_ * (double)std::max<size_t>(prog_.instrs.size(), 1) / 1e10;
-    return controlHeat_ > 0 && blockMs < 0.5 && !(prog_.options & kOptTramDane) && !(forceHip && std::strncmp(forceHip, "xlate", 5) == 0);
+    return controlHeat_ > 0 && blockMs < 0.5 && !(prog_.options & kOptTramDane) && !knobs_.kernelStartsWith("xlate");
 }
 
 int Batch::ensureLowered() {
@@ -488,8 +484,8 @@ void Batch::adoptStageOptions() {
     t.pick = c_.stagePick;
     // (built for "the cheapest": from now on the code goes by the stage count it was built for)
     c_.key = codeKeyFor(laneForced(), cls, c_.deferred, t.pick);
-    const bool tuneOff = std::getenv("FX_STAGES_TUNE") && std::atoi(std::getenv("FX_STAGES_TUNE")) == 0;
-    if (c_.stageOptions.empty() || std::getenv("FX_STAGES")) { t.done = true; return; }
+    const bool tuneOff = !knobs_.stagesTune;
+    if (c_.stageOptions.empty() || knobs_.stages) { t.done = true; return; }
     const double best = c_.stageOptions.front().predicted;
     for (const StageOption& o : c_.stageOptions)
         if (t.options.size() < 3 && (t.options.empty() || o.predicted <= best * kTuneBand)) t.options.push_back(o);
@@ -584,8 +580,7 @@ struct Batch::Builder {
 };
 
 bool Batch::builderWanted() const {
-    const char* knob = std::getenv("FX_BUILDER");
-    return !(knob && std::atoi(knob) == 0);
+    return knobs_.builder;
 }
 
 void Batch::requestBuild(BuildInputs&& in) {
@@ -751,8 +746,8 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
     Lowered fresh;
     bool asmOk = false;
     const bool tramPinned = iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0;
-    const char* forceHip = std::getenv("FX_KERNEL");
-    const bool wantAsm = !(forceHip && std::strcmp(forceHip, "hip") == 0) && !std::getenv("FX_INST_PER_LANE");
+    const char* forceHip = knobs_.kernel.empty() ? nullptr : knobs_.kernel.c_str();
+    const bool wantAsm = !knobs_.kernelIs("hip") && !knobs_.instPerLaneSet;
     if (wantAsm && (!tramPinned || instPerLane_ == 1)) {
         // first choice: register file in VGPRs (row pitch 1 = plain indices), else in LDS
         const bool tryVgpr = !(forceHip && std::strcmp(forceHip, "asm_lds") == 0);
@@ -848,8 +843,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
             // wavefronts of a SIMD by turns at the top priority (fx_xlate.hpp prioritySlices): wherever a SIMD holds two or more
             // (the build chosen above has at most four slots then; FX_XLATE_PRIO=0 / 1 in the environment: never / whenever unstaged)
             const size_t waves = ((size_t)n_ + 63) / 64, simds = 1024;
-            const char* knob = std::getenv("FX_XLATE_PRIO");
-            xprog.prioritySlices = knob ? std::atoi(knob) != 0 : (waves >= 2 * simds && kAsmWavesPerSimd[c.variant] <= 4);
+            xprog.prioritySlices = knobs_.xlatePrio >= 0 ? knobs_.xlatePrio != 0 : (waves >= 2 * simds && kAsmWavesPerSimd[c.variant] <= 4);
             c.prioritySlices = xprog.prioritySlices;
         }
         XlateImage image;
@@ -882,7 +876,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
                 // (several workgroups per CU must fit its 160 KiB of LDS together)
                 const int64_t groupsPerCu = std::max<int64_t>(1, ((n_ + 63) / 64 + 255) / 256);
                 const uint32_t ldsBudget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(144 * 1024, 160 * 1024 / groupsPerCu - 256));
-                built = buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, plan, &image, nullptr, nullptr, &why, ldsBudget, maxGroup);
+                built = buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, plan, &image, nullptr, nullptr, &why, ldsBudget, maxGroup, knobs_.stagesGroup);
                 if (!built) { c.stagesWhyNot = why; image = XlateImage(); }
             }
         }
@@ -1366,8 +1360,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                 // wherever a SIMD holds two or more (a build of at most four slots); a turn = 1/24 of the block at about 20 us
                 // per sample and four wavefronts, between 0.66 and 10 ms
                 const size_t waves = ((size_t)n_ + 63) / 64;
-                const char* knob = std::getenv("FX_XLATE_PRIO");
-                if (knob ? std::atoi(knob) != 0 : (waves >= 2048 && kAsmWavesPerSimd[c_.variant] <= 4)) {
+                if (knobs_.xlatePrio >= 0 ? knobs_.xlatePrio != 0 : (waves >= 2048 && kAsmWavesPerSimd[c_.variant] <= 4)) {
                     int shift = 6;
                     while ((1 << (shift - 6 + 1)) <= a.nSamples) ++shift;   // floor(log2(samples of the launch)) + 6
                     g.tramDane |= 4 | (std::min(std::max(shift, 16), 20) << 8);
@@ -1383,6 +1376,22 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
                     g.stages = c_.dStream + nOps * 16 + c_.low.loadRows.size() + c_.low.storeRows.size() + c_.low.zeroRows.size();
                     g.nStages = c_.stages;
                 }
+#ifdef FX_DIAGNOSTICS
+                if (c_.stages <= 1 && FX_DIAG_KNOB("FX_XLATE_ENDSTAMP")) {
+                    // the end stamps' own buffer rides in the kernarg slot of the stage descriptors, which an unstaged launch leaves
+                    // unused (nStages stays 0: the template never looks at the pointer)
+                    const size_t words = ((size_t)n_ + 63) / 64;
+                    if (words > stampWords_) {
+                        waitLastLaunch();
+                        (void)hipFree(dStamps_);
+                        dStamps_ = nullptr;
+                        stampWords_ = 0;
+                        if (hipMalloc(reinterpret_cast<void**>(&dStamps_), words * 4) != hipSuccess) return fail(FX_E_MEMORY, "end stamps");
+                        stampWords_ = words;
+                    }
+                    g.stages = dStamps_;
+                }
+#endif
                 e = launchAsmFunction(c_.fn, g, (unsigned)((n_ + 63) / 64), c_.ldsBytes, s, (unsigned)c_.stages);
             } else {
                 e = launchAsmInterp(g, c_.variant, c_.variant == ASM_LDS ? (size_t)a.nRows * 256 : 0, device_, s);
@@ -1391,11 +1400,16 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
             e = launchStepBlock(a, c_.low.multipass, s);
         }
     }
+    const hipError_t launchError = e;   // (of the event record in front of the launch or of the launch itself)
     if (e == hipSuccess && !untimed_) e = hipEventRecord(ev1_, s);
-    if (e != hipSuccess && c_.useXlate && c_.stages > 1 && !stagingOff_) {
-        // a workgroup of several wavefronts that the device will not start (registers x wavefronts beyond a CU, LDS): the plain
-        // program runs everywhere - no stages for this handle from now on, and this block again
-        (void)hipGetLastError();
+    // A workgroup of several wavefronts that the device will not start (registers x wavefronts beyond a CU, LDS): the plain
+    // program runs everywhere - no stages for this handle from now on, and this block again.  Only for what a launch
+    // CONFIGURATION can cause: any other error (a fault of an earlier kernel that this call merely inherits, a lost device) is
+    // reported as it is and leaves the handle's choice of code alone.  Nothing has been consumed at this point that the second
+    // attempt needs: a staged program has no control tracks (planStages refuses them), so uploadTracks has not run.
+    const bool configError = launchError == hipErrorInvalidValue || launchError == hipErrorInvalidConfiguration || launchError == hipErrorLaunchOutOfResources;
+    if (configError && c_.useXlate && c_.stages > 1 && !stagingOff_ && trackRegs_.empty()) {
+        (void)hipGetLastError();   // (the launch's own error, just read: not a sticky one)
         stagingOff_ = true;
         lowDirty_ = true;
         return processDevice(dIn, dOut, nSamples, stream);
@@ -1467,7 +1481,7 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
     // Large blocks: copy-in, kernel and copy-out of consecutive pieces overlap.  268 MB each way (tools/host_block_rate.py):
     // pinned caller buffers 6.5 ms instead of 12.7 (both DMA directions at once), pageable ones 9.7 instead of 12.9 (the driver
     // pins them on the fly; a freshly allocated, untouched output buffer costs 2-3 x that in page faults either way).
-    static const bool pipelineOff = std::getenv("FX_HOST_PIPELINE") && std::atoi(std::getenv("FX_HOST_PIPELINE")) == 0;  // diagnostics
+    const bool pipelineOff = !knobs_.hostPipeline;
     if (count * 4 >= kPipelinedBytes && nSamples >= 2 * kHostPieces && !tracksArmed() && !pipelineOff)
         return processHostPipelined(in, out, nSamples, pitch);
     const size_t rows = (size_t)nSamples * prog_.numChannels, width = (size_t)n_ * 4;
@@ -1649,7 +1663,9 @@ int Batch::loadStateColumns(const uint8_t* image, const SnapshotHeader& hdr, int
     int rc = snapshotShape(&mine);
     if (rc != 0) return rc;
     if (hdr.magic != mine.magic || hdr.version != mine.version) return fail(FX_E_ARG, "snapshot: not a state image of this library version");
-    if (mine.channels != hdr.channels || mine.nRegs != hdr.nRegs || mine.stateRows != hdr.stateRows || hdr.iSlots > mine.iSlots || hdr.xSlots > mine.xSlots)
+    // (every field is checked before any of them enters an address: the image may be a damaged file)
+    if (hdr.iSlots < 0 || hdr.xSlots < 0 || hdr.n < n_ || mine.channels != hdr.channels || mine.nRegs != hdr.nRegs || mine.stateRows != hdr.stateRows ||
+        hdr.iSlots > mine.iSlots || hdr.xSlots > mine.xSlots)
         return fail(FX_E_ARG, "snapshot: the image is of another program (registers, channels or delay lines differ)");
     waitLastLaunch();
     hipError_t e = hipStreamSynchronize(stream_);
@@ -1782,9 +1798,26 @@ float Batch::lastKernelMs() {
     return ms;
 }
 
+#ifdef FX_DIAGNOSTICS
+int Batch::readEndStamps(uint32_t* out, int64_t nWords) {
+    (void)hipSetDevice(device_);
+    if (!out || nWords < 0) return fail(FX_E_ARG, "end stamps: bad argument");
+    if (!dStamps_) return fail(FX_E_NOTREADY, "end stamps: no unstaged translated launch with FX_XLATE_ENDSTAMP set has run");
+    waitLastLaunch();
+    const size_t take = std::min((size_t)nWords, stampWords_);
+    const hipError_t e = hipMemcpy(out, dStamps_, take * 4, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? (int)std::min<size_t>(take, 0x7fffffff) : hipFail(e, "end stamps");
+}
+#endif
+
 // "translated to gfx950 code (fx_xlate_v128, 8 stages)" / "interpreter (fx_interp_v96): <why the translation failed>" / "HIP C++
 // kernel: <why not an assembly tier>" - of the code in force (before the first block: nothing has been lowered yet)
 std::string Batch::tierNote() const {
+    // (never in the release library: fx_knobs.hpp)
+    return kDiagnosticsBuild ? "DIAGNOSTICS BUILD (environment knobs may change or corrupt results): " + tierNotePlain() : tierNotePlain();
+}
+
+std::string Batch::tierNotePlain() const {
     static const char* const regs[ASM_VARIANTS] = {"lds", "v64", "v72", "v80", "v96", "v128", "v168", "v256"};
     if (!loaded_) return "no program loaded";
     if (c_.key.empty() && !c_.useAsm && c_.low.steady.empty()) return "not lowered yet (the first block, fxb_prepare or an fxb_info query does it)";

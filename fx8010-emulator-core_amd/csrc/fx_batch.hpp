@@ -13,6 +13,7 @@
 #include "fx_xlate.hpp"
 #include "fx_decode.hpp"
 #include "fx_kernel.hpp"
+#include "fx_knobs.hpp"
 #include "fx_model.hpp"
 
 namespace fx {
@@ -57,8 +58,15 @@ public:
     };
     static_assert(sizeof(SnapshotHeader) == 64, "SnapshotHeader layout");
     int snapshotShape(SnapshotHeader* hdr);   // what this batch would save (lowers the program first); n = this batch's instances
+    // bytes of an image with this header; -1 for a header no batch could have written (a damaged file: negative or absurd
+    // counts - nothing of it may enter an address computation)
     static int64_t snapshotBytes(const SnapshotHeader& hdr) {
-        return (int64_t)sizeof(SnapshotHeader) + (int64_t)hdr.n * 4 * ((int64_t)hdr.stateRows + hdr.iSlots + hdr.xSlots);
+        constexpr int64_t kMaxRows = 1 << 20, kMaxSlots = 1 << 20, kMaxInstances = (int64_t)1 << 40;
+        if (hdr.n < 1 || hdr.n > kMaxInstances || hdr.stateRows < 1 || hdr.stateRows > kMaxRows || hdr.nRegs < 0 || hdr.nRegs > hdr.stateRows ||
+            hdr.channels < 1 || hdr.channels > 4 || hdr.iSlots < 0 || hdr.iSlots > kMaxSlots || hdr.xSlots < 0 || hdr.xSlots > kMaxSlots)
+            return -1;
+        const uint64_t words = (uint64_t)hdr.stateRows + (uint64_t)hdr.iSlots + (uint64_t)hdr.xSlots;   // <= 2^20 + 2^21
+        return (int64_t)(sizeof(SnapshotHeader) + (uint64_t)hdr.n * 4u * words);                            // < 2^40 * 2^24: no overflow
     }
     int saveStateColumns(uint8_t* image, const SnapshotHeader& hdr, int64_t first);
     int loadStateColumns(const uint8_t* image, const SnapshotHeader& hdr, int64_t first);
@@ -86,6 +94,7 @@ public:
     int setOption(unsigned option, bool on);
 
 private:
+    std::string tierNotePlain() const;
     int fail(int code, const std::string& what);
     int hipFail(hipError_t e, const char* where);
     int afterLoad(bool ok);
@@ -104,6 +113,7 @@ private:
     void waitLastLaunch();        // host waits for the most recent kernel (an event of ours, not the caller's stream handle)
 
     Program prog_;
+    const ReleaseKnobs knobs_;          // the environment's release knobs as they were when the handle was created (fx_knobs.hpp)
     std::vector<float> hostValue_;      // current value of every register as the host knows it
     std::vector<uint8_t> forcedLane_;   // registers that live in a row of the register file although no instruction writes them:
                                         // per-instance values (setRegisterAt / setRegisterArray / a per-instance schedule) or a moving control
@@ -265,6 +275,15 @@ private:
     hipEvent_t evIn_[kHostPieces] = {}, evDone_[kHostPieces] = {};
     int processHostPipelined(const float* in, float* out, int nSamples, int64_t pitch);
     unsigned lastGrid_ = 0;
+#ifdef FX_DIAGNOSTICS
+  public:
+    // diagnostics build (fx_knobs.hpp): one word per wavefront, written by generated code behind its last sample when
+    // FX_XLATE_ENDSTAMP is set (fx_xlate.cpp) - the low word of the 100 MHz clock at which the wavefront finished
+    int readEndStamps(uint32_t* out, int64_t nWords);
+  private:
+    uint32_t* dStamps_ = nullptr;
+    size_t stampWords_ = 0;
+#endif
 
     std::string lastError_;
 };

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "fx_batch.hpp"
+#include "fx_knobs.hpp"
 #include "fx_shard.hpp"
 #include "fx_xlate.hpp"
 
@@ -132,6 +133,16 @@ int fx_set_option(fx_handle* h, unsigned option, int on) { return h ? h->batch.s
 int fx_get_channels(fx_handle* h) { return h ? h->batch.loaderChannels() : 0; }
 int fx_ready(fx_handle* h) { return (h && h->batch.program().ready) ? 1 : 0; }
 const char* fx_last_error(fx_handle* h) { return h ? h->batch.lastError().c_str() : "null handle"; }
+
+#ifdef FX_DIAGNOSTICS
+/* ---- diagnostics build only (fx_diag.h) ---- */
+extern "C" int fxb_diag_build(void) { return 1; }
+extern "C" int fxb_diag_read_end_stamps(void* handle, uint32_t* out, int64_t n_words) {
+    fxb_handle* h = static_cast<fxb_handle*>(handle);
+    if (!h || h->batch.shards() != 1) return FX_E_ARG;
+    return guard(&h->batch.front(), FX_E_PROGRAM, [&] { return h->batch.front().readEndStamps(out, n_words); });
+}
+#endif
 
 /* ---- batch ---- */
 fxb_handle* fxb_create(int64_t n, int ch, int device) { return create<fxb_handle>(n, ch, std::vector<int>{device}); }
@@ -349,7 +360,7 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     std::vector<int> trackRows;
     for (int r : h->tracked) trackRows.push_back(low.rowOfReg[(size_t)r]);
     fx::XlateProgram xprog = fx::xlateProgramOf(steadyRecords, lastRecords, h->prog.iTramSize, h->prog.xTramSize, low.nRows, low.inRow, low.latchRow, trackRows);
-    if (const char* knob = std::getenv("FX_XLATE_PRIO")) xprog.prioritySlices = std::atoi(knob) != 0;   // (what a batch with that knob generates: tests)
+    if (const int prio = fx::ReleaseKnobs::fromEnvironment().xlatePrio; prio >= 0) xprog.prioritySlices = prio != 0;   // (what a batch with that knob generates: tests)
     std::vector<std::vector<uint32_t>> stagedCode;
     std::vector<std::string> stagedText;
     if (stagesOut) *stagesOut = 1;
@@ -357,7 +368,8 @@ static int64_t translateImpl(fxp_handle* h, int vgprs, int stream, void* code, i
     if (stages >= 2) {
         const fx::StagePlan sp = fx::planStages(steadyRecords, lastRecords, xprog, low.nRows, stages);
         if (!sp.cuts.empty()) {
-            if (!fx::buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, sp, &plan, &stagedCode, &stagedText, &h->err)) return FX_E_PROGRAM;
+            if (!fx::buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, sp, &plan, &stagedCode, &stagedText, &h->err, 144u * 1024u, fx::kStageGroupMax,
+                                      fx::ReleaseKnobs::fromEnvironment().stagesGroup)) return FX_E_PROGRAM;
             staged = true;
             if (stagesOut) *stagesOut = plan.stages;
             // info: per cut its record index and the number of rows handed over, then the LDS bytes of a workgroup
@@ -426,7 +438,8 @@ int64_t fxp_code_hash(fxp_handle* h, int vgprs, int stages, unsigned flags) {
         bool built = false;
         if (stages >= 2) {
             const fx::StagePlan sp = fx::planStages(steadyRecords, lastRecords, xprog, low.nRows, stages);
-            if (!sp.cuts.empty()) built = fx::buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, sp, &image, nullptr, nullptr, &h->err);
+            if (!sp.cuts.empty()) built = fx::buildStagedImage(steadyRecords, lastRecords, *tmpl, xprog, sp, &image, nullptr, nullptr, &h->err, 144u * 1024u, fx::kStageGroupMax,
+                                                              fx::ReleaseKnobs::fromEnvironment().stagesGroup);
             if (!built) image = fx::XlateImage();
         }
         if (!built && !fx::buildXlateImage(steadyRecords, lastRecords, *tmpl, xprog, &image, &h->err)) return FX_E_PROGRAM;

@@ -285,8 +285,12 @@ int Sharded::loadState(const void* buf, int64_t bytes) {
     Batch::SnapshotHeader hdr;
     if (!buf || bytes < (int64_t)sizeof(hdr)) { lastError_ = "load_state: no image"; return FX_E_ARG; }
     std::memcpy(&hdr, buf, sizeof(hdr));
-    if (hdr.magic != Batch::SnapshotHeader().magic || hdr.n != n_ || bytes < Batch::snapshotBytes(hdr)) {
-        lastError_ = "load_state: not a state image of a batch of this many instances (or truncated)";
+    // the header is the caller's (a file that may be damaged): version, every count and the size they imply are checked here,
+    // before a shard computes a single address from them
+    const Batch::SnapshotHeader ours;
+    const int64_t need = Batch::snapshotBytes(hdr);
+    if (hdr.magic != ours.magic || hdr.version != ours.version || hdr.n != n_ || need < 0 || bytes < need) {
+        lastError_ = "load_state: not a state image of a batch of this many instances (wrong version, damaged header or truncated)";
         return FX_E_ARG;
     }
     return fan([&](int k, Batch& b) { return b.loadStateColumns(static_cast<const uint8_t*>(buf), hdr, shards_[(size_t)k]->first); });

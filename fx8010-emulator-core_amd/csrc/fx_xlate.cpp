@@ -1,6 +1,8 @@
 // fx_xlate.cpp — FX8010 program -> gfx950 machine code (see fx_xlate.hpp).
 #include "fx_xlate.hpp"
 
+#include "fx_knobs.hpp"
+
 #include <elf.h>
 
 #include <algorithm>
@@ -748,13 +750,13 @@ class Translator {
             // diagnostics: FX_XLATE_LOOPPAD=n / FX_XLATE_LOOPPAD_SLOW=n put n independent instructions (plain / 4-clock class, on a
             // spare register) into every sample of every stream - does a stage's loop pay for issue slots or for the latency of
             // its dependent chain?  (tools/stage_pad_probe.sh)
-            static const int pad = std::getenv("FX_XLATE_LOOPPAD") ? std::atoi(std::getenv("FX_XLATE_LOOPPAD")) : 0;
-            static const int padSlow = std::getenv("FX_XLATE_LOOPPAD_SLOW") ? std::atoi(std::getenv("FX_XLATE_LOOPPAD_SLOW")) : 0;
+            static const int pad = knobInt(FX_DIAG_KNOB("FX_XLATE_LOOPPAD"), 0);
+            static const int padSlow = knobInt(FX_DIAG_KNOB("FX_XLATE_LOOPPAD_SLOW"), 0);
             for (int k = 0; k < pad; ++k) e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 31, vreg(31), 31);
             for (int k = 0; k < padSlow; ++k) e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(31), vreg(31));
             // ... FX_XLATE_LOOPPAD_SALU=n: n scalar instructions (does a wavefront's scalar work - delay-line addresses, loop
             // control - cost the SIMD issue time, or do the other wavefronts' vector instructions go out beside it?)
-            static const int padScalar = std::getenv("FX_XLATE_LOOPPAD_SALU") ? std::atoi(std::getenv("FX_XLATE_LOOPPAD_SALU")) : 0;
+            static const int padScalar = knobInt(FX_DIAG_KNOB("FX_XLATE_LOOPPAD_SALU"), 0);
             for (int k = 0; k < padScalar; ++k) e_.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSTemp), sreg(kSTemp), imm32(1));
         }
         if (!staged || usesSkipCounter) e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
@@ -794,19 +796,27 @@ class Translator {
             }
         }
         if (storesPerSample > 0) pcmAccess(false, kSPcmOut, false);
+#ifdef FX_DIAGNOSTICS
         {
-            // diagnostics (FX_XLATE_ENDSTAMP=1, wrong output): when does each wavefront finish?  The last sample's PCM output of the
-            // wavefront's first instance is replaced by the low word of the 100 MHz clock (tools/wave_end_probe.py)
-            static const bool stamp = std::getenv("FX_XLATE_ENDSTAMP") != nullptr;
-            if (stamp && isLast_ && !staged && storesPerSample > 0) {
-                e_.memRealTime(kSTemp);
+            // diagnostics build only (FX_XLATE_ENDSTAMP=1): when does each wavefront finish?  Behind the last sample's PCM store the
+            // low word of the 100 MHz clock goes to word [wavefront] of a buffer of ITS OWN - the batch hands it over in the kernarg
+            // slot of the stage descriptors, which an unstaged launch does not use (fx_batch.cpp; read back with
+            // fxb_diag_read_stamps, tools/wave_end_probe.py) - never into an output element (MI355X_MICROARCH.md on stamps)
+            static const bool stamp = FX_DIAG_KNOB("FX_XLATE_ENDSTAMP") != nullptr;
+            if (stamp && isLast_ && !staged) {
+                constexpr int kKernargStages = 0xc0;   // AsmArgs.stages (fx_asm.hpp)
+                smemLoad(2, kSTemp, 0, kKernargStages);
+                e_.memRealTime(kSTemp + 2);
                 e_.waitLgkm0();
-                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), sreg(kSTemp));
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(2), sreg(kSTemp + 2));
+                e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(3), sreg(2));                       // s2 = wavefront of the launch
+                e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(2), 3);
                 e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), imm32(1));
-                e_.global(GLOBAL_STORE_DWORD, false, 2, kVInstance4, kSPcmOut);
+                e_.global(GLOBAL_STORE_DWORD, false, 2, 3, kSTemp);
                 e_.sop1(SOP1_MOV_B64, "s_mov_b64", named(126, "exec"), named(193, "-1"));
             }
         }
+#endif
         for (int q : {kSPcmIn, kSPcmOut}) {
             bool anyInput = false;
             for (int c = 0; c < channels; ++c) anyInput = anyInput || prog_.inRows[(size_t)c] >= 0;
@@ -974,7 +984,7 @@ class Translator {
     bool fail(const std::string& m) { err_ = m; return false; }
     // non-temporal hint per access class (1 TRAM load, 2 TRAM store, 4 PCM load, 8 PCM store); FX_XLATE_NT overrides (diagnostics)
     bool streaming(int cls) const {
-        static const int mask = std::getenv("FX_XLATE_NT") ? std::atoi(std::getenv("FX_XLATE_NT")) : -1;
+        static const int mask = knobInt(FX_DIAG_KNOB("FX_XLATE_NT"), -1);
         if (mask >= 0) return (mask & cls) != 0;
         return prog_.tramStreaming && (cls & 3) != 0;
     }
@@ -1385,9 +1395,9 @@ class Translator {
         // must lie in [0, W), W a constant of the grid (fx_frontend.cpp lutGuessWindowHi) - one unsigned compare of d's high
         // word, three LDS reads instead of four.  A miss (one lane in ~10^5 within reach of a threshold) reads the thresholds
         // after all and corrects the index as the guarded form does.
-        static const int prio = std::getenv("FX_XLATE_LUTPRIO") ? std::atoi(std::getenv("FX_XLATE_LUTPRIO")) : 0;   // diagnostics
+        static const int prio = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTPRIO"), 0);   // diagnostics
         // diagnostics, WRONG RESULTS (timing only): 1 = no branch to the miss path, 2 = no LDS reads and no wait, 4 = reads but no wait
-        static const int probe = std::getenv("FX_XLATE_LUTPROBE_WRONG_RESULTS") ? std::atoi(std::getenv("FX_XLATE_LUTPROBE_WRONG_RESULTS")) : 0;
+        static const int probe = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTPROBE_WRONG_RESULTS"), 0);
         if (prio > 0 && lds) e_.sopp(0x0fu, "s_setprio", (uint32_t)prio & 3u, true);
         if (!(lds && (probe & 2))) lutFetch(site, window == 0, quick);
         e_.vop1(VOP1_CVT_F64_F32, "v_cvt_f64_f32_e32", vreg64(12), vreg(vA));
@@ -1395,9 +1405,9 @@ class Translator {
             // diagnostics: how much independent work fits into the LDS round trip for nothing?  FX_XLATE_LUTPAD=n pads every
             // LOG / EXP with n plain (double-rate class) instructions on a spare register, FX_XLATE_LUTPAD_SLOW=n with n
             // conversions (the 4-clock class) between the reads and their wait (tools/lut_pad_probe.sh)
-            static const int pad = std::getenv("FX_XLATE_LUTPAD") ? std::atoi(std::getenv("FX_XLATE_LUTPAD")) : 0;
-            static const int padSlow = std::getenv("FX_XLATE_LUTPAD_SLOW") ? std::atoi(std::getenv("FX_XLATE_LUTPAD_SLOW")) : 0;
-            static const int padAfter = std::getenv("FX_XLATE_LUTPAD_AFTER") ? std::atoi(std::getenv("FX_XLATE_LUTPAD_AFTER")) : 0;
+            static const int pad = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTPAD"), 0);
+            static const int padSlow = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTPAD_SLOW"), 0);
+            static const int padAfter = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTPAD_AFTER"), 0);
             if (lds && !padAfter) {
                 for (int k = 0; k < pad; ++k) e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 31, vreg(31), 31);
                 for (int k = 0; k < padSlow; ++k) e_.vop1(VOP1_CVT_F32_U32, "v_cvt_f32_u32_e32", vreg(31), vreg(31));
@@ -2685,7 +2695,7 @@ void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string
         // slow - shorter slices than that it misses; measured on blocks of 64 ... 512 samples) and 2^20 ticks
         e.sop1(SOP1_FLBIT_I32_B32, "s_flbit_i32_b32", sreg(kSSliceShift), sreg(kSNumSamples));
         e.sop2(SOP2_SUB_I32, "s_sub_i32", sreg(kSSliceShift), imm32((uint32_t)(31 + sliceBias)), sreg(kSSliceShift));
-        static const int minShift = std::getenv("FX_XLATE_PRIO_MINSHIFT") ? std::atoi(std::getenv("FX_XLATE_PRIO_MINSHIFT")) : 16;   // (diagnostics)
+        static const int minShift = knobInt(FX_DIAG_KNOB("FX_XLATE_PRIO_MINSHIFT"), 16);   // (diagnostics)
         e.sop2(SOP2_MAX_I32, "s_max_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32((uint32_t)minShift));
         e.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32(20));
     }
@@ -2768,7 +2778,7 @@ int32_t danePosition(uint32_t bits, bool shifted, int32_t size) {
 HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, const XlateProgram& p) {
     HoistPlan H;
     if (!p.uniformCursors) return H;
-    if (const char* knob = std::getenv("FX_XLATE_HOIST"))  // diagnostics: 0 = delay-line reads stay in place
+    if (const char* knob = FX_DIAG_KNOB("FX_XLATE_HOIST"))  // diagnostics: 0 = delay-line reads stay in place
         if (std::atoi(knob) == 0) return H;
     auto isRead = [](uint32_t slot) { return slot == AS_TRAM_IR || slot == AS_TRAM_XR; };
     auto isWrite = [](uint32_t slot) { return slot == AS_TRAM_IW || slot == AS_TRAM_XW; };
@@ -2990,7 +3000,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     XlateProgram pooledProgram = program;
     pooledProgram.vconst.clear();
     {
-        const char* knob = std::getenv("FX_XLATE_VCONST");  // diagnostics: 0 = none
+        const char* knob = FX_DIAG_KNOB("FX_XLATE_VCONST");  // diagnostics: 0 = none
         const int firstFree = kRegFileBase + (int)program.wildRow.size();
         if (!program.lutTables.empty() && tmpl.vgprs - firstFree >= 4 && !(knob && std::atoi(knob) == 0)) {
             int v = tmpl.vgprs;
@@ -3015,7 +3025,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     }
     // ... and the product cache of the fast streams (Translator::product): per entry an even-aligned pair and a single
     {
-        const char* knob = std::getenv("FX_XLATE_CSE");  // diagnostics: number of entries (0 = none)
+        const char* knob = FX_DIAG_KNOB("FX_XLATE_CSE");  // diagnostics: number of entries (0 = none)
         const int top = stageTop;
         const int base = (kRegFileBase + (int)program.wildRow.size() + 1) & ~1;
         int entries = std::min(kProductCacheEntries, knob ? std::atoi(knob) : kProductCacheEntries);
@@ -3263,7 +3273,7 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
     // stage with less than a quarter of an even share of the program is not worth a barrier: fewer stages then).
     bool anyInputRow = false;
     for (int r : prog.inRows) anyInputRow = anyInputRow || r >= 0;
-    static const bool flat = std::getenv("FX_STAGES_BALANCE") && std::atoi(std::getenv("FX_STAGES_BALANCE")) == 0;   // diagnostics: the program's share only
+    static const bool flat = knobInt(FX_DIAG_KNOB("FX_STAGES_BALANCE"), 1) == 0;   // diagnostics: the program's share only
     const int kInputCost = anyInputRow && !flat ? 14 : 0, kOutputCost = flat ? 0 : 7, kRecvCost = flat ? 0 : 3, kSendCost = flat ? 0 : 1, kFixedCost = 8;
     std::vector<size_t> bounds{0};
     for (size_t b = 1; b < n; ++b)
@@ -3301,7 +3311,7 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
     }
     P.totalCost = total;
     for (size_t i = 0; i < n; ++i) P.totalLuts += steadyRecords[i].w[0] == AS_LUT ? 1 : 0;
-    if (std::getenv("FX_STAGES_DEBUG")) {
+    if (FX_DIAG_KNOB("FX_STAGES_DEBUG")) {
         std::string line;
         for (size_t b = 0; b <= n; ++b) line += allowed[b] ? '+' : '.';
         std::fprintf(stderr, "planStages: %zu records, total cost %d, boundaries %s\n", n, total, line.c_str());
@@ -3325,7 +3335,7 @@ StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vecto
         }
         (void)lo;
     }
-    if (std::getenv("FX_STAGES_DEBUG")) {
+    if (FX_DIAG_KNOB("FX_STAGES_DEBUG")) {
         std::string line;
         for (size_t k = 0; k < P.stageCost.size(); ++k) line += " " + std::to_string(P.stageCost[k]) + "(" + std::to_string(P.stageLuts[k]) + ")";
         std::fprintf(stderr, "planStages: wanted %d -> %zu stages, cost per stage (LOG/EXP):%s\n", wanted, P.stageCost.size(), line.c_str());
@@ -3450,7 +3460,7 @@ std::vector<MicroOp> stageRecords(const std::vector<MicroOp>& all, size_t from, 
 // LDS of a staged program: the LOG/EXP tables (shared by all stages: every wavefront stages the same bytes), one flag row per
 // stage ("my packets may hold non-finite values", Translator::stageFlagCheck), the ring of 4 * group packet buffers (the
 // generated code steps through them with an add and an AND: the stride is a power of two), the epilogue's scratch
-bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* L) {
+bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* L, int pinGroup) {
     const int K = (int)plan.cuts.size() + 1;
     const uint32_t tableBytes = program.lutTables.empty() ? 0u : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
     L->cutOff.clear();
@@ -3462,13 +3472,10 @@ bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t
     L->scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0)
     int group = kStageGroupMax;
     while (group > 1 && group > maxGroup) group /= 2;
-    if (const char* knob = std::getenv("FX_STAGES_GROUP")) {   // tests: a shorter ring than the LDS would allow (1, 2, 4)
-        const int g = std::atoi(knob);
-        if (g == 1 || g == 2 || g == 4) group = g;
-    }
+    if (pinGroup == 1 || pinGroup == 2 || pinGroup == 4) group = pinGroup;   // tests: a shorter ring than the LDS would allow
     // without tables the ring lies at address 0 (the pointer's and-mask needs no base: StageInfo::ptrBias), flag rows and scratch
     // behind it; with tables: [tables][flags][ring][scratch]
-    static const bool pairOff = std::getenv("FX_XLATE_LDS2") && std::atoi(std::getenv("FX_XLATE_LDS2")) == 0;   // diagnostics
+    static const bool pairOff = knobInt(FX_DIAG_KNOB("FX_XLATE_LDS2"), 1) == 0;   // diagnostics
     L->ringFirst = tableBytes == 0 && !pairOff;
     const uint32_t fixed = ((tableBytes + 255u) & ~255u) + 256u * (uint32_t)K + L->scratchBytes;
     while (group > 1 && fixed + 4u * (uint32_t)group * L->bufStride > ldsBudget) group /= 2;
@@ -3489,13 +3496,13 @@ bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t
 
 bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
                       const XlateProgram& program, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* codeOut,
-                      std::vector<std::string>* listingOut, std::string* err, uint32_t ldsBudget, int maxGroup) {
+                      std::vector<std::string>* listingOut, std::string* err, uint32_t ldsBudget, int maxGroup, int pinGroup) {
     const int K = (int)plan.cuts.size() + 1;
     if (K < 2) { if (err) *err = "not a staged plan"; return false; }
     size_t n = 0;
     while (n < steadyRecords.size() && steadyRecords[n].w[0] != AS_ENDSAMPLE) ++n;
     StageLds L;
-    if (!stageLdsLayout(program, plan, ldsBudget, maxGroup, &L)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
+    if (!stageLdsLayout(program, plan, ldsBudget, maxGroup, &L, pinGroup)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
     const std::vector<uint32_t>& cutOff = L.cutOff;
     const uint32_t bufStride = L.bufStride, flagBase = L.flagBase, bufBase = L.bufBase;
     const int group = L.group;
@@ -3544,7 +3551,7 @@ bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vect
                 break;
             }
         // steps far shorter than a trip to memory: PCM input in bursts (a stage with delay lines keeps the loop's own prefetch)
-        p.stage.inRing = (p.tramOpsInline == 0 && p.hoist.leadCount == 0 && !std::getenv("FX_STAGES_NO_RING")) ? -2 : -1;
+        p.stage.inRing = (p.tramOpsInline == 0 && p.hoist.leadCount == 0 && !FX_DIAG_KNOB("FX_STAGES_NO_RING")) ? -2 : -1;
         if (k == 0) stage0Hoist = p.hoist;
         XlateImage one;
         std::vector<uint32_t> c5[5];

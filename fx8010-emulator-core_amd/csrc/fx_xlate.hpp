@@ -206,7 +206,8 @@ struct StageLds {
     int group = 1;
     bool ringFirst = false;         // [ring][flags][scratch] instead of [tables][flags][ring][scratch]
 };
-bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* out);
+// pinGroup: 1, 2 or 4 = exactly that many samples between two barriers, whatever would fit (the FX_STAGES_GROUP knob: tests of short rings)
+bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* out, int pinGroup = 0);
 
 // what the template needs per stage (fx_interp_gfx950.S, KA_STAGES): 32 bytes each
 struct StageDescriptor {
@@ -251,6 +252,7 @@ bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vecto
 bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
                       const XlateProgram& prog, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* code,
                       std::vector<std::string>* listing, std::string* err, uint32_t ldsBudget = 144u * 1024u,   // LDS a workgroup may take (several per CU: less)
-                      int maxGroup = kStageGroupMax);   // samples between two barriers at most: short blocks want short steps (the pipeline fills and drains in 3 (K - 1) of them)
+                      int maxGroup = kStageGroupMax,    // samples between two barriers at most: short blocks want short steps (the pipeline fills and drains in 3 (K - 1) of them)
+                      int pinGroup = 0);                // stageLdsLayout
 
 }  // namespace fx

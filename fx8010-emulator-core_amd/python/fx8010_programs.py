@@ -246,8 +246,10 @@ CONFIGS = {
     "config5_dane": config5_dane,
 }
 
-# instances / samples BASELINE.json quotes per config (config 5: per-GPU shard of 2 097 152 / 8)
+# instances BASELINE.json quotes per config: CONFIG_TOTAL_INSTANCES = the whole job (config 5: 2 097 152, "sharded across 8" - a FIXED
+# total: strong scaling), CONFIG_INSTANCES = one GPU's share of it when all the GPUs the config names are there (config 5: 1/8)
 CONFIG_INSTANCES = {"config1_shipped": 1, "config1_logtube": 1, "config2": 4096, "config3": 65536, "config4": 262144, "config5": 262144, "tram_bound": 262144, "config5_dane": 262144}
+CONFIG_TOTAL_INSTANCES = dict(CONFIG_INSTANCES, config5=2097152, tram_bound=2097152, config5_dane=2097152)
 
 
 def count_instructions(text):

@@ -774,3 +774,105 @@ def test_wavefronts_of_a_simd_take_turns(gpu, kernel, monkeypatch):
                 assert b.instruction_counter_i(inst) == o.instruction_counter()
         del b
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+RELEASE_KNOB_VALUES = [
+    ("FX_KERNEL", ["xlate", "xlate_v168", "asm", "asm_v128", "asm_lds", "hip"]),
+    ("FX_INST_PER_LANE", ["1", "2", "4"]),
+    ("FX_STAGES", ["1", "2", "4", "8", "16"]),
+    ("FX_STAGES_GROUP", ["1", "2", "4"]),
+    ("FX_STAGES_TUNE", ["0"]),
+    ("FX_BUILDER", ["0"]),
+    ("FX_XLATE_PRIO", ["0", "1"]),
+    ("FX_HOST_PIPELINE", ["0"]),
+]
+
+
+def test_no_release_knob_changes_a_bit(gpu, monkeypatch):
+    """INTEGRATION.md's table of environment knobs - everything the release library reads (csrc/fx_knobs.hpp; the CPU half:
+    tests/test_release_knobs.py) - value by value on config3 (delay line with feedback, 256 instructions): three blocks through
+    the host boundary, one of them large enough (33 MiB) for the pipelined copy that FX_HOST_PIPELINE switches off, then every
+    output word, the registers and delay-line positions of sampled instances, every instance's instruction counter total and
+    the out-of-domain flags must equal the default's; the default itself is checked against the oracle.  A knob may cost time,
+    never a bit: the contract is the reference's process() (source/FX8010.cpp:1023-1249)."""
+    for k, _ in RELEASE_KNOB_VALUES:
+        monkeypatch.delenv(k, raising=False)
+    text = progs.CONFIGS["config3"]()
+    N, cuts = 4100, [0, 7, 39, 39 + 2048]
+    x = progs.stimulus(N, cuts[-1])
+    watch = (0, 63, 64, 2049, N - 1)
+
+    def run():
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        b.set_register_i("t", 64, 0.125)     # one per-instance value: a row that the code did not ask for
+        y = np.concatenate([b.process_block(x[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])], axis=0)
+        regs = {n: [b.get_register_bits_i(r, n) for r in ("t", "a", "rd", "out", "ccr")] + b.get_cursors_i(n) + [b.instruction_counter_i(n)] for n in watch}
+        return y, regs, b.instruction_counter(), b.ood_flags(), b.tier_note()
+
+    y0, regs0, count0, ood0, note0 = run()
+    assert ood0 == 0 and note0.startswith("translated to gfx950 code")
+    for n in watch:
+        o = Oracle(1)
+        assert o.load_text(text)
+        if n == 64:
+            o.set_register("t", 0.125)
+        ref = o.process_block(x[:, n].copy())
+        assert np.array_equal(bits(ref), bits(y0[:, n])), n
+        assert regs0[n][-1] == o.instruction_counter() and regs0[n][5:9] == o.cursors()
+    seen = set()
+    for knob, values in RELEASE_KNOB_VALUES:
+        for v in values:
+            monkeypatch.setenv(knob, v)
+            if knob == "FX_STAGES_GROUP":
+                monkeypatch.setenv("FX_STAGES", "4")      # (a ring length only means something for a staged program)
+            y, regs, count, ood, note = run()
+            monkeypatch.delenv(knob)
+            monkeypatch.delenv("FX_STAGES", raising=False)
+            seen.add(note.split(":")[0].split(",")[0])
+            assert np.array_equal(bits(y), bits(y0)), "%s=%s changed an output word (%s)" % (knob, v, note)
+            assert regs == regs0 and count == count0 and ood == ood0, "%s=%s (%s)" % (knob, v, note)
+    assert len(seen) >= 4, seen   # the knobs did reach other tiers and builds
+
+
+def test_damaged_state_images_are_refused_before_any_address_is_computed(gpu):
+    """fxb_load_state reads a header the CALLER supplies (a checkpoint file): every field is validated before it enters pointer
+    arithmetic - negative or absurd slot counts (which would make the size check accept a short buffer and the section
+    pointers run backwards), a wrong version, other register counts, a truncated image.  Each refusal leaves the handle as it
+    was: the next block continues bit-exactly.  (negative iSlots / xSlots used to pass both checks.)"""
+    import struct
+    text = ("itramsize 37 \nxtramsize 100 \nstatic rd\nstatic xd\nstatic a\ninput in 0\noutput out 0\n"
+            "idelay read, rd, at, 0\nxdelay read, xd, at, 0\nmacs a, in, rd, 0.5\nidelay write, a, at, 0\nxdelay write, a, at, 0\nmacs out, a, xd, 0.25\nend")
+    N, S = 130, 60
+    x = progs.stimulus(N, 3 * S)
+    b = gpu.Batch(N, 1, 0)
+    twin = gpu.Batch(N, 1, 0)
+    assert b.load_text(text) and twin.load_text(text)
+    b.process_block(x[:S])
+    twin.process_block(x[:S])
+    img = b.save_state()
+    # header: magic u32, version u32, n i64, channels, nRegs, stateRows, iSlots, xSlots i32, reserved[7]
+    magic, version, n, channels, n_regs, rows, islots, xslots = struct.unpack_from("<IIqiiiii", img, 0)
+    assert (magic, version, n, channels) == (0x54535846, 1, N, 1) and islots == 37 and xslots == 100
+
+    def mutated(**kw):
+        f = dict(magic=magic, version=version, n=n, channels=channels, n_regs=n_regs, rows=rows, islots=islots, xslots=xslots)
+        f.update(kw)
+        out = img.copy()
+        struct.pack_into("<IIqiiiii", out, 0, f["magic"], f["version"], f["n"], f["channels"], f["n_regs"], f["rows"], f["islots"], f["xslots"])
+        return out
+
+    bad = [mutated(islots=-37), mutated(xslots=-100), mutated(islots=-(rows + 100)), mutated(xslots=-2 ** 31), mutated(islots=2 ** 30), mutated(version=2),
+           mutated(magic=0), mutated(n=N + 1), mutated(n=-N), mutated(channels=0), mutated(n_regs=n_regs + 1), mutated(rows=rows + 1), mutated(rows=-1), mutated(rows=0),
+           mutated(islots=38), img[:-4], img[:64], img[:10], mutated(islots=-37)[:64 + N * 4 * (rows + 100 - 37)]]
+    for k, image in enumerate(bad):
+        with pytest.raises(RuntimeError):
+            b.load_state(image)
+        assert b.last_error(), k
+    # the handle is where it was: the next blocks equal an untouched twin's, and the good image still loads
+    assert np.array_equal(bits(b.process_block(x[S:2 * S])), bits(twin.process_block(x[S:2 * S])))
+    b.load_state(img)
+    twin.load_state(img)
+    assert np.array_equal(bits(b.process_block(x[2 * S:])), bits(twin.process_block(x[2 * S:])))
+    # a smaller delay line in the image than in the batch is legal (the rest stays zero) - and not a way around the size check
+    assert b.info("itram_slots") == 37

@@ -1081,6 +1081,62 @@ def test_config5_full_shard_beyond_the_delay_line(gpu, monkeypatch):
     torch.cuda.empty_cache()
 
 
+def test_config5_all_instances_on_one_gpu(gpu, monkeypatch):
+    """BASELINE configs[4] itself on ONE MI355X - what bench.py times at --gpus 1 (strong scaling: the whole job on the one GPU):
+    2 097 152 instances (less 37: a ragged last wavefront) of the 512-instruction reverb, 64 GiB of xTRAM, 32 rounds of
+    wavefronts per SIMD in one launch of the same code the 1/8 shard runs.  PCM generated in HBM (bench.py device_stimulus),
+    2 304 samples in three launches (the delay lines wrap at sample 2048).  48 instances spread over the job - first / last
+    lanes of a wavefront, the ragged tail, both sides of every 262 144-instance shard boundary of the 8-GPU split - against the
+    oracle bit for bit with their instruction counters, twins fed the same PCM at far-apart places, and the exact
+    instruction total of the job (no SKIP in this program: every instance executes every instruction)"""
+    import torch
+
+    import bench
+    monkeypatch.delenv("FX_KERNEL", raising=False)
+    monkeypatch.delenv("FX_INST_PER_LANE", raising=False)
+    text = progs.config5()
+    N, cuts = progs.CONFIG_TOTAL_INSTANCES["config5"] - 37, [0, 1500, 2050, 2304]
+    S = cuts[-1]
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    need = 2 * N * S * 4 + N * 8192 * 4 + (8 << 30)
+    assert free > need, "this test needs %.0f GiB of HBM, %.0f are free" % (need / 2 ** 30, free / 2 ** 30)
+    x = bench.device_stimulus(torch, N, S, 0, dev)
+    twins = [7, 64 * 4097 + 63, 3 * 262144 + 1, N - 1]
+    for t in twins[1:]:
+        x[:, t] = x[:, twins[0]]
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(text), b.errors()
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        b.process_block_dev(x[lo:hi].data_ptr(), y[lo:hi].data_ptr(), hi - lo)
+    b.sync()
+    assert b.info("kernel") >= 9 and b.info("waves_per_wg") == 1
+    assert b.info("xtram_slots") == 8192 and b.info("grid") == (N + 63) // 64
+    edges = [k * 262144 + d for k in range(1, 8) for d in (-1, 0)]
+    picks = sorted(set([0, 63, 64, 4097, N - 65, N - 2] + edges + [int(v) for v in np.linspace(0, N - 1, 30)]) - set(twins[1:]))
+    assert len(picks) >= 48
+    cols = torch.tensor(picks + twins, device=dev)
+    xs = x[:, cols].cpu().numpy()
+    ys = y[:, cols].cpu().numpy()
+    for j, t in enumerate(twins[1:], start=len(picks) + 1):
+        assert np.array_equal(bits(ys[:, j]), bits(ys[:, len(picks)])), "instance %d differs from its twin" % t
+    for j, n in enumerate(picks):
+        assert np.array_equal(bits(xs[:, j]), bits(progs.stimulus(1, S, first_instance=n)[:, 0])), "device stimulus differs from the host's"
+        o = Oracle(1)
+        assert o.load_text(text)
+        ref = o.process_block(xs[:, j].copy())
+        bad = np.nonzero(bits(ref) != bits(ys[:, j]))[0]
+        assert bad.size == 0, "instance %d: first mismatch at sample %d" % (n, bad[0])
+        assert b.instruction_counter_i(n) == o.instruction_counter()
+        assert b.get_register_bits_i("d3", n) == o.get_register_bits("d3") and o.get_register_bits("d3") & 0x7fffffff
+    assert b.ood_flags() == 0
+    assert b.instruction_counter() == N * progs.count_instructions(text) * S
+    del b, x, y
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_api_sequences(gpu, seed, monkeypatch):
     """Random sequences of the calls a host makes between blocks - block lengths from 1 sample up, broadcast control
