@@ -261,8 +261,8 @@ bool Batch::laneResident(int reg) const {
 // Small batches leave SIMDs empty (and a lone wavefront issues an instruction only every ~4 clocks): a program that can be cut
 // runs as a pipeline of stages over the wavefronts of a workgroup (fx_xlate.hpp StageInfo).  Beyond two wavefronts of instances
 // per SIMD the plain program has always been the faster one.  FX_STAGES pins the number asked for (1 = never).
-bool Batch::stagingPossible() const {
-    if (stagingOff_) return false;
+bool Batch::stagingPossibleGiven(bool stagingOff) const {
+    if (stagingOff) return false;
     if (knobs_.stages) return knobs_.stages >= 2;
     return (n_ + 63) / 64 < 2048;
 }
@@ -279,9 +279,9 @@ bool Batch::stagingPossible() const {
 // The options come back cheapest first.  The model is good to ~ 20 % (how the dispatcher spreads workgroups over the CUs is not
 // in it), so options within kTuneBand of the best are MEASURED on the caller's own blocks before one is kept (noteLaunchTime).
 std::vector<Batch::StageOption> Batch::rankStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
-                                                  const XlateProgram& xprog, int nRows, int blockClass, int wavesPerSimdCap) const {
+                                                  const XlateProgram& xprog, int nRows, int blockClass, int wavesPerSimdCap, bool stagingOff) const {
     std::vector<StageOption> out;
-    if (stagingOff_) { out.push_back(StageOption()); return out; }
+    if (stagingOff) { out.push_back(StageOption()); return out; }
     if (knobs_.stages) {
         StageOption o;
         o.wanted = knobs_.stages;
@@ -298,7 +298,7 @@ std::vector<Batch::StageOption> Batch::rankStages(const std::vector<MicroOp>& st
     bool havePlain = false;
     std::vector<int> seen;
     for (int wanted : {8, 4, 2}) {
-        if (!stagingPossible()) break;
+        if (!stagingPossibleGiven(stagingOff)) break;
         const StagePlan plan = planStages(steadyRecords, lastRecords, xprog, nRows, wanted);
         if (!havePlain && plan.totalCost > 0) {
             plain.wanted = plain.stages = 1;
@@ -575,7 +575,9 @@ struct Batch::Builder {
     std::deque<BuildInputs> jobs;
     std::string running;                          // key being built
     std::vector<std::unique_ptr<Code>> finished;
-    std::vector<std::string> failed;              // keys the offline path cannot build (left to the caller's thread)
+    std::deque<std::string> failed;               // keys the offline path could not build (left to the caller's thread); the most recent kMaxFailed
+    static constexpr size_t kMaxFailed = 32;      // (a forgotten one is merely asked for again)
+    hipStream_t upload = nullptr;                 // the thread's own copy stream (created and destroyed by it; read by it only)
     bool quit = false;
 };
 
@@ -590,10 +592,15 @@ void Batch::requestBuild(BuildInputs&& in) {
         Builder* b = builder_.get();
         b->thread = std::thread([this, b] {
             (void)hipSetDevice(device_);
+            if (hipStreamCreateWithFlags(&b->upload, hipStreamNonBlocking) != hipSuccess) { b->upload = nullptr; (void)hipGetLastError(); }
             std::unique_lock<std::mutex> lock(b->mu);
             for (;;) {
                 b->cv.wait(lock, [b] { return b->quit || !b->jobs.empty(); });
-                if (b->quit) return;
+                if (b->quit) {
+                    if (b->upload) (void)hipStreamDestroy(b->upload);
+                    b->upload = nullptr;
+                    return;
+                }
                 BuildInputs job = std::move(b->jobs.front());
                 b->jobs.pop_front();
                 b->running = job.key;
@@ -605,7 +612,10 @@ void Batch::requestBuild(BuildInputs&& in) {
                 lock.lock();
                 b->running.clear();
                 if (rc == 0) b->finished.push_back(std::move(c));
-                else b->failed.push_back(job.key);
+                else {
+                    b->failed.push_back(job.key);
+                    if (b->failed.size() > Builder::kMaxFailed) b->failed.pop_front();
+                }
                 b->cv.notify_all();
             }
         });
@@ -729,6 +739,11 @@ Batch::BuildInputs Batch::buildInputs(const std::string& key, int blockClass, bo
     in.forced = laneForced();
     in.trackRegs = trackRegs_;
     in.stagePick = pickFor(blockClass);
+    in.instPerLane = instPerLane_;
+    in.iSlotsAlloc = iSlotsAlloc_;
+    in.xSlotsAlloc = xSlotsAlloc_;
+    in.stateRows = stateRows_;
+    in.stagingOff = stagingOff_;
     return in;
 }
 
@@ -745,10 +760,13 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
     // Programs it does not cover run on the HIP C++ kernel.  TRAM tiling pins K once allocated.
     Lowered fresh;
     bool asmOk = false;
-    const bool tramPinned = iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0;
+    // (offline: the snapshot the request came with - the members belong to the caller's thread)
+    const int instPerLane = offline ? in.instPerLane : instPerLane_;
+    const bool stagingOff = offline ? in.stagingOff : stagingOff_;
+    const bool tramPinned = offline ? (in.iSlotsAlloc > 0 || in.xSlotsAlloc > 0) : (iSlotsAlloc_ > 0 || xSlotsAlloc_ > 0);
     const char* forceHip = knobs_.kernel.empty() ? nullptr : knobs_.kernel.c_str();
     const bool wantAsm = !knobs_.kernelIs("hip") && !knobs_.instPerLaneSet;
-    if (wantAsm && (!tramPinned || instPerLane_ == 1)) {
+    if (wantAsm && (!tramPinned || instPerLane == 1)) {
         // first choice: register file in VGPRs (row pitch 1 = plain indices), else in LDS
         const bool tryVgpr = !(forceHip && std::strcmp(forceHip, "asm_lds") == 0);
         if (tryVgpr) {
@@ -769,7 +787,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
                 }
                 // a small batch is cut into stages (below): each stage wants spare registers for its packets and its input
                 // bursts, and at most 4 wavefronts per SIMD will be resident anyway - the 128-register build costs nothing
-                if (stagingPossible())
+                if (stagingPossibleGiven(stagingOff))
                     while (v < ASM_V128) ++v;
                 // two or more wavefronts per SIMD: they take turns at the top priority (fx_xlate.hpp prioritySlices), which has
                 // four levels - and a fifth resident wavefront adds nothing to a SIMD that four keep issuing (measured: config5
@@ -799,7 +817,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
     if (!asmOk && offline) return fail(FX_E_NOTREADY, "offline build: not a program for the assembly tiers");
     if (!asmOk) fresh = lowerProgram(prog_, in.hostValue, in.forced, chooseInstPerLane());
     if (!fresh.error.empty()) return fail(FX_E_PROGRAM, fresh.error);
-    if (offline && (fresh.instPerLane != instPerLane_ || fresh.iSlots > iSlotsAlloc_ || fresh.xSlots > xSlotsAlloc_ || makeLayout((int)prog_.regs.size(), prog_.numChannels).totalRows != stateRows_))
+    if (offline && (fresh.instPerLane != in.instPerLane || fresh.iSlots > in.iSlotsAlloc || fresh.xSlots > in.xSlotsAlloc || makeLayout((int)prog_.regs.size(), prog_.numChannels).totalRows != in.stateRows))
         return fail(FX_E_NOTREADY, "offline build: the batch's device state would have to change");
     int rc = 0;
     if (!offline) {
@@ -838,7 +856,8 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
         for (int reg : in.trackRegs) trackRows.push_back(c.low.rowOfReg[(size_t)reg]);
         XlateProgram xprog = xlateProgramOf(steadyRecords, lastRecords, prog_.iTramSize, prog_.xTramSize, c.low.nRows, c.low.inRow, c.low.latchRow, trackRows);
         // 256 bytes per wavefront and slot; the Infinity Cache holds 256 MiB
-        xprog.tramStreaming = ((size_t)iSlotsAlloc_ + (size_t)xSlotsAlloc_) * (((size_t)n_ + 63) / 64) * 256 > ((size_t)512 << 20);
+        const size_t slotsAlloc = offline ? (size_t)in.iSlotsAlloc + (size_t)in.xSlotsAlloc : (size_t)iSlotsAlloc_ + (size_t)xSlotsAlloc_;
+        xprog.tramStreaming = slotsAlloc * (((size_t)n_ + 63) / 64) * 256 > ((size_t)512 << 20);
         {
             // wavefronts of a SIMD by turns at the top priority (fx_xlate.hpp prioritySlices): wherever a SIMD holds two or more
             // (the build chosen above has at most four slots then; FX_XLATE_PRIO=0 / 1 in the environment: never / whenever unstaged)
@@ -854,7 +873,7 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
         // into stages run by the wavefronts of one workgroup (fx_xlate.hpp StageInfo) until ~4 wavefronts per SIMD are in
         // flight.  FX_STAGES pins the number asked for (1 = never).
         // how many stages: the caller's pick (a measured one, or an option on trial), else the cheapest by the planner's costs
-        c.stageOptions = tmpl ? rankStages(steadyRecords, lastRecords, xprog, c.low.nRows, blockClass, kAsmWavesPerSimd[c.variant]) : std::vector<StageOption>();
+        c.stageOptions = tmpl ? rankStages(steadyRecords, lastRecords, xprog, c.low.nRows, blockClass, kAsmWavesPerSimd[c.variant], stagingOff) : std::vector<StageOption>();
         int wantStages = in.stagePick > 0 ? in.stagePick : (c.stageOptions.empty() ? 1 : c.stageOptions.front().wanted);
         c.stagePick = wantStages;
         // (the wavefronts of a workgroup must be resident together: a CU holds 4 SIMDs x the build's wavefronts per SIMD - a pinned
@@ -955,7 +974,15 @@ int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::stri
         std::memcpy(host.data() + p, c.stageDesc.data(), (size_t)c.stages * 32);
         p += (size_t)c.stages * 8;
     }
-    hipError_t e = hipMemcpy(c.dStream, host.data(), words * 4, hipMemcpyHostToDevice);   // (a buffer of its own: no launch reads it yet)
+    // (a buffer of its own: no launch reads it yet.  The builder thread copies through a non-blocking stream of its own: a plain
+    // hipMemcpy goes through the null stream, which would wait for - and hold up - a caller that launches on a blocking stream)
+    hipError_t e;
+    if (offline && builder_ && builder_->upload) {
+        e = hipMemcpyAsync(c.dStream, host.data(), words * 4, hipMemcpyHostToDevice, builder_->upload);
+        if (e == hipSuccess) e = hipStreamSynchronize(builder_->upload);
+    } else {
+        e = hipMemcpy(c.dStream, host.data(), words * 4, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) return hipFail(e, "stream upload");
     c.key = in.key;
     return 0;
@@ -1489,11 +1516,17 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
                                : hipMemcpy2DAsync(dIn_, width, in, (size_t)pitch * 4, width, rows, hipMemcpyHostToDevice, stream_);
     if (e != hipSuccess) return hipFail(e, "H2D");
     int rc = processDevice(dIn_, dOut_, nSamples, stream_);
-    if (rc != 0) return rc;
+    if (rc != 0) {
+        (void)hipStreamSynchronize(stream_);   // (whatever went wrong: no copy may still read the caller's buffer when this returns)
+        return rc;
+    }
     e = pitch == n_ ? hipMemcpyAsync(out, dOut_, count * 4, hipMemcpyDeviceToHost, stream_)
                     : hipMemcpy2DAsync(out, (size_t)pitch * 4, dOut_, width, width, rows, hipMemcpyDeviceToHost, stream_);
     if (e == hipSuccess) e = hipStreamSynchronize(stream_);
-    if (e != hipSuccess) return hipFail(e, "D2H");
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(stream_);
+        return hipFail(e, "D2H");
+    }
     return 0;
 }
 

@@ -207,6 +207,10 @@ private:
         std::vector<uint8_t> forced;             // laneForced()
         std::vector<int> trackRegs;
         int stagePick = 0;                       // stages to ask the planner for; 0: the cheapest by its costs (rankStages)
+        // the batch's device state as it was when the build was asked for: a build on the builder thread must not change any of
+        // it and reads only this copy (the caller's thread may be growing the state or the delay lines meanwhile)
+        int instPerLane = 1, iSlotsAlloc = 0, xSlotsAlloc = 0, stateRows = 0;
+        bool stagingOff = false;
     };
     BuildInputs buildInputs(const std::string& key, int blockClass, bool defer) const;
     int buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::string* err);
@@ -218,10 +222,11 @@ private:
     bool controlMode_ = false;                   // the declared controls have rows (the host has moved one)
 
     // ---- how many stages (rankStages: the planner's costs; noteLaunchTime: options the model cannot tell apart are measured)
-    bool stagingPossible() const;
+    bool stagingPossible() const { return stagingPossibleGiven(stagingOff_); }
+    bool stagingPossibleGiven(bool stagingOff) const;
     bool stagingOff_ = false;                    // a staged launch failed to start on this device: the plain program from then on
     std::vector<StageOption> rankStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& xprog,
-                                        int nRows, int blockClass, int wavesPerSimdCap) const;
+                                        int nRows, int blockClass, int wavesPerSimdCap, bool stagingOff) const;
     static constexpr double kTuneBand = 1.6;     // options predicted within this factor of the cheapest are tried
     static constexpr int kTuneRuns = 3, kTuneMinSamples = 8;
     struct Tuner {

@@ -103,7 +103,7 @@ int Sharded::fan(const std::function<int(int, Batch&)>& f) {
     // one post at a time per handle: every worker has ONE mailbox slot, and a second host thread (a UI thread reading a register
     // while the audio thread processes a block) must not overwrite a task that has not been picked up yet - its caller would
     // wait for `done` forever.  (A handle is still not meant for concurrent use: calls are serialised, not made independent.)
-    std::lock_guard<std::mutex> post(post_);
+    Serial post(api_);
     for (size_t k = 0; k < shards_.size(); ++k) {
         Worker* w = shards_[k].get();
         std::lock_guard<std::mutex> lock(w->mu);
@@ -130,7 +130,7 @@ int Sharded::runOn(int k, const std::function<int(Batch&)>& f) {
         DeviceGuard guard;
         return f(*w->batch);
     }
-    std::lock_guard<std::mutex> post(post_);
+    Serial post(api_);
     {
         std::lock_guard<std::mutex> lock(w->mu);
         w->task = [&f, w] { return f(*w->batch); };
@@ -153,31 +153,38 @@ int Sharded::shardOf(int64_t inst) const {
 const std::string& Sharded::lastError() { return lastError_.empty() ? shards_.front()->batch->lastError() : lastError_; }
 
 bool Sharded::loadFile(const std::string& path) {
+    Serial serial(api_);
     lastError_.clear();
     return fan([&](int, Batch& b) { return b.loadFile(path) ? 0 : 1; }) == 0;
 }
 bool Sharded::loadText(const std::string& text) {
+    Serial serial(api_);
     lastError_.clear();
     return fan([&](int, Batch& b) { return b.loadText(text) ? 0 : 1; }) == 0;
 }
 int Sharded::setRegister(const std::string& key, float v) {
+    Serial serial(api_);
     lastError_.clear();
     return fan([&](int, Batch& b) { return b.setRegister(key, v); });
 }
 void Sharded::setChannels(int c) {
+    Serial serial(api_);
     fan([&](int, Batch& b) { b.setChannels(c); return 0; });
 }
 int Sharded::setOption(unsigned option, bool on) {
+    Serial serial(api_);
     lastError_.clear();
     return fan([&](int, Batch& b) { return b.setOption(option, on) ? -3 : 0; });
 }
 int Sharded::setRegisterAt(const std::string& key, int64_t inst, float v) {
+    Serial serial(api_);
     lastError_.clear();
     const int k = shardOf(inst);
     if (k < 0) { lastError_ = "instance out of range"; return front().program().findRegister(key) < 0 ? 1 : FX_E_ARG; }
     return runOn(k, [&](Batch& b) { return b.setRegisterAt(key, inst - shards_[(size_t)k]->first, v); });
 }
 float Sharded::getRegisterAt(const std::string& key, int64_t inst) {
+    Serial serial(api_);
     lastError_.clear();
     const int k = shardOf(inst);
     float out = 1.0f;
@@ -185,16 +192,19 @@ float Sharded::getRegisterAt(const std::string& key, int64_t inst) {
     return out;
 }
 int Sharded::setRegisterArray(const std::string& key, const float* values) {
+    Serial serial(api_);
     lastError_.clear();
     if (!values) { lastError_ = "null buffer"; return FX_E_ARG; }
     return fan([&](int k, Batch& b) { return b.setRegisterArray(key, values + shards_[(size_t)k]->first); });
 }
 int Sharded::getRegisterArray(const std::string& key, float* values) {
+    Serial serial(api_);
     lastError_.clear();
     if (!values) { lastError_ = "null buffer"; return FX_E_ARG; }
     return fan([&](int k, Batch& b) { return b.getRegisterArray(key, values + shards_[(size_t)k]->first); });
 }
 int Sharded::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
+    Serial serial(api_);
     lastError_.clear();
     const int k = shardOf(inst);
     if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
@@ -202,6 +212,7 @@ int Sharded::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
 }
 
 int Sharded::setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance) {
+    Serial serial(api_);
     lastError_.clear();
     if (!values) { lastError_ = "null buffer"; return FX_E_ARG; }
     // per-instance schedules are [step][all instances]: a shard takes its columns
@@ -209,6 +220,7 @@ int Sharded::setRegisterTrack(const std::string& key, const float* values, int n
 }
 
 int Sharded::processHost(const float* in, float* out, int nSamples) {
+    Serial serial(api_);
     lastError_.clear();
     if (shards_.size() == 1) return runOn(0, [&](Batch& b) { return b.processHost(in, out, nSamples); });
     if (nSamples > 0 && (!in || !out)) { lastError_ = "null buffer"; return FX_E_ARG; }
@@ -218,21 +230,25 @@ int Sharded::processHost(const float* in, float* out, int nSamples) {
     });
 }
 int Sharded::processDeviceShards(const float* const* dIn, float* const* dOut, int nSamples) {
+    Serial serial(api_);
     lastError_.clear();
     if (nSamples > 0 && (!dIn || !dOut)) { lastError_ = "null buffer table"; return FX_E_ARG; }
     return fan([&](int k, Batch& b) { return b.processDevice(dIn ? dIn[k] : nullptr, dOut ? dOut[k] : nullptr, nSamples, nullptr); });
 }
 int Sharded::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_t stream) {
+    Serial serial(api_);
     lastError_.clear();
     if (shards_.size() != 1) { lastError_ = "a batch of several shards takes one buffer pair per shard: fxb_process_block_dev_shards"; return FX_E_ARG; }
     return runOn(0, [&](Batch& b) { return b.processDevice(dIn, dOut, nSamples, stream); });
 }
 int Sharded::sync() {
+    Serial serial(api_);
     lastError_.clear();
     return fan([](int, Batch& b) { return b.sync(); });
 }
 
 int64_t Sharded::instructionCounter() {
+    Serial serial(api_);
     std::vector<int64_t> part(shards_.size(), 0);
     fan([&](int k, Batch& b) { part[(size_t)k] = b.instructionCounter(); return 0; });
     int64_t sum = 0;
@@ -243,6 +259,7 @@ int64_t Sharded::instructionCounter() {
     return sum;
 }
 int64_t Sharded::instructionCounterAt(int64_t inst) {
+    Serial serial(api_);
     const int k = shardOf(inst);
     if (k < 0) return 0;
     int64_t out = 0;
@@ -250,6 +267,7 @@ int64_t Sharded::instructionCounterAt(int64_t inst) {
     return out;
 }
 uint32_t Sharded::oodFlags() {
+    Serial serial(api_);
     std::vector<uint32_t> part(shards_.size(), 0);
     fan([&](int k, Batch& b) { part[(size_t)k] = b.oodFlags(); return 0; });
     uint32_t all = 0;
@@ -257,6 +275,7 @@ uint32_t Sharded::oodFlags() {
     return all;
 }
 float Sharded::lastKernelMs() {
+    Serial serial(api_);
     std::vector<float> part(shards_.size(), -1.0f);
     fan([&](int k, Batch& b) { part[(size_t)k] = b.lastKernelMs(); return 0; });  // (a shard's events belong to its thread's device)
     float worst = -1.0f;
@@ -264,6 +283,7 @@ float Sharded::lastKernelMs() {
     return worst;
 }
 int64_t Sharded::stateBytes() {
+    Serial serial(api_);
     lastError_.clear();
     Batch::SnapshotHeader hdr;
     if (runOn(0, [&](Batch& b) { return b.snapshotShape(&hdr); }) != 0) return -1;
@@ -271,6 +291,7 @@ int64_t Sharded::stateBytes() {
     return Batch::snapshotBytes(hdr);
 }
 int Sharded::saveState(void* buf, int64_t cap) {
+    Serial serial(api_);
     lastError_.clear();
     Batch::SnapshotHeader hdr;
     int rc = runOn(0, [&](Batch& b) { return b.snapshotShape(&hdr); });
@@ -281,6 +302,7 @@ int Sharded::saveState(void* buf, int64_t cap) {
     return fan([&](int k, Batch& b) { return b.saveStateColumns(static_cast<uint8_t*>(buf), hdr, shards_[(size_t)k]->first); });
 }
 int Sharded::loadState(const void* buf, int64_t bytes) {
+    Serial serial(api_);
     lastError_.clear();
     Batch::SnapshotHeader hdr;
     if (!buf || bytes < (int64_t)sizeof(hdr)) { lastError_ = "load_state: no image"; return FX_E_ARG; }
@@ -296,27 +318,32 @@ int Sharded::loadState(const void* buf, int64_t bytes) {
     return fan([&](int k, Batch& b) { return b.loadStateColumns(static_cast<const uint8_t*>(buf), hdr, shards_[(size_t)k]->first); });
 }
 int Sharded::getTramAt(int which, int64_t inst, float* out, int nSlots) {
+    Serial serial(api_);
     lastError_.clear();
     const int k = shardOf(inst);
     if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
     return runOn(k, [&](Batch& b) { return b.getTramAt(which, inst - shards_[(size_t)k]->first, out, nSlots); });
 }
 int Sharded::getCursorsAt(int64_t inst, int32_t out4[4]) {
+    Serial serial(api_);
     lastError_.clear();
     const int k = shardOf(inst);
     if (k < 0) { lastError_ = "instance out of range"; return FX_E_ARG; }
     return runOn(k, [&](Batch& b) { return b.getCursorsAt(inst - shards_[(size_t)k]->first, out4); });
 }
 int Sharded::prepare(int nSamples, bool wait) {
+    Serial serial(api_);
     lastError_.clear();
     return fan([&](int, Batch& b) { return b.prepare(nSamples, wait); });
 }
 float Sharded::lastKernelMsOf(int k) {
+    Serial serial(api_);
     float ms = -1.0f;
     runOn(k, [&](Batch& b) { ms = b.lastKernelMs(); return 0; });
     return ms;
 }
 int64_t Sharded::info(int what) {
+    Serial serial(api_);
     std::vector<int64_t> part(shards_.size(), 0);
     fan([&](int k, Batch& b) { part[(size_t)k] = b.info(what); return 0; });
     if (what == FXB_INFO_GRID) {

@@ -106,7 +106,13 @@ private:
     int64_t n_ = 0;
     std::vector<std::unique_ptr<Worker>> shards_;
     std::string lastError_;
-    std::mutex post_;   // serialises posts to the workers' mailboxes (fan / runOn)
+    // One call at a time per handle.  A handle is not meant for concurrent use (the reference's objects are not either), but a host
+    // with a UI thread that reads a register while its audio thread processes a block must get serialised calls, not corrupted
+    // ones: every public call that touches the shards or lastError_ holds this for its whole duration (recursive: fan / runOn
+    // take it again for their posts to the one-slot mailboxes).  Found wanting by ThreadSanitizer: lastError_.clear() used to run
+    // in front of the lock (tests/hipstub/host_threads.cpp, scenario "shards").
+    std::recursive_mutex api_;
+    using Serial = std::lock_guard<std::recursive_mutex>;
 };
 
 }  // namespace fx

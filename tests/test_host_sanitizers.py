@@ -32,3 +32,35 @@ def test_host_code_under_asan_and_ubsan():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-6000:]
     assert "passed" in r.stdout
+
+
+def _host_threads(target, env, runs):
+    """build tests/hipstub/host_threads.cpp against the library's host sources (csrc/Makefile `tsan` / `stubasan`) and run it"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("no ROCm clang on this machine")
+    subprocess.check_call(["make", "-s", "-C", CSRC, target])
+    exe = os.path.join(CSRC, "build", target, "host_threads")
+    for args in runs:
+        r = subprocess.run([exe] + args, cwd=ROOT, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0 and "0 check(s) failed" in r.stdout, "%s %s\n%s\n%s" % (target, args, r.stdout[-2000:], r.stderr[-6000:])
+        for name in ("controls", "queued", "shards", "handles", "memory", "modules", "images"):
+            assert "%-9s ok" % name in r.stdout, r.stdout
+        assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-6000:]
+
+
+def test_host_threads_under_tsan():
+    """ThreadSanitizer over the library's own threads (the reference has none: /root/reference/include/FX8010.h:47-75) - the builder
+    thread and the code cache it hands across, cache eviction while the caller keeps lowering, the launch-timing tuner with
+    launches queued, drainBuilder during a load, a 3-shard handle with two host threads posting - without a GPU: the host
+    sources are linked against tests/hipstub/ (streams are worker threads; kernels take time and touch their buffers), at three
+    kernel durations for other interleavings.  First run (round 5) found: the builder reading instPerLane_ / iSlotsAlloc_ while
+    the caller's own build wrote them (now a snapshot in BuildInputs), Sharded::lastError_ cleared in front of the mailbox lock
+    (now one lock per call), and a failed block returning with its H2D copy still queued on the caller's buffer."""
+    _host_threads("tsan", {"TSAN_OPTIONS": "halt_on_error=1 second_deadlock_stack=1"}, [["--kernel-us=0"], ["--kernel-us=60"], ["--kernel-us=700"]])
+
+
+def test_host_logic_and_error_paths_under_asan_without_a_device():
+    """the same scenarios under AddressSanitizer + UBSan + LeakSanitizer: allocation failure (FX_E_MEMORY, handle stays usable,
+    nothing leaks over 50 create / load / run / destroy cycles), module-load failures on the caller's and on the builder's thread,
+    damaged state images in exactly-sized heap buffers (a read outside the image is a report)"""
+    _host_threads("stubasan", {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}, [[]])

@@ -44,6 +44,9 @@ print(json.dumps(d, indent=1))
 PY
   cp $OUT/${c}_bench.json $OUT/${TAG}_${c}_bench.json
   f=$(find $OUT/${c}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${c}_kernel_stats.csv
+  # (gpurun copies at most 64 MiB back: the raw traces and counter tables stay on the box, the summaries above are what is kept)
+  du -sh $OUT/${c}_trace $OUT/${c}_hbm $OUT/${c}_pmc $OUT/${c}_valu 2>/dev/null
+  rm -rf $OUT/${c}_trace $OUT/${c}_hbm $OUT/${c}_pmc $OUT/${c}_valu
 done
 ls $OUT | grep "^${TAG}_"
 echo done
