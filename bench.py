@@ -566,6 +566,24 @@ def main():
                                    "parity_checked": (r.get("parity") or {}).get("parity_checked"), "parity_ok": (r.get("parity") or {}).get("parity_ok")}
                 except Exception as e:  # an extra must never take the headline line down
                     extra[name] = {"error": str(e)[:200]}
+            # the reference's own measure of speed (source/main.cpp:99-155): 32-sample blocks at 48 kHz against 666.667 us, host-fed
+            # from pinned buffers with a slider moving every 8th block - how many instances stay inside the budget at p99.9
+            # (tools/realtime_capacity.py; the full sweep with 5 000 blocks per point is profiles/r05_realtime.json)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import realtime_capacity as rt
+                rows = []
+                for mode, counts in (("host", (65536, 131072, 196608)), ("device", (131072, 262144, 393216))):
+                    for n in counts:
+                        r = rt.measure(torch, fx8010_amd, progs, n, 1500, 200, mode)
+                        rows.append({k: r[k] for k in ("instances", "mode", "median_us", "p99_us", "p999_us", "max_us", "kernel_us_median", "within_budget_p999",
+                                                        "pcie_GBps_each_way_at_median", "translations_in_timed_region", "parity_ok", "blocks")})
+                extra["realtime"] = {"budget_us": round(rt.BUDGET_US, 3), "block_samples": rt.BLOCK, "program": "config5", "control_moved_every_blocks": rt.SLIDER_EVERY,
+                                     "capacity_host_fed": rt.capacity([r for r in rows if r["mode"] == "host"]),
+                                     "capacity_device_resident": rt.capacity([r for r in rows if r["mode"] == "device"]),
+                                     "note": "largest N of the rows whose p99.9 block time (call -> output in host memory / -> fxb_sync) is within the budget", "rows": rows}
+            except Exception as e:
+                extra["realtime"] = {"error": str(e)[:200]}
             out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:

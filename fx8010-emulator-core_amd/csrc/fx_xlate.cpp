@@ -1,9 +1,7 @@
-// fx_xlate.cpp — FX8010 program -> gfx950 machine code (see fx_xlate.hpp).
+// fx_xlate.cpp — FX8010 program -> gfx950 machine code (see fx_xlate.hpp): the Translator (one stream of records -> one sample
+// loop), the run-once code, hoist planning, row classes (xlateProgramOf) and the layout of a program's four streams
+// (planXlate).  The encoder is fx_xlate_emit.hpp, the template images fx_xlate_elf.cpp, the stage planner fx_xlate_stages.cpp.
 #include "fx_xlate.hpp"
-
-#include "fx_knobs.hpp"
-
-#include <elf.h>
 
 #include <algorithm>
 #include <cmath>
@@ -12,531 +10,14 @@
 #include <cstring>
 #include <functional>
 #include <map>
-#include <mutex>
+
+#include "fx_knobs.hpp"
+#include "fx_xlate_emit.hpp"
+#include "fx_xlate_internal.hpp"
 
 namespace fx {
+using namespace xl;
 namespace {
-
-// the template code objects (XLATE flavour of fx_interp_gfx950.S, one per VGPR build), embedded by the Makefile
-const unsigned char kBlobV64[] = {
-#include "build/fx_xlate_v64_blob.inc"
-};
-const unsigned char kBlobV72[] = {
-#include "build/fx_xlate_v72_blob.inc"
-};
-const unsigned char kBlobV80[] = {
-#include "build/fx_xlate_v80_blob.inc"
-};
-const unsigned char kBlobV96[] = {
-#include "build/fx_xlate_v96_blob.inc"
-};
-const unsigned char kBlobV128[] = {
-#include "build/fx_xlate_v128_blob.inc"
-};
-const unsigned char kBlobV168[] = {
-#include "build/fx_xlate_v168_blob.inc"
-};
-const unsigned char kBlobV256[] = {
-#include "build/fx_xlate_v256_blob.inc"
-};
-
-struct BlobRef { const unsigned char* p; size_t n; const char* kernel; int vgprs; };
-const BlobRef kBlobs[ASM_VARIANTS] = {
-    {nullptr, 0, "", 0},
-    {kBlobV64, sizeof(kBlobV64), "fx_xlate_v64", 64},
-    {kBlobV72, sizeof(kBlobV72), "fx_xlate_v72", 72},
-    {kBlobV80, sizeof(kBlobV80), "fx_xlate_v80", 80},
-    {kBlobV96, sizeof(kBlobV96), "fx_xlate_v96", 96},
-    {kBlobV128, sizeof(kBlobV128), "fx_xlate_v128", 128},
-    {kBlobV168, sizeof(kBlobV168), "fx_xlate_v168", 168},
-    {kBlobV256, sizeof(kBlobV256), "fx_xlate_v256", 256},
-};
-
-// ---- ELF: value and file offset of a named symbol ------------------------------------------------------
-struct SymbolAt { uint64_t value = 0; size_t fileOff = 0; bool found = false; };
-
-SymbolAt findSymbol(const unsigned char* img, size_t n, const std::string& name) {
-    SymbolAt r;
-    if (n < sizeof(Elf64_Ehdr)) return r;
-    Elf64_Ehdr eh;
-    std::memcpy(&eh, img, sizeof(eh));
-    if (std::memcmp(eh.e_ident, ELFMAG, SELFMAG) != 0 || eh.e_ident[EI_CLASS] != ELFCLASS64) return r;
-    if (eh.e_shoff == 0 || eh.e_shentsize != sizeof(Elf64_Shdr) || eh.e_shoff + (uint64_t)eh.e_shnum * sizeof(Elf64_Shdr) > n) return r;
-    std::vector<Elf64_Shdr> sh(eh.e_shnum);
-    std::memcpy(sh.data(), img + eh.e_shoff, sh.size() * sizeof(Elf64_Shdr));
-    for (const Elf64_Shdr& s : sh) {
-        if (s.sh_type != SHT_SYMTAB && s.sh_type != SHT_DYNSYM) continue;
-        if (s.sh_link >= sh.size() || s.sh_entsize != sizeof(Elf64_Sym) || s.sh_offset + s.sh_size > n) continue;
-        const Elf64_Shdr& str = sh[s.sh_link];
-        if (str.sh_offset + str.sh_size > n) continue;
-        const size_t count = s.sh_size / sizeof(Elf64_Sym);
-        for (size_t i = 0; i < count; ++i) {
-            Elf64_Sym sym;
-            std::memcpy(&sym, img + s.sh_offset + i * sizeof(Elf64_Sym), sizeof(sym));
-            if (sym.st_name >= str.sh_size) continue;
-            const char* nm = reinterpret_cast<const char*>(img + str.sh_offset + sym.st_name);
-            const size_t maxLen = str.sh_size - sym.st_name;
-            if (strnlen(nm, maxLen) == maxLen || name != nm) continue;
-            if (sym.st_shndx == SHN_UNDEF || sym.st_shndx >= sh.size()) continue;
-            const Elf64_Shdr& sec = sh[sym.st_shndx];
-            if (sym.st_value < sec.sh_addr || sym.st_value > sec.sh_addr + sec.sh_size) continue;
-            r.value = sym.st_value;
-            r.fileOff = (size_t)(sec.sh_offset + (sym.st_value - sec.sh_addr));
-            r.found = true;
-            return r;
-        }
-    }
-    return r;
-}
-
-std::mutex g_mu;
-XlateTemplate g_templates[ASM_VARIANTS];
-bool g_parsed[ASM_VARIANTS] = {};
-std::string g_parseErr[ASM_VARIANTS];
-
-// ---- operands --------------------------------------------------------------------------------------------
-// operand texts are only needed for a listing; building them costs more than the encoding itself
-thread_local bool tlsWantText = false;
-
-struct Src {
-    uint32_t code = 0;  // 9-bit source operand
-    uint32_t lit = 0;
-    bool hasLit = false;
-    std::string text;
-};
-
-Src vreg(int n) {
-    Src s;
-    s.code = 256u + (uint32_t)n;
-    if (tlsWantText) s.text = "v" + std::to_string(n);
-    return s;
-}
-Src vreg64(int n) {
-    Src s;
-    s.code = 256u + (uint32_t)n;
-    if (tlsWantText) s.text = "v[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
-    return s;
-}
-Src sreg(int n) {
-    Src s;
-    s.code = (uint32_t)n;
-    if (tlsWantText) s.text = "s" + std::to_string(n);
-    return s;
-}
-Src sreg64(int n) {
-    Src s;
-    s.code = (uint32_t)n;
-    if (tlsWantText) s.text = "s[" + std::to_string(n) + ":" + std::to_string(n + 1) + "]";
-    return s;
-}
-Src named(uint32_t code, const char* text) {
-    Src s;
-    s.code = code;
-    if (tlsWantText) s.text = text;
-    return s;
-}
-
-struct InlineF { uint32_t bits; uint32_t code; const char* text; };
-const InlineF kInlineF32[] = {
-    {0x3f000000u, 240, "0.5"}, {0xbf000000u, 241, "-0.5"}, {0x3f800000u, 242, "1.0"},  {0xbf800000u, 243, "-1.0"},      {0x40000000u, 244, "2.0"},
-    {0xc0000000u, 245, "-2.0"}, {0x40800000u, 246, "4.0"},  {0xc0800000u, 247, "-4.0"}, {0x3e22f983u, 248, "0.15915494"},
-};
-struct InlineD { uint64_t bits; uint32_t code; const char* text; };
-const InlineD kInlineF64[] = {
-    {0x0000000000000000ull, 128, "0"},   {0x3fe0000000000000ull, 240, "0.5"}, {0xbfe0000000000000ull, 241, "-0.5"},
-    {0x3ff0000000000000ull, 242, "1.0"}, {0xbff0000000000000ull, 243, "-1.0"}, {0x4000000000000000ull, 244, "2.0"},
-    {0xc000000000000000ull, 245, "-2.0"}, {0x4010000000000000ull, 246, "4.0"},  {0xc010000000000000ull, 247, "-4.0"},
-};
-
-// a 32-bit value as a source operand: inline constant when the bit pattern has one, else a literal
-Src imm32(uint32_t bits, bool forceLiteral = false) {
-    Src s;
-    const int32_t iv = (int32_t)bits;
-    if (!forceLiteral) {
-        if (iv >= 0 && iv <= 64) { s.code = 128u + (uint32_t)iv; if (tlsWantText) s.text = std::to_string(iv); return s; }
-        if (iv >= -16 && iv <= -1) { s.code = 192u + (uint32_t)(-iv); if (tlsWantText) s.text = std::to_string(iv); return s; }
-        for (const InlineF& k : kInlineF32)
-            if (k.bits == bits) { s.code = k.code; if (tlsWantText) s.text = k.text; return s; }
-    }
-    s.code = 255;
-    s.lit = bits;
-    s.hasLit = true;
-    if (tlsWantText) {
-        char buf[16];
-        std::snprintf(buf, sizeof(buf), "0x%x", bits);
-        s.text = buf;
-    }
-    return s;
-}
-
-// ---- instruction emitter -----------------------------------------------------------------------------------
-class Emitter {
-    static constexpr uint32_t DS_READ2_B32_OP = 0x37, VOP2_ADDC_OP = 0x1c;
-
-  public:
-    Emitter(std::vector<uint32_t>* words, std::string* listing) : w_(*words), text_(listing) { tlsWantText = listing != nullptr; }
-
-    size_t bytes() const { return w_.size() * 4; }
-    int count() const { return count_; }
-    // vector-ALU instructions on the path a finite, in-domain wave takes every sample (cold(true) brackets code that
-    // such a wave does not execute: entry stubs, out-of-range paths, the second LUT trip)
-    int valu() const { return valu_; }
-    int valuSlow() const { return valuSlow_; }
-    int valuClocks() const { return (int)((valuClocksX100_ + 50) / 100); }
-    void cold(bool on) { coldDepth_ += on ? 1 : -1; cold_ = coldDepth_ > 0; }
-    // uniform constants kept in VGPRs for the whole launch (XlateProgram::vconst)
-    void constants(const std::vector<std::pair<uint32_t, int>>* pool) { pool_ = pool; }
-    int pooled(uint32_t bits) const {
-        if (pool_)
-            for (const auto& c : *pool_)
-                if (c.first == bits) return c.second;
-        return -1;
-    }
-    // the listing is kept as lines until the stream is complete (forward branches are patched in place)
-    void finish() {
-        if (!text_) return;
-        for (const std::string& l : lines_) { *text_ += l; *text_ += '\n'; }
-        lines_.clear();
-    }
-
-    // a SOPP branch whose target is not known yet; bind() fixes it to the then-current position
-    struct Fixup { size_t word = 0, lineNo = 0; std::string name; };
-    Fixup branchForward(uint32_t op, const char* name) {
-        Fixup f;
-        f.word = w_.size();
-        f.lineNo = lines_.size();
-        f.name = name;
-        w_.push_back(0xbf800000u | (op << 16));
-        ++count_;
-        if (text_) lines_.push_back(std::string(name) + " 0");
-        return f;
-    }
-    void bind(const Fixup& f) {
-        const size_t delta = w_.size() - (f.word + 1);
-        w_[f.word] = (w_[f.word] & 0xffff0000u) | (uint32_t)(delta & 0xffffu);
-        if (text_) lines_[f.lineNo] = f.name + " " + std::to_string(delta);
-    }
-    // branch to a position already emitted (word index inside this stream)
-    bool branchBack(uint32_t op, const char* name, size_t targetWord) {
-        const int64_t delta = (int64_t)targetWord - ((int64_t)w_.size() + 1);
-        if (delta < -32768) return false;
-        sopp(op, name, (uint32_t)delta & 0xffffu, true);
-        return true;
-    }
-    size_t words() const { return w_.size(); }
-    // a two-dword instruction given as its words and its listing line (SMEM loads)
-    void raw2(uint32_t w0, uint32_t w1, const std::string& text) {
-        w_.push_back(w0);
-        w_.push_back(w1);
-        ++count_;
-        if (text_) line(text);
-    }
-    // s_waitcnt vmcnt(n), the other counters left alone (n <= 63: bits 3:0 and 15:14)
-    void waitVmcnt(int n) {
-        if (n > 63) n = 63;
-        if (n < 0) n = 0;
-        w_.push_back(0xbf8c0000u | 0x0f70u | (uint32_t)(n & 15) | ((uint32_t)(n >> 4) << 14));
-        ++count_;
-        if (text_) line("s_waitcnt vmcnt(" + std::to_string(n) + ")");
-    }
-
-    void vop2(uint32_t op, const char* name, int vdst, const Src& src0, int vsrc1, const char* tail = "") {
-        tally(name);
-        put((op << 25) | ((uint32_t)vdst << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
-        if (text_) line(std::string(name) + " v" + std::to_string(vdst) + ", " + src0.text + ", v" + std::to_string(vsrc1) + tail);
-    }
-    void vop1(uint32_t op, const char* name, const Src& vdst, const Src& src0) {
-        tally(name);
-        put(0x7e000000u | ((vdst.code & 0xffu) << 17) | (op << 9) | src0.code, src0);
-        if (text_) line(std::string(name) + " " + vdst.text + ", " + src0.text);
-    }
-    void vopc(uint32_t op, const char* name, const Src& src0, int vsrc1) {
-        tally(name);
-        put(0x7c000000u | (op << 17) | ((uint32_t)vsrc1 << 9) | src0.code, src0);
-        if (text_) line(std::string(name) + " vcc, " + src0.text + ", v" + std::to_string(vsrc1));
-    }
-    // VOP3A: no literals on gfx9; neg = per-source negate bits
-    void vop3(uint32_t op, const char* name, const Src& vdst, const Src& s0, const Src& s1, const Src* s2, uint32_t neg = 0) {
-        tally(name);
-        w_.push_back(0xd0000000u | (op << 16) | (vdst.code & 0xffu));
-        w_.push_back(s0.code | (s1.code << 9) | ((s2 ? s2->code : 0u) << 18) | (neg << 29));
-        ++count_;
-        if (!text_) return;
-        std::string t = std::string(name) + " " + vdst.text + ", " + ((neg & 1) ? "-" : "") + s0.text + ", " + ((neg & 2) ? "-" : "") + s1.text;
-        if (s2) t += std::string(", ") + ((neg & 4) ? "-" : "") + s2->text;
-        line(t);
-    }
-    // VOPC in its VOP3 form, result to VCC, |src0| when abs0
-    void vop3cmp(uint32_t op, const char* name, const Src& s0, bool abs0, const Src& s1) {
-        tally(name);
-        w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | 106u);
-        w_.push_back(s0.code | (s1.code << 9));
-        ++count_;
-        if (text_) line(std::string(name) + " vcc, " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
-    }
-    void sop1(uint32_t op, const char* name, const Src& sdst, const Src& ssrc) {
-        put(0xbe800000u | ((sdst.code & 0x7fu) << 16) | (op << 8) | ssrc.code, ssrc);
-        if (text_) line(std::string(name) + " " + sdst.text + ", " + ssrc.text);
-    }
-    void sop1NoDst(uint32_t op, const char* name, const Src& ssrc) {
-        put(0xbe800000u | (op << 8) | ssrc.code, ssrc);
-        if (text_) line(std::string(name) + " " + ssrc.text);
-    }
-    void sop2(uint32_t op, const char* name, const Src& sdst, const Src& s0, const Src& s1) {
-        // at most one literal, which then follows the instruction word
-        const Src& l = s1.hasLit ? s1 : s0;
-        put(0x80000000u | (op << 23) | ((sdst.code & 0x7fu) << 16) | (s1.code << 8) | s0.code, l);
-        if (text_) line(std::string(name) + " " + sdst.text + ", " + s0.text + ", " + s1.text);
-    }
-    // global_{load,store}_dword with an SGPR base pair and a VGPR byte offset, no immediate offset
-    void global(uint32_t op, bool load, int vdata, int vaddr, int sbase, bool nt = false) {
-        w_.push_back(0xdc008000u | (op << 18) | (nt ? 1u << 17 : 0u));  // (offset field 0)
-        w_.push_back((uint32_t)vaddr | (load ? 0u : (uint32_t)vdata << 8) | ((uint32_t)sbase << 16) | (load ? (uint32_t)vdata << 24 : 0u));
-        ++count_;
-        const std::string base = "s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]";
-        if (!text_) return;
-        if (load) line("global_load_dword v" + std::to_string(vdata) + ", v" + std::to_string(vaddr) + ", " + base + (nt ? " nt" : ""));
-        else line("global_store_dword v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + ", " + base + (nt ? " nt" : ""));
-    }
-    void waitVmcnt0() { waitVmcnt(0); }
-    // global_load_dwordx2 / x4 into v[vdata ..], VGPR byte offset, SGPR base pair
-    void globalLoadWide(uint32_t op, int dwords, int vdata, int vaddr, int sbase) {
-        w_.push_back(0xdc008000u | (op << 18));
-        w_.push_back((uint32_t)vaddr | ((uint32_t)sbase << 16) | ((uint32_t)vdata << 24));
-        ++count_;
-        if (text_) line("global_load_dwordx" + std::to_string(dwords) + " v[" + std::to_string(vdata) + ":" + std::to_string(vdata + dwords - 1) + "], v" +
-             std::to_string(vaddr) + ", s[" + std::to_string(sbase) + ":" + std::to_string(sbase + 1) + "]");
-    }
-    // LDS: reads return into v[vdst..], byte offset in the instruction (read2: two dword offsets)
-    void dsRead(uint32_t op, const char* name, int dwords, int vdst, int vaddr, uint32_t offset) {
-        w_.push_back(0xd8000000u | (op << 17) | (offset & 0xffffu));
-        w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
-        ++count_;
-        if (text_) line(std::string(name) + " v[" + std::to_string(vdst) + ":" + std::to_string(vdst + dwords - 1) + "], v" + std::to_string(vaddr) +
-             (offset ? " offset:" + std::to_string(offset) : ""));
-    }
-    void dsRead2B32(int vdst, int vaddr, uint32_t dword0, uint32_t dword1) {
-        w_.push_back(0xd8000000u | (DS_READ2_B32_OP << 17) | (dword1 << 8) | dword0);
-        w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
-        ++count_;
-        if (text_) line("ds_read2_b32 v[" + std::to_string(vdst) + ":" + std::to_string(vdst + 1) + "], v" + std::to_string(vaddr) +
-             (dword0 ? " offset0:" + std::to_string(dword0) : "") + " offset1:" + std::to_string(dword1));
-    }
-    void dsWrite2B32(int vaddr, int vdata0, int vdata1, uint32_t dword0, uint32_t dword1) {
-        w_.push_back(0xd8000000u | (0x0eu << 17) | (dword1 << 8) | dword0);
-        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata0 << 8) | ((uint32_t)vdata1 << 16));
-        ++count_;
-        if (text_) line("ds_write2_b32 v" + std::to_string(vaddr) + ", v" + std::to_string(vdata0) + ", v" + std::to_string(vdata1) +
-             (dword0 ? " offset0:" + std::to_string(dword0) : "") + " offset1:" + std::to_string(dword1));
-    }
-    void dsReadB32(int vdst, int vaddr, uint32_t offset) {
-        w_.push_back(0xd8000000u | (0x36u << 17) | (offset & 0xffffu));
-        w_.push_back((uint32_t)vaddr | ((uint32_t)vdst << 24));
-        ++count_;
-        if (text_) line("ds_read_b32 v" + std::to_string(vdst) + ", v" + std::to_string(vaddr) + (offset ? " offset:" + std::to_string(offset) : ""));
-    }
-    void dsWriteB32(int vaddr, int vdata, uint32_t offset) {
-        w_.push_back(0xd8000000u | (0x0du << 17) | (offset & 0xffffu));
-        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
-        ++count_;
-        if (text_) line("ds_write_b32 v" + std::to_string(vaddr) + ", v" + std::to_string(vdata) + (offset ? " offset:" + std::to_string(offset) : ""));
-    }
-    void barrier() { sopp(0x0au, "s_barrier", 0, false); }
-    void dsWriteB128(int vaddr, int vdata, uint32_t offset) {
-        w_.push_back(0xd8000000u | (0xdfu << 17) | (offset & 0xffffu));
-        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
-        ++count_;
-        if (text_) line("ds_write_b128 v" + std::to_string(vaddr) + ", v[" + std::to_string(vdata) + ":" + std::to_string(vdata + 3) + "]" +
-             (offset ? " offset:" + std::to_string(offset) : ""));
-    }
-    void dsWriteB64(int vaddr, int vdata, uint32_t offset) {
-        w_.push_back(0xd8000000u | (0x4du << 17) | (offset & 0xffffu));
-        w_.push_back((uint32_t)vaddr | ((uint32_t)vdata << 8));
-        ++count_;
-        if (text_) line("ds_write_b64 v" + std::to_string(vaddr) + ", v[" + std::to_string(vdata) + ":" + std::to_string(vdata + 1) + "]" +
-                        (offset ? " offset:" + std::to_string(offset) : ""));
-    }
-    // v = v + carry (VCC in and out)
-    void addCarry(int v) {
-        tally("v_addc_co_u32");
-        w_.push_back((VOP2_ADDC_OP << 25) | ((uint32_t)v << 17) | ((uint32_t)v << 9) | 128u);
-        ++count_;
-        if (text_) line("v_addc_co_u32_e32 v" + std::to_string(v) + ", vcc, 0, v" + std::to_string(v) + ", vcc");
-    }
-    // v = v - borrow, borrow in from the SGPR pair `sin`, borrow out to the pair `sout`
-    void subBorrow(int v, int sin, int sout) {
-        tally("v_subbrev_co_u32");
-        w_.push_back(0xd0000000u | (0x11eu << 16) | ((uint32_t)sout << 8) | (uint32_t)v);
-        w_.push_back(128u | ((256u + (uint32_t)v) << 9) | ((uint32_t)sin << 18));
-        ++count_;
-        if (text_) line("v_subbrev_co_u32_e64 v" + std::to_string(v) + ", s[" + std::to_string(sout) + ":" + std::to_string(sout + 1) + "], 0, v" +
-                        std::to_string(v) + ", s[" + std::to_string(sin) + ":" + std::to_string(sin + 1) + "]");
-    }
-    // VGPR index mode on: M0 = s<n>, mode 1 = src0 relative (SOPC encoding, the mode nibble in the src1 field)
-    void setGprIdxOn(int sreg, uint32_t mode) {
-        w_.push_back(0xbf000000u | (0x11u << 16) | (mode << 8) | (uint32_t)sreg);
-        ++count_;
-        if (text_) line("s_set_gpr_idx_on s" + std::to_string(sreg) + ", gpr_idx(" + (mode == 1u ? "SRC0" : mode == 2u ? "SRC1" : "DST") + ")");
-    }
-    // s_memrealtime s[sdata:sdata+1] (the 100 MHz clock; diagnostics)
-    void memRealTime(int sdata) {
-        w_.push_back(0xc0000000u | (0x25u << 18) | ((uint32_t)sdata << 6));
-        w_.push_back(0u);
-        ++count_;
-        if (text_) line("s_memrealtime s[" + std::to_string(sdata) + ":" + std::to_string(sdata + 1) + "]");
-    }
-    void waitLgkm0() { waitLgkm(0); }
-    // s_waitcnt lgkmcnt(n), the other counters left alone (n <= 15: bits 11:8)
-    void waitLgkm(int n) {
-        if (n > 15) n = 15;
-        w_.push_back(0xbf8cc07fu | ((uint32_t)n << 8));
-        ++count_;
-        if (text_) line("s_waitcnt lgkmcnt(" + std::to_string(n) + ")");
-    }
-    // VOPC in its VOP3 form: destination VCC or an SGPR pair, optional |src0|
-    void vop3cmpG(uint32_t op, const char* name, const Src& sdst, const Src& s0, bool abs0, const Src& s1) {
-        tally(name);
-        w_.push_back(0xd0000000u | (op << 16) | (abs0 ? 0x100u : 0u) | (sdst.code & 0xffu));
-        w_.push_back(s0.code | (s1.code << 9));
-        ++count_;
-        if (text_) line(std::string(name) + " " + sdst.text + ", " + (abs0 ? "|" + s0.text + "|" : s0.text) + ", " + s1.text);
-    }
-    // VOPC in its VOP3 form with an SGPR-pair destination
-    void vop3cmpTo(uint32_t op, const char* name, int sdst, const Src& s0, const Src& s1) {
-        tally(name);
-        w_.push_back(0xd0000000u | (op << 16) | (uint32_t)sdst);
-        w_.push_back(s0.code | (s1.code << 9));
-        ++count_;
-        if (text_) line(std::string(name) + " s[" + std::to_string(sdst) + ":" + std::to_string(sdst + 1) + "], " + s0.text + ", " + s1.text);
-    }
-    void sopc(uint32_t op, const char* name, const Src& s0, const Src& s1) {
-        w_.push_back(0xbf000000u | (op << 16) | (s1.code << 8) | s0.code);
-        if (s1.hasLit) w_.push_back(s1.lit);
-        else if (s0.hasLit) w_.push_back(s0.lit);
-        ++count_;
-        if (text_) line(std::string(name) + " " + s0.text + ", " + s1.text);
-    }
-    // SOPK with an SGPR destination (s_getreg_b32: simm16 = {size - 1, offset, register id})
-    void sopk(uint32_t op, const char* name, int sdst, uint32_t simm, const std::string& operandText) {
-        w_.push_back(0xb0000000u | (op << 23) | ((uint32_t)sdst << 16) | (simm & 0xffffu));
-        ++count_;
-        if (text_) line(std::string(name) + " s" + std::to_string(sdst) + ", " + operandText);
-    }
-    void sopp(uint32_t op, const char* name, uint32_t simm, bool showImm, const std::string& text = std::string()) {
-        w_.push_back(0xbf800000u | (op << 16) | (simm & 0xffffu));
-        ++count_;
-        if (text_) line(!text.empty() ? text : (showImm ? std::string(name) + " " + std::to_string(simm) : std::string(name)));
-    }
-
-  private:
-    void put(uint32_t word, const Src& maybeLit) {
-        w_.push_back(word);
-        if (maybeLit.hasLit) w_.push_back(maybeLit.lit);
-        ++count_;
-    }
-    void line(const std::string& t) {
-        if (text_) lines_.push_back(t);
-    }
-    bool listing() const { return text_ != nullptr; }
-    std::vector<uint32_t>& w_;
-    std::string* text_;
-    std::vector<std::string> lines_;
-    int count_ = 0, valu_ = 0, valuSlow_ = 0;
-    long valuClocksX100_ = 0;
-    bool cold_ = false;
-    int coldDepth_ = 0;
-    const std::vector<std::pair<uint32_t, int>>* pool_ = nullptr;
-    // Issue cost of a wave64 VALU instruction on a busy SIMD, in clocks x 100.  Measured on MI355X as the time an instruction
-    // adds to a realistic mix at four waves per SIMD (tools/micro/mix_cost.hip; the homogeneous loops of valu_rate.hip
-    // bound it from above) and scaled so that the table reproduces that mix's own time (12 instructions in 14.8 ns at
-    // 2.35 GHz): plain fp32 add / sub / mul, moves, 32-bit integer add / sub / and / or / xor 2.05; v_fma_f32 2.4;
-    // v_med3 / min / max 2.6; conversions to and from fp64 and all fp64 arithmetic 4.25; everything else (compares,
-    // integer conversions, left shifts, selects, carries) 3.95.
-    static bool startsWith(const char* name, const char* prefix) { return std::strncmp(name, prefix, std::strlen(prefix)) == 0; }
-    static int issueCost(const char* name) {
-        static const char* const fast[] = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32",
-                                           "v_or_b32", "v_xor_b32", "v_lshrrev_b32"};
-        for (const char* f : fast)
-            if (startsWith(name, f)) return 205;
-        if (startsWith(name, "v_fma_f32")) return 240;
-        if (startsWith(name, "v_med3_f32") || startsWith(name, "v_max_f32") || startsWith(name, "v_min_f32")) return 260;
-        if (std::strstr(name, "f64")) return 425;
-        return 395;
-    }
-    void tally(const char* name) {
-        if (cold_) return;
-        ++valu_;
-        const int cost = issueCost(name);
-        if (cost > 300) ++valuSlow_;
-        valuClocksX100_ += cost;
-    }
-};
-
-// gfx950 opcodes used (checked against llvm-mc by tests/test_xlate.py, which re-assembles the listing)
-enum : uint32_t {
-    VOP2_CNDMASK = 0, VOP2_ADD_F32 = 1, VOP2_SUB_F32 = 2, VOP2_SUBREV_F32 = 3, VOP2_MUL_F32 = 5, VOP2_MAX_I32 = 0x0d, VOP2_ADD_U32 = 0x34,
-    VOP1_MOV = 1, VOP1_CVT_F32_F64 = 0x0f, VOP1_CVT_F64_F32 = 0x10,
-    VOPC_CMP_U_F32 = 0x48, VOPC_CMP_EQ_U32 = 0xca, VOPC_CMP_NE_U32 = 0xcd, VOPC_CMP_LE_U32 = 0xcb, VOPC_CMP_LE_F32 = 0x43, VOPC_CMP_GT_U32 = 0xcc,
-    SOPC_CMP_LG_U64 = 0x13, SOPP_CBRANCH_SCC1 = 5, SOPP_CBRANCH_VCCZ = 6, SOPP_CBRANCH_VCCNZ = 7,
-    SOP2_ADD_I32 = 2, SOP2_SUB_I32 = 3, SOP2_MIN_I32 = 6, SOP2_MIN_U32 = 7, SOP2_CSELECT_B32 = 0x0a, SOP2_OR_B32 = 0x0e, SOP2_OR_B64 = 0x0f, SOP2_LSHL_B32 = 0x1c, SOP2_LSHR_B32 = 0x1e,
-    SOPC_CMP_GT_I32 = 2, SOPC_CMP_GE_I32 = 3, SOPC_CMP_LT_I32 = 4, SOPC_CMP_EQ_U32 = 6, SOPC_CMP_GE_U32 = 9, SOPC_CMP_LT_U32 = 0x0a, SOP2_MUL_I32 = 0x24, SOPP_BRANCH = 2, SOPP_CBRANCH_SCC0 = 4, SOPP_WAITCNT = 0x0c,
-    VOP3_CMP_NLE_F32 = 0x4c, VOP1_READFIRSTLANE = 2,
-    VOP1_CVT_F32_U32 = 6, VOPC_CMP_LT_F32 = 0x41, VOPC_CMP_EQ_F32 = 0x42, VOPC_CMP_GT_F32 = 0x44, VOP3_CMP_EQ_F32 = 0x42, VOP3_CMP_GT_F32 = 0x44,
-    SOP2_AND_B32 = 0x0c, SOP2_AND_B64 = 0x0d, SOP2_ANDN2_B64 = 0x13,
-    VOP2_ADDC_CO_U32 = 0x1c, VOP3B_SUBBREV_CO_U32 = 0x11e,
-    VOP1_CVT_I32_F32 = 8, VOP2_LSHLREV_B32 = 0x12, VOP2_SUB_U32 = 0x35, VOP3_MED3_I32 = 0x1d7, VOPC_CMP_GE_F32 = 0x46, VOPC_CMP_NGE_F32 = 0x49, VOPC_CMP_NGT_F32 = 0x4b, VOPC_CMP_NLE_F32 = 0x4c,
-    VOP3_CMP_LT_F32 = 0x41, VOP3_CMP_NLT_F32 = 0x4e, GLOBAL_LOAD_DWORDX2 = 0x15, GLOBAL_LOAD_DWORDX4 = 0x17, DS_READ_B64 = 0x76, DS_READ_B128 = 0xff, VOP2_OR_B32 = 0x14, VOP2_AND_B32 = 0x13, VOP2_XOR_B32 = 0x15, VOP2_LSHRREV_B32 = 0x10, VOPC_CMP_CLASS_F32 = 0x10, GLOBAL_LOAD_DWORD = 0x14, GLOBAL_STORE_DWORD = 0x1c,
-    VOP3_CNDMASK = 0x100, VOP3_MED3_F32 = 0x1d6, VOP3_FMA_F32 = 0x1cb, VOP3_FMA_F64 = 0x1cc, VOP3_ADD_F64 = 0x280, VOP3_MUL_F64 = 0x281,
-    SOP1_MOV_B32 = 0, SOP1_MOV_B64 = 1, SOP1_SETPC = 0x1d, SOP1_FLBIT_I32_B32 = 0x12, SOP2_MAX_I32 = 8,
-    SOP2_ADD_U32 = 0, SOP2_SUB_U32 = 1, SOP2_ADDC_U32 = 4,
-    SOPP_NOP = 0, SOPP_IDX_OFF = 0x1c,
-    VOP2_ASHRREV_I32 = 0x11, VOP1_FLOOR_F32 = 0x1f, VOP1_CVT_F32_I32 = 5, VOPC_CMP_EQ_U32_ = 0xca, VOPC_CMP_GT_I32 = 0xc4,
-};
-
-// register conventions shared with fx_interp_gfx950.S
-constexpr int kRegFileBase = 32;  // v32 = row 0
-constexpr int kVNumSkip = 14, kVShadowCount = 15;
-constexpr int kSRecord = 16;      // s16.. = record window of handler set _a: s18..s23 = w2..w7
-constexpr int kSReturn = 24;      // s[24:25] = where a handler of set _a continues
-constexpr int kSEntry = 32;       // s[32:33] = address of the kernel entry
-constexpr int kSEndSample = 34;   // s[34:35] = end-of-sample frame
-constexpr int kSTemp = 62;        // s[62:63] scratch of the handlers, free between them
-constexpr int kSTaint = 78;       // s[78:79] lanes that hold a non-finite value (template prologue)
-constexpr int kVLane4 = 1;        // v1 = lane * 4
-constexpr int kVClassMask = 29;   // v29 = v_cmp_class mask of NaN and +-Inf
-constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane
-constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read
-constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
-constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
-// LUT tables in LDS, every array indexed by segment * 8 bytes (ds_read_b64: at most two lanes of a 32-lane group share
-// a bank): {xthr[g], xthr[g+1]} fp32 pairs | x1[64] fp64 | per table slope[64] fp64, y1[64] fp64
-constexpr uint32_t kLdsThr = 0, kLdsX1 = 512, kLdsTables = 1024, kLdsTableBytes = 1024;
-constexpr int kSLut = 40;          // s[40:41] = LUT blob
-constexpr int kSLutXthr = 88, kSLutX1 = 90, kSLutSeg = 92;  // s[88:93]: bases of the fp32 thresholds, x1[] and the current table's segments
-constexpr int kSTramBase[2] = {36, 38}, kSTramSize[2] = {56, 57}, kSTramSlots[2] = {46, 47};  // [iTRAM, xTRAM]
-// the sample loop (frame registers of fx_interp_gfx950.S)
-constexpr int kSSample = 3, kSNumSamples = 9;       // sample index, block length
-constexpr int kSPcmIn = 12, kSPcmOut = 14;          // s[12:13] / s[14:15]: PCM in / out of the current sample
-constexpr int kSSampleBytes = 45, kSChannelBytes = 68;  // bytes per sample (channels * N * 4) and per channel-sample (N * 4)
-constexpr int kSValidLanes = 58;                    // s[58:59]: lanes that hold an instance
-constexpr int kVInput = 23;                         // v23..v26: PCM input of the current sample, channel 0..3 (requested one sample ahead)
-constexpr int kVInstance4 = 27;                     // v27 = instance * 4: byte offset into a PCM / state row
-constexpr int kSPrefetched = 94;                    // s94 = 1: the leading TRAM reads of this sample are already in flight
-constexpr int kSEventNext = 28;                         // control tracks: the sample at which the next event of the block's list is due (0xFFFFFFFF: none left)
-constexpr int kSEventPtr = 26;                          // s[26:27]: address of that event's record (fx_xlate.hpp TrackEvent)
-constexpr int kKernargTracks = 0xb8;                    // AsmArgs.tracks (fx_asm.hpp)
-constexpr int kSSliceShift = 8;                        // unstaged programs with time-sliced priorities: log2 of a slice in 100 MHz ticks (emitInit)
-constexpr int kSHoistOk = 95;                       // s95 = 1: this launch may issue leading TRAM reads one sample ahead (emitInit)
-constexpr int kVRing = 30;                          // staged programs: lane * 4 + the LDS buffer of this sample's packets (sent and requested, see stageRequest)
-// staged programs (s4..s8 are the template's dispatch scratch and the interpreter's fetch offset: free in generated code)
-// A steady stream: s7 counts down to the next event - the group's barrier or the end of the steady stream - from s5 - 1; when it
-// borrows, s8 (samples left in the group) and s6 (steady samples left) both go down by s5 and whichever reached 0 is served.
-// A last-sample stream: s7 = samples of the group still to come after this one (the barrier follows when it borrows).
-constexpr int kSGroupLeft = 7;
-constexpr int kSSteadyLeft = 6;
-constexpr int kSLoaded = 5, kSGroupSamples = 8;
-
-int32_t danePosition(uint32_t bits, bool shifted, int32_t size);  // (defined with the hoist planning below)
 
 // the four VGPR constants of the quick LOG/EXP index guess (Translator::lut)
 struct LutGuessConstants {
@@ -547,10 +28,6 @@ struct LutGuessConstants {
     bool available(const Emitter& e) const { return e.pooled(scale) >= 0 && e.pooled(bias) >= 0 && e.pooled(magic) >= 0 && e.pooled(mask) >= 0; }
 };
 const LutGuessConstants kLutGuess;
-
-// (defined with the stage planner below) register-file rows a record reads and writes
-struct Access { uint32_t reads[3]; int nReads = 0; int write = -1; bool ccr = false, tram = false, noise = false; };
-Access accessOf(const MicroOp& r);
 
 class Translator {
   public:
@@ -2632,45 +2109,6 @@ class Translator {
 
 }  // namespace
 
-const XlateTemplate* xlateTemplate(AsmVariant variant, std::string* err) {
-    if (variant <= ASM_LDS || variant >= ASM_VARIANTS) {
-        if (err) *err = "no translation template for this build";
-        return nullptr;
-    }
-    std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_parsed[variant]) {
-        g_parsed[variant] = true;
-        const BlobRef& b = kBlobs[variant];
-        XlateTemplate t;
-        t.image = b.p;
-        t.imageBytes = b.n;
-        t.kernelName = b.kernel;
-        t.vgprs = b.vgprs;
-        const SymbolAt kn = findSymbol(b.p, b.n, t.kernelName);
-        const SymbolAt tab = findSymbol(b.p, b.n, t.kernelName + "_table");
-        const SymbolAt hole = findSymbol(b.p, b.n, t.kernelName + "_hole");
-        if (!kn.found || !tab.found || !hole.found || tab.fileOff + (kAsmSlots + 2) * 4 > b.n) {
-            g_parseErr[variant] = "translation template " + t.kernelName + ": symbols not found in the code object";
-        } else {
-            uint32_t table[kAsmSlots + 2];
-            std::memcpy(table, b.p + tab.fileOff, sizeof(table));
-            std::memcpy(t.handlerOff, table, sizeof(t.handlerOff));
-            t.holeOff = table[kAsmSlots];
-            t.holeBytes = table[kAsmSlots + 1];
-            t.holeFileOff = hole.fileOff;
-            if ((uint64_t)t.holeOff != hole.value - kn.value || t.holeFileOff + t.holeBytes > b.n || (t.holeBytes & 3u))
-                g_parseErr[variant] = "translation template " + t.kernelName + ": inconsistent hole";
-            else
-                g_templates[variant] = t;
-        }
-    }
-    if (!g_parseErr[variant].empty()) {
-        if (err) *err = g_parseErr[variant];
-        return nullptr;
-    }
-    return &g_templates[variant];
-}
-
 bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& tmpl, const XlateProgram& prog, uint32_t codeBase,
                      bool isLast, uint32_t nextBase, const std::vector<uint32_t>* exactReturns, std::vector<uint32_t>* code,
                      std::string* listing, XlateStats* stats, std::vector<uint32_t>* returns, uint32_t* coldEntry, std::string* err) {
@@ -2679,14 +2117,11 @@ bool translateStream(const std::vector<MicroOp>& records, const XlateTemplate& t
     return t.run(records, stats, returns, coldEntry, err);
 }
 
-namespace {
-inline uint32_t align64(uint32_t v) { return (v + 63u) & ~63u; }
-
 // Run-once code (one wavefront = one workgroup; entered from the template with the TRAM cursors in v16..v19 and
 // s95 = 0, returns through s[24:25]):
 //  * the LOG/EXP tables the program uses -> LDS, lane g writing segment g of every array (layout: kLds*);
 //  * s95 = 1 when this launch may issue its leading TRAM reads one sample ahead (HoistPlan).
-void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string* listing, int sliceBias = -1) {
+void xl::emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string* listing, int sliceBias) {
     Emitter e(code, listing);
     if (sliceBias >= 0) {
         // time-sliced priorities (Translator::run): a slice of 2^shift ticks of the 100 MHz clock is about 1/24 of the block -
@@ -2745,7 +2180,6 @@ void emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::string
     e.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSReturn));
     e.finish();
 }
-}
 
 namespace {
 int32_t truncX86(uint32_t bits) {  // cvttss2si: 0x80000000 for NaN and anything outside int32
@@ -2755,9 +2189,11 @@ int32_t truncX86(uint32_t bits) {  // cvttss2si: 0x80000000 for NaN and anything
     return (int32_t)f;
 }
 
+}  // namespace
+
 // tap position of the opt-in DANE model from a uniform operand: whole samples, or a DANE address fraction (value * 2^31,
 // 0x800 per sample); reduced to 0 .. size-1
-int32_t danePosition(uint32_t bits, bool shifted, int32_t size) {
+int32_t xl::danePosition(uint32_t bits, bool shifted, int32_t size) {
     int64_t q;
     if (shifted) {
         float f;
@@ -2774,6 +2210,7 @@ int32_t danePosition(uint32_t bits, bool shifted, int32_t size) {
     return (int32_t)(q < 0 ? q + size : q);
 }
 
+namespace {
 // Which TRAM reads can be issued one sample ahead, where, and for which cursor distances that is unsafe (fx_xlate.hpp HoistPlan)
 HoistPlan planHoist(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, const XlateProgram& p) {
     HoistPlan H;
@@ -3096,547 +2533,6 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
         if (err) *err = "translated program larger than the code hole of the template";
         return false;
     }
-    return true;
-}
-
-// ---- stage pipelining (fx_xlate.hpp StageInfo) ---------------------------------------------------------------------
-namespace {
-// register-file rows a record reads and writes (uniform operands are not rows; the X word of LOG / EXP is a table)
-Access accessOf(const MicroOp& r) {
-    Access a;
-    const uint32_t slot = r.w[0];
-    if (slot == AS_ENDSAMPLE || slot == AS_NOP || slot == AS_PRED || slot == AS_UNPRED) return a;
-    const bool hot = slot >= AS_MACS && slot < (uint32_t)kAsmSlots;
-    const uint32_t kind = hot ? ((slot - AS_MACS) % 16) / 2 : (r.w[6] & 7u);
-    auto read = [&](uint32_t word, bool uniform) { if (!uniform) a.reads[a.nReads++] = word; };
-    if (slot == AS_SKIP) {
-        a.reads[a.nReads++] = 0;  // the CCR row
-        read(r.w[3], kind & 2u);
-        read(r.w[4], kind & 4u);
-        return a;
-    }
-    if (slot == AS_NOISE) { a.noise = true; a.write = (int)r.w[5]; return a; }
-    if (slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) {
-        a.tram = true;
-        read(r.w[4], kind & 4u);
-        if (slot == AS_TRAM_IR || slot == AS_TRAM_XR) a.write = (int)r.w[5];
-        else read(r.w[2], kind & 1u);
-        return a;
-    }
-    if (hot && kind == 7u) { a.write = (int)r.w[5]; a.ccr = (slot - AS_MACS) & 1u; return a; }  // folded on the host
-    read(r.w[2], kind & 1u);
-    if (slot == AS_LUT) read(r.w[3], kind & 2u);   // (the table number: a row when it is a per-instance value)
-    else if (slot != AS_MOV) {
-        read(r.w[3], kind & 2u);
-        read(r.w[4], kind & 4u);
-    }
-    a.write = (int)r.w[5];
-    a.ccr = hot ? ((slot - AS_MACS) & 1u) != 0 : ((r.w[6] >> 3) & 1u) != 0;
-    return a;
-}
-// a rough count of the vector instructions a record costs (for balancing the stages only)
-int costOf(const MicroOp& r) {
-    const uint32_t slot = r.w[0];
-    if (slot == AS_ENDSAMPLE || slot == AS_NOP || slot == AS_UNPRED) return 0;
-    if (slot == AS_PRED) return 6;
-    if (slot == AS_SKIP) return 3;
-    if (slot == AS_MOV) return 1;
-    if (slot == AS_LUT) return 16;
-    if (slot == AS_NOISE || slot == AS_LIMIT || slot == AS_LIMITN) return 4;
-    if (slot >= AS_TRAM_IR && slot <= AS_TRAM_XW) return 2;
-    if (slot < AS_MACS) return 12;  // wrap-around family, logic, TSTNEG
-    const uint32_t rel = slot - AS_MACS, family = rel / 16;
-    return (family == 3 ? 7 : 3) + ((rel & 1u) ? 12 : 0);
-}
-}  // namespace
-
-namespace {
-bool verifyStagePlan(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, size_t n, const XlateProgram& prog, int rows, const StagePlan& P, std::string* why);
-}
-
-StagePlan planStages(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateProgram& prog, int nRows, int wanted) {
-    StagePlan P;
-    auto no = [&](const std::string& why) { P.why = why; P.cuts.clear(); P.live.clear(); return P; };
-    if (wanted < 2) return no("one stage asked for");
-    if (!prog.trackRows.empty()) return no("control tracks");
-    if (prog.tramDane) return no("DANE delay-line model");
-    if (steadyRecords.size() != lastRecords.size()) return no("streams of different length");
-    size_t n = 0;
-    while (n < steadyRecords.size() && steadyRecords[n].w[0] != AS_ENDSAMPLE) ++n;
-    if (n < 4 || n >= steadyRecords.size() || lastRecords[n].w[0] != AS_ENDSAMPLE) return no("too short");
-    auto shape = [](const MicroOp& r) { return r.w[0] >= AS_MACS && r.w[0] < (uint32_t)kAsmSlots ? (r.w[0] & ~1u) : r.w[0]; };  // (hot slots: without the CCR bit)
-    for (size_t i = 0; i < n; ++i)
-        if (shape(steadyRecords[i]) != shape(lastRecords[i]) || steadyRecords[i].w[5] != lastRecords[i].w[5]) return no("streams differ in structure");
-    const int rows = std::max(nRows, 1);
-    // boundary b (1 .. n-1) = a cut between record b-1 and record b
-    std::vector<uint8_t> allowed(n + 1, 1);
-    allowed[0] = 0;
-    allowed[n] = 0;
-    std::vector<std::vector<int>> liveAt(n + 1);
-    auto forbid = [&](size_t lo, size_t hi) {  // no cut b with lo < b <= hi
-        for (size_t b = lo + 1; b <= hi && b <= n; ++b) allowed[b] = 0;
-    };
-    auto addLive = [&](size_t lo, size_t hi, int row) {  // row is live at every cut b with lo < b <= hi
-        for (size_t b = lo + 1; b <= hi && b <= n; ++b)
-            if (std::find(liveAt[b].begin(), liveAt[b].end(), row) == liveAt[b].end()) liveAt[b].push_back(row);
-    };
-    // structure: a SKIP, the instruction in front of it (fused predicate) and its shadow up to the UNPRED stay together;
-    // delay-line and noise instructions belong to stage 0
-    {
-        bool open = false;
-        size_t from = 0, lastOwned = 0;
-        bool anyOwned = false;
-        for (size_t i = 0; i < n; ++i) {
-            const uint32_t slot = steadyRecords[i].w[0];
-            if (slot == AS_SKIP && !open) { open = true; from = i > 0 ? i - 1 : 0; }
-            if (slot == AS_PRED && !open) { open = true; from = i > 0 ? i - 1 : 0; }
-            if (slot == AS_UNPRED && open) { forbid(from, i); open = false; }
-            const Access a = accessOf(steadyRecords[i]);
-            if (a.tram || a.noise) { lastOwned = i; anyOwned = true; }
-        }
-        if (open) forbid(from, n);
-        if (anyOwned) forbid(0, lastOwned + 1 > n ? n : lastOwned + 1);
-    }
-    std::vector<uint8_t> isInput((size_t)rows, 0);
-    for (int r : prog.inRows)
-        if (r >= 0 && r < rows) isInput[(size_t)r] = 1;
-    for (const std::vector<MicroOp>* recs : {&steadyRecords, &lastRecords}) {
-        // per row: its writes (position, conditional?) in program order
-        std::vector<std::vector<std::pair<size_t, bool>>> writes((size_t)rows);
-        bool shadow = false;
-        std::vector<uint8_t> shadowed(n, 0);
-        for (size_t i = 0; i < n; ++i) {
-            const uint32_t slot = (*recs)[i].w[0];
-            if (slot == AS_PRED) shadow = true;
-            else if (slot == AS_UNPRED) shadow = false;
-            shadowed[i] = shadow;
-            const Access a = accessOf((*recs)[i]);
-            if (a.write >= 0 && a.write < rows) writes[(size_t)a.write].emplace_back(i, shadow);
-            if (a.ccr) writes[0].emplace_back(i, shadow);
-        }
-        for (size_t i = 0; i < n; ++i) {
-            const Access a = accessOf((*recs)[i]);
-            for (int k = 0; k < a.nReads; ++k) {
-                const uint32_t R = a.reads[k];
-                if (R >= (uint32_t)rows) return no("operand row out of range");
-                if (isInput[R]) { addLive(0, i, (int)R); continue; }  // stage 0 loads the PCM input; it travels with the packets
-                const auto& W = writes[R];
-                // walk back from the read: conditional writes, down to the nearest unconditional one
-                size_t lowest = i;  // the earliest position the value can come from (same sample)
-                bool found = false;
-                for (size_t q = W.size(); q-- > 0;) {
-                    if (W[q].first >= i) continue;
-                    lowest = W[q].first;
-                    if (!W[q].second) { found = true; break; }
-                }
-                if (found) { addLive(lowest, i, (int)R); continue; }
-                // ... the value (also) comes from the previous sample: every candidate definition - the conditional ones of
-                // this sample, and the previous sample's from the end of the program back to its last unconditional one -
-                // must be in the reader's stage
-                size_t highest = i;
-                for (size_t q = W.size(); q-- > 0;) {
-                    if (W[q].first < i) break;
-                    highest = std::max(highest, W[q].first);
-                    if (!W[q].second) break;
-                }
-                if (!W.empty()) {
-                    size_t top = i;
-                    for (const auto& w : W)
-                        if (w.first >= i) top = std::max(top, w.first);
-                    highest = top;  // (conservative: up to the last write of the row)
-                }
-                forbid(lowest, i);
-                forbid(i, highest);
-            }
-        }
-        // the stage of a row's LAST write stores it (state rows at the end of a block, PCM latch rows every sample): if that
-        // write is conditional the stage needs the value it replaces - from the nearest unconditional write in front of it, or,
-        // when there is none in the sample, from the previous sample: then all writes of the row stay in one stage
-        for (int R = 0; R < rows; ++R) {
-            const auto& W = writes[(size_t)R];
-            if (W.size() < 2 || !W.back().second) continue;
-            size_t q = W.size() - 1;
-            while (q > 0 && W[q].second) --q;
-            if (W[q].second) forbid(W.front().first, W.back().first);
-            else addLive(W[q].first, W.back().first, R);
-        }
-    }
-    // balance: cumulative cost, cuts at allowed boundaries nearest to the ideal positions
-    std::vector<int> cum(n + 1, 0);
-    for (size_t i = 0; i < n; ++i) cum[i + 1] = cum[i] + costOf(steadyRecords[i]);
-    const int total = cum[n];
-    if (total < 16 * wanted) wanted = std::max(1, total / 16);
-    if (wanted < 2) return no("too little work per stage");
-    // The slowest stage sets the pace of the whole workgroup (everybody meets at the step's barrier), and a stage's time is its
-    // share of the program PLUS what the pipeline costs it: stage 0 fetches the PCM input (ring of bursts, index mode), the last
-    // writer of an output latch stores PCM, every row received costs a move and a request, every row sent a write.  Cuts = the allowed boundaries that minimise the largest such sum (dynamic programme over boundaries; a
-    // stage with less than a quarter of an even share of the program is not worth a barrier: fewer stages then).
-    bool anyInputRow = false;
-    for (int r : prog.inRows) anyInputRow = anyInputRow || r >= 0;
-    static const bool flat = knobInt(FX_DIAG_KNOB("FX_STAGES_BALANCE"), 1) == 0;   // diagnostics: the program's share only
-    const int kInputCost = anyInputRow && !flat ? 14 : 0, kOutputCost = flat ? 0 : 7, kRecvCost = flat ? 0 : 3, kSendCost = flat ? 0 : 1, kFixedCost = 8;
-    std::vector<size_t> bounds{0};
-    for (size_t b = 1; b < n; ++b)
-        if (allowed[b]) bounds.push_back(b);
-    bounds.push_back(n);
-    const size_t nb = bounds.size();
-    auto stageCost = [&](size_t lo, size_t hi) {   // indices into bounds
-        const size_t from = bounds[lo], to = bounds[hi];
-        int c = cum[to] - cum[from] + kFixedCost;
-        if (from == 0) c += kInputCost; else c += kRecvCost * (int)liveAt[from].size();
-        if (to == n) c += kOutputCost; else c += kSendCost * (int)liveAt[to].size();
-        return c;
-    };
-    std::vector<int> cuts;
-    for (int K = std::min<int>(wanted, (int)nb - 1); K >= 2 && cuts.empty(); --K) {
-        const int kInf = 1 << 30;
-        // best[k][j]: the smallest possible largest-stage cost of records [0, bounds[j]) in k stages
-        std::vector<std::vector<int>> best((size_t)K + 1, std::vector<int>(nb, kInf)), from((size_t)K + 1, std::vector<int>(nb, -1));
-        best[0][0] = 0;
-        for (int k = 1; k <= K; ++k)
-            for (size_t j = 1; j < nb; ++j)
-                for (size_t i = 0; i < j; ++i) {
-                    if (best[(size_t)k - 1][i] == kInf) continue;
-                    if ((cum[bounds[j]] - cum[bounds[i]]) * 4 * wanted < total) continue;
-                    const int c = std::max(best[(size_t)k - 1][i], stageCost(i, j));
-                    if (c < best[(size_t)k][j]) { best[(size_t)k][j] = c; from[(size_t)k][j] = (int)i; }
-                }
-        if (best[(size_t)K][nb - 1] == kInf) continue;
-        size_t j = nb - 1;
-        for (int k = K; k >= 1; --k) {
-            j = (size_t)from[(size_t)k][j];
-            if (k > 1) cuts.push_back((int)bounds[j]);
-        }
-        std::reverse(cuts.begin(), cuts.end());
-    }
-    P.totalCost = total;
-    for (size_t i = 0; i < n; ++i) P.totalLuts += steadyRecords[i].w[0] == AS_LUT ? 1 : 0;
-    if (FX_DIAG_KNOB("FX_STAGES_DEBUG")) {
-        std::string line;
-        for (size_t b = 0; b <= n; ++b) line += allowed[b] ? '+' : '.';
-        std::fprintf(stderr, "planStages: %zu records, total cost %d, boundaries %s\n", n, total, line.c_str());
-    }
-    P.totalCost = total;
-    if (cuts.empty()) return no("no legal cut");
-    P.cuts = cuts;
-    {   // what the plan expects each stage to cost (the units of costOf: roughly vector instructions), pipeline overhead included
-        size_t lo = 0;
-        std::vector<size_t> edges{0};
-        for (int b : cuts) edges.push_back((size_t)b);
-        edges.push_back(n);
-        for (size_t k = 0; k + 1 < edges.size(); ++k) {
-            int c = cum[edges[k + 1]] - cum[edges[k]] + kFixedCost;
-            if (edges[k] == 0) c += kInputCost; else c += kRecvCost * (int)liveAt[edges[k]].size();
-            if (edges[k + 1] == n) c += kOutputCost; else c += kSendCost * (int)liveAt[edges[k + 1]].size();
-            int luts = 0;
-            for (size_t i = edges[k]; i < edges[k + 1]; ++i) luts += steadyRecords[i].w[0] == AS_LUT ? 1 : 0;
-            P.stageCost.push_back(c);
-            P.stageLuts.push_back(luts);
-        }
-        (void)lo;
-    }
-    if (FX_DIAG_KNOB("FX_STAGES_DEBUG")) {
-        std::string line;
-        for (size_t k = 0; k < P.stageCost.size(); ++k) line += " " + std::to_string(P.stageCost[k]) + "(" + std::to_string(P.stageLuts[k]) + ")";
-        std::fprintf(stderr, "planStages: wanted %d -> %zu stages, cost per stage (LOG/EXP):%s\n", wanted, P.stageCost.size(), line.c_str());
-    }
-    for (int b : cuts) {
-        std::vector<int> l = liveAt[(size_t)b];
-        std::sort(l.begin(), l.end());
-        P.live.push_back(l);
-    }
-    const int K = (int)cuts.size() + 1;
-    auto stageOf = [&](size_t pos) { int st = 0; for (int b : cuts) if ((int)pos >= b) ++st; return st; };
-    // who stores what at the end of a block: the stage of the row's last write (the last stream decides: it makes every CCR
-    // write live); rows no record writes - PCM input rows, untouched state - stay with stage 0, which loads every input channel
-    P.storeStage.assign((size_t)rows, 0);
-    for (size_t i = 0; i < n; ++i) {
-        const Access a = accessOf(lastRecords[i]);
-        if (a.write >= 0 && a.write < rows) P.storeStage[(size_t)a.write] = stageOf(i);
-        if (a.ccr) P.storeStage[0] = stageOf(i);
-    }
-    P.pcmStage.assign(prog.latchRows.size(), 0);
-    for (size_t c = 0; c < prog.latchRows.size(); ++c)
-        if (prog.latchRows[c] >= 0 && prog.latchRows[c] < rows) P.pcmStage[c] = P.storeStage[(size_t)prog.latchRows[c]];
-    P.inMask.assign((size_t)K, 0);
-    for (size_t c = 0; c < prog.inRows.size(); ++c)
-        if (prog.inRows[c] >= 0) P.inMask[0] |= 1u << c;
-    {
-        std::string why;
-        if (!verifyStagePlan(steadyRecords, lastRecords, n, prog, rows, P, &why)) return no(why);
-    }
-    return P;
-}
-
-namespace {
-// A plan is checked before it is used, by running the program's DATA FLOW twice over a few samples and two launches - as the
-// reference runs it (one register file, records in order) and as the stages would (one file per stage, the rows of `live`
-// copied at each cut, inputs loaded by stage 0, rows stored at the end of a launch by their owners) - on symbolic values: every
-// write makes a value that is a hash of the record, the sample and the values it read (a conditional write: also of the value
-// it may leave in place).  Every read, every PCM output and every stored row must see the same value in both runs.
-uint64_t mix64(uint64_t h, uint64_t v) {
-    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
-    h *= 0xff51afd7ed558ccdull;
-    return h ^ (h >> 33);
-}
-bool verifyStagePlan(const std::vector<MicroOp>& steady, const std::vector<MicroOp>& last, size_t n, const XlateProgram& prog, int rows, const StagePlan& P, std::string* why) {
-    const int K = (int)P.cuts.size() + 1;
-    const std::vector<MicroOp>* current = &steady;   // (the last sample of a launch runs the last-sample stream: every CCR write live)
-    auto stageOf = [&](size_t pos) { int st = 0; for (int b : P.cuts) if ((int)pos >= b) ++st; return st; };
-    std::vector<uint64_t> state((size_t)rows);
-    for (int r = 0; r < rows; ++r) state[(size_t)r] = mix64(0x1234, (uint64_t)r);
-    std::vector<uint8_t> shadowed(n, 0);
-    {
-        bool sh = false;
-        for (size_t i = 0; i < n; ++i) {
-            if (steady[i].w[0] == AS_PRED) sh = true;
-            else if (steady[i].w[0] == AS_UNPRED) sh = false;
-            shadowed[i] = sh;
-        }
-    }
-    auto step = [&](std::vector<uint64_t>& file, size_t i, int launch, int t, std::vector<uint64_t>* trace) {
-        const Access a = accessOf((*current)[i]);
-        uint64_t h = mix64(mix64((uint64_t)i * 977 + 13, (uint64_t)t), (uint64_t)launch);
-        for (int k = 0; k < a.nReads; ++k) {
-            const uint64_t v = file[a.reads[k]];
-            if (trace) trace->push_back(v);
-            h = mix64(h, v);
-        }
-        auto write = [&](int R) {
-            uint64_t v = mix64(h, (uint64_t)R);
-            if (shadowed[i]) v = mix64(v, file[(size_t)R]);  // (may leave the old value in place)
-            file[(size_t)R] = v;
-        };
-        if (a.write >= 0 && a.write < rows) write(a.write);
-        if (a.ccr) write(0);
-    };
-    for (int launch = 0; launch < 2; ++launch) {
-        std::vector<uint64_t> seq = state;
-        std::vector<std::vector<uint64_t>> file((size_t)K, state);
-        for (int t = 0; t < 3; ++t) {
-            current = t == 2 ? &last : &steady;
-            std::vector<uint64_t> want, got;
-            for (size_t c = 0; c < prog.inRows.size(); ++c)
-                if (prog.inRows[c] >= 0 && prog.inRows[c] < rows) {
-                    seq[(size_t)prog.inRows[c]] = mix64(mix64(0x77, c), (uint64_t)(launch * 16 + t));
-                    file[0][(size_t)prog.inRows[c]] = seq[(size_t)prog.inRows[c]];
-                }
-            for (size_t i = 0; i < n; ++i) step(seq, i, launch, t, &want);
-            for (int k = 0; k < K; ++k) {
-                if (k > 0)
-                    for (int R : P.live[(size_t)k - 1]) file[(size_t)k][(size_t)R] = file[(size_t)k - 1][(size_t)R];
-                const size_t from = k == 0 ? 0 : (size_t)P.cuts[(size_t)k - 1], to = k + 1 == K ? n : (size_t)P.cuts[(size_t)k];
-                for (size_t i = from; i < to; ++i) step(file[(size_t)k], i, launch, t, &got);
-            }
-            if (want != got) { if (why) *why = "plan check: a read would see another value"; return false; }
-            for (size_t c = 0; c < prog.latchRows.size(); ++c) {
-                const int R = prog.latchRows[c];
-                if (R < 0 || R >= rows) continue;
-                if (file[(size_t)P.pcmStage[c]][(size_t)R] != seq[(size_t)R]) { if (why) *why = "plan check: PCM output of another stage's copy"; return false; }
-            }
-        }
-        for (int R = 0; R < rows; ++R) {
-            if (file[(size_t)P.storeStage[(size_t)R]][(size_t)R] != seq[(size_t)R]) { if (why) *why = "plan check: a row would be stored by the wrong stage"; return false; }
-            state[(size_t)R] = seq[(size_t)R];
-        }
-        (void)stageOf;
-    }
-    return true;
-}
-
-// the records of one stage as a stream of its own (ENDSAMPLE and the fetch pad behind it)
-std::vector<MicroOp> stageRecords(const std::vector<MicroOp>& all, size_t from, size_t to) {
-    std::vector<MicroOp> out(all.begin() + (long)from, all.begin() + (long)to);
-    MicroOp end{};
-    end.w[0] = AS_ENDSAMPLE;
-    out.push_back(end);
-    MicroOp nop{};
-    nop.w[0] = AS_NOP;
-    for (int k = 0; k < 4; ++k) out.push_back(nop);
-    return out;
-}
-}  // namespace
-
-// LDS of a staged program: the LOG/EXP tables (shared by all stages: every wavefront stages the same bytes), one flag row per
-// stage ("my packets may hold non-finite values", Translator::stageFlagCheck), the ring of 4 * group packet buffers (the
-// generated code steps through them with an add and an AND: the stride is a power of two), the epilogue's scratch
-bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* L, int pinGroup) {
-    const int K = (int)plan.cuts.size() + 1;
-    const uint32_t tableBytes = program.lutTables.empty() ? 0u : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
-    L->cutOff.clear();
-    uint32_t bufStride = 0;
-    for (const auto& l : plan.live) { L->cutOff.push_back(bufStride); bufStride += 256u * (uint32_t)l.size(); }
-    uint32_t pow2 = 256u;
-    while (pow2 < bufStride) pow2 <<= 1;
-    L->bufStride = pow2;
-    L->scratchBytes = (uint32_t)K * 512u;   // the template's epilogue (counts and flags of the stages -> stage 0)
-    int group = kStageGroupMax;
-    while (group > 1 && group > maxGroup) group /= 2;
-    if (pinGroup == 1 || pinGroup == 2 || pinGroup == 4) group = pinGroup;   // tests: a shorter ring than the LDS would allow
-    // without tables the ring lies at address 0 (the pointer's and-mask needs no base: StageInfo::ptrBias), flag rows and scratch
-    // behind it; with tables: [tables][flags][ring][scratch]
-    static const bool pairOff = knobInt(FX_DIAG_KNOB("FX_XLATE_LDS2"), 1) == 0;   // diagnostics
-    L->ringFirst = tableBytes == 0 && !pairOff;
-    const uint32_t fixed = ((tableBytes + 255u) & ~255u) + 256u * (uint32_t)K + L->scratchBytes;
-    while (group > 1 && fixed + 4u * (uint32_t)group * L->bufStride > ldsBudget) group /= 2;
-    L->group = group;
-    const uint32_t ring = 4u * (uint32_t)group * L->bufStride;
-    if (L->ringFirst) {
-        L->bufBase = 0;
-        L->flagBase = ring;
-        L->scratchOff = ring + 256u * (uint32_t)K;
-    } else {
-        L->flagBase = (tableBytes + 255u) & ~255u;
-        L->bufBase = L->flagBase + 256u * (uint32_t)K;
-        L->scratchOff = L->bufBase + ring;
-    }
-    L->bytes = fixed + ring;
-    return !(L->bufBase + L->bufStride > 0xff00u || L->bytes > std::min(ldsBudget, 160u * 1024u));
-}
-
-bool buildStagedImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords, const XlateTemplate& tmpl,
-                      const XlateProgram& program, const StagePlan& plan, XlateImage* out, std::vector<std::vector<uint32_t>>* codeOut,
-                      std::vector<std::string>* listingOut, std::string* err, uint32_t ldsBudget, int maxGroup, int pinGroup) {
-    const int K = (int)plan.cuts.size() + 1;
-    if (K < 2) { if (err) *err = "not a staged plan"; return false; }
-    size_t n = 0;
-    while (n < steadyRecords.size() && steadyRecords[n].w[0] != AS_ENDSAMPLE) ++n;
-    StageLds L;
-    if (!stageLdsLayout(program, plan, ldsBudget, maxGroup, &L, pinGroup)) { if (err) *err = "staged program: packets beyond the LDS"; return false; }
-    const std::vector<uint32_t>& cutOff = L.cutOff;
-    const uint32_t bufStride = L.bufStride, flagBase = L.flagBase, bufBase = L.bufBase;
-    const int group = L.group;
-    std::vector<std::vector<uint32_t>> code((size_t)K * 4 + 1);
-    std::vector<std::string> listing((size_t)K * 4 + 1);
-    uint32_t at = tmpl.holeOff;
-    out->stages = K;
-    out->stageDesc.assign((size_t)K, StageDescriptor{});
-    out->stageStoreRows.assign((size_t)K, {});
-    out->plan = plan;
-    out->wildRow = program.wildRow;
-    out->steady = XlateStats();
-    out->last = XlateStats();
-    for (size_t r = 0; r < plan.storeStage.size(); ++r) out->stageStoreRows[(size_t)plan.storeStage[r]].push_back((int)r);
-    int worstValu = -1;
-    HoistPlan stage0Hoist;
-    for (int k = 0; k < K; ++k) {
-        const size_t from = k == 0 ? 0 : (size_t)plan.cuts[(size_t)k - 1], to = k + 1 == K ? n : (size_t)plan.cuts[(size_t)k];
-        const std::vector<MicroOp> steady = stageRecords(steadyRecords, from, to), last = stageRecords(lastRecords, from, to);
-        // the stage as a program of its own: its delay-line reads may lead (stage 0 owns all of them), its PCM channels; tables,
-        // row classes and the LDS layout are the whole program's
-        std::vector<int> inRows = program.inRows;
-        for (size_t c = 0; c < inRows.size(); ++c)
-            if (!((plan.inMask[(size_t)k] >> c) & 1u)) inRows[c] = -1;
-        XlateProgram p = xlateProgramOf(steady, last, program.iSize, program.xSize, (int)program.wildRow.size(), inRows, program.latchRows);
-        p.lutTables = program.lutTables;
-        p.wildRow = program.wildRow;
-        p.tramStreaming = program.tramStreaming;
-        p.stage.index = k;
-        p.stage.count = K;
-        p.stage.bufBase = bufBase;
-        p.stage.flagBase = flagBase;
-        p.stage.bufStride = bufStride;
-        p.stage.group = group;
-        if (k > 0) { p.stage.recvRows = plan.live[(size_t)k - 1]; p.stage.recvOff = cutOff[(size_t)k - 1]; }
-        if (k + 1 < K) { p.stage.sendRows = plan.live[(size_t)k]; p.stage.sendOff = cutOff[(size_t)k]; }
-        p.stage.ptrBias = L.ringFirst ? (k > 0 ? p.stage.recvOff : p.stage.sendOff) : 0u;
-        p.stage.storeMask = 0;
-        for (size_t c = 0; c < plan.pcmStage.size(); ++c)
-            if (plan.pcmStage[c] == k) p.stage.storeMask |= 1u << c;
-        // a leading delay-line read issued a sample ahead lands in its row while this sample's tail is still to come: a row the
-        // tail hands to the next stage must not be one of those (the hoist point only knows the stage's own records)
-        for (int q = 0; q < p.hoist.leadCount; ++q)
-            if (std::find(p.stage.sendRows.begin(), p.stage.sendRows.end(), (int)steady[(size_t)q].w[5]) != p.stage.sendRows.end()) {
-                p.hoist = HoistPlan();
-                break;
-            }
-        // steps far shorter than a trip to memory: PCM input in bursts (a stage with delay lines keeps the loop's own prefetch)
-        p.stage.inRing = (p.tramOpsInline == 0 && p.hoist.leadCount == 0 && !FX_DIAG_KNOB("FX_STAGES_NO_RING")) ? -2 : -1;
-        if (k == 0) stage0Hoist = p.hoist;
-        XlateImage one;
-        std::vector<uint32_t> c5[5];
-        std::string t5[5];
-        // planXlate lays its streams out from the hole's start; here they follow the previous stage's
-        XlateTemplate shifted = tmpl;
-        shifted.holeOff = at;
-        shifted.holeBytes = tmpl.holeBytes - (at - tmpl.holeOff);
-        if (!planXlate(steady, last, shifted, p, &one, c5, listingOut ? t5 : nullptr, err)) return false;
-        // (its run-once code is dropped: one copy for the whole program follows the last stage)
-        uint32_t end = at;
-        for (int q = 0; q < 4; ++q) {
-            code[(size_t)k * 4 + (size_t)q] = c5[q];
-            listing[(size_t)k * 4 + (size_t)q] = t5[q];
-            if (!c5[q].empty()) end = std::max(end, one.base[q] + align64((uint32_t)c5[q].size() * 4));
-        }
-        StageDescriptor& d = out->stageDesc[(size_t)k];
-        d.steadyFast = one.steadyFastOff;
-        d.steadyExact = one.steadyOff;
-        d.lastFast = one.lastFastOff;
-        d.lastExact = one.lastOff;
-        for (int q = 0; q < 4; ++q) out->base[q] = one.base[q];  // (of the last stage: diagnostics only)
-        out->stageBases.push_back({one.base[0], one.base[1], one.base[2], one.base[3]});
-        // statistics: the stages' vector instructions ADD UP to the work of one sample of one instance group (the slowest
-        // stage sets the pace: worstValu)
-        worstValu = std::max(worstValu, one.steady.valu);
-        for (auto pr : {std::make_pair(&out->steady, &one.steady), std::make_pair(&out->last, &one.last)}) {
-            XlateStats& a = *pr.first;
-            const XlateStats& b = *pr.second;
-            a.inlined += b.inlined; a.called += b.called; a.instructions += b.instructions; a.valu += b.valu; a.valuSlow += b.valuSlow;
-            a.valuClocks += b.valuClocks; a.fusedSkips += b.fusedSkips; a.regions += b.regions; a.unitMultipliers += b.unitMultipliers;
-            a.reusedProducts += b.reusedProducts; a.fusedZeroAdds += b.fusedZeroAdds; a.unsaturated += b.unsaturated;
-        }
-        out->vgprConstants = one.vgprConstants;
-        at = end;
-    }
-    // the run-once code: tables of the whole program, the hoist decision of stage 0
-    out->initOff = 0;
-    out->ldsBytes = L.bytes;
-    for (StageDescriptor& d : out->stageDesc) d.scratchOff = L.scratchOff;
-    {
-        XlateProgram initProg = program;
-        initProg.hoist = stage0Hoist;
-        if (!initProg.lutTables.empty() || initProg.hoist.leadCount > 0) {
-            emitInit(initProg, &code[(size_t)K * 4], listingOut ? &listing[(size_t)K * 4] : nullptr);
-            out->initOff = at;
-            at += align64((uint32_t)code[(size_t)K * 4].size() * 4);
-        }
-    }
-    out->codeBytes = at - tmpl.holeOff;
-    out->slowestStageValu = worstValu;
-    if (out->codeBytes + 4 > tmpl.holeBytes) { if (err) *err = "translated program larger than the code hole of the template"; return false; }
-    out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
-    for (int k = 0; k < K; ++k)
-        for (int q = 0; q < 4; ++q) {
-            const std::vector<uint32_t>& c = code[(size_t)k * 4 + (size_t)q];
-            if (!c.empty()) std::memcpy(out->elf.data() + tmpl.holeFileOff + (out->stageBases[(size_t)k][(size_t)q] - tmpl.holeOff), c.data(), c.size() * 4);
-        }
-    if (out->initOff) std::memcpy(out->elf.data() + tmpl.holeFileOff + (out->initOff - tmpl.holeOff), code[(size_t)K * 4].data(), code[(size_t)K * 4].size() * 4);
-    if (codeOut) *codeOut = code;
-    if (listingOut) *listingOut = listing;
-    return true;
-}
-
-uint64_t imageHash(const XlateImage& image) {
-    uint64_t h = 0xcbf29ce484222325ull;   // FNV-1a over 8-byte words
-    const size_t n = image.elf.size() / 8;
-    for (size_t k = 0; k < n; ++k) {
-        uint64_t w;
-        std::memcpy(&w, image.elf.data() + 8 * k, 8);
-        h = (h ^ w) * 0x100000001b3ull;
-    }
-    for (size_t k = 8 * n; k < image.elf.size(); ++k) h = (h ^ image.elf[k]) * 0x100000001b3ull;
-    h = (h ^ (uint64_t)image.stages ^ ((uint64_t)image.ldsBytes << 8)) * 0x100000001b3ull;
-    return h & 0x7fffffffffffffffull;
-}
-
-bool buildXlateImage(const std::vector<MicroOp>& steadyRecords, const std::vector<MicroOp>& lastRecords,
-                     const XlateTemplate& tmpl, const XlateProgram& prog, XlateImage* out, std::string* err) {
-    std::vector<uint32_t> code[5];
-    if (!planXlate(steadyRecords, lastRecords, tmpl, prog, out, code, nullptr, err)) return false;
-    out->elf.assign(tmpl.image, tmpl.image + tmpl.imageBytes);
-    const uint32_t offs[5] = {out->base[0], out->base[1], out->base[2], out->base[3], out->initOff};
-    for (int k = 0; k < 5; ++k)
-        if (!code[k].empty()) std::memcpy(out->elf.data() + tmpl.holeFileOff + (offs[k] - tmpl.holeOff), code[k].data(), code[k].size() * 4);
     return true;
 }
 

@@ -876,3 +876,56 @@ def test_damaged_state_images_are_refused_before_any_address_is_computed(gpu):
     assert np.array_equal(bits(b.process_block(x[2 * S:])), bits(twin.process_block(x[2 * S:])))
     # a smaller delay line in the image than in the batch is legal (the rest stays zero) - and not a way around the size check
     assert b.info("itram_slots") == 37
+
+
+def test_delay_memory_that_cannot_be_allocated(gpu):
+    """a program whose delay lines do not fit the device - xtramsize 1 048 576 x 262 144 instances = 1 TiB on a 288 GB GPU: the
+    first block (and fxb_prepare) returns FX_E_MEMORY with the runtime's message, nothing of the attempt stays allocated, the
+    handle stays alive and usable - as the reference's object does after a failed loadFile (source/FX8010.cpp:777-875: `false`
+    + error list, object intact): a further load that shrinks the line (the loader's size is whatever the last xtramsize line
+    said) runs, bit-exactly.  Then 50 create / load / run / destroy cycles leave hipMemGetInfo where it was.  (The same paths
+    under AddressSanitizer with an injected allocator, and module-load failures, without a GPU:
+    tests/test_host_sanitizers.py.)"""
+    import torch
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    N = 262144
+    big = ("xtramsize 1048576 \ninput in 0\noutput out 0\nstatic xd\nstatic a\nxdelay read, xd, at, 0\nmacs a, in, xd, 0.5\nxdelay write, a, at, 0\nmacs out, a, 0, 0\nend")
+    b = gpu.Batch(N, 1, 0)
+    assert b.load_text(big), b.errors()
+    free0, total = torch.cuda.mem_get_info(0)
+    assert total < N * 1048576 * 4
+    x = progs.stimulus(N, 8)
+    for attempt in range(2):
+        with pytest.raises(RuntimeError) as e:
+            b.process_block(x)
+        assert "(-5)" in str(e.value) and "TRAM" in str(e.value), str(e.value)     # FX_E_MEMORY, "hipMalloc TRAM: out of memory"
+    with pytest.raises(RuntimeError) as e:
+        b.prepare(8, True)
+    assert "(-5)" in str(e.value)
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert abs(free1 - free0) < (256 << 20), (free0, free1)                         # nothing of the attempt is left (the state rows are there in both readings)
+    assert b.load_text("xtramsize 64 \nend"), b.errors()                            # the handle lives: the accumulated program with a line that fits
+    y = b.process_block(x)
+    for n in (0, 63, 64, N - 1):
+        o = Oracle(1)
+        assert o.load_text(big) and o.load_text("xtramsize 64 \nend")
+        assert np.array_equal(bits(o.process_block(x[:, n].copy())), bits(y[:, n])), n
+    assert b.ood_flags() == 0 and b.info("xtram_slots") <= 64
+    del b
+    # create / load / run / destroy: the device's free memory comes back to where it was
+    def cycle():
+        c = gpu.Batch(20000, 1, 0)
+        assert c.load_text(progs.CONFIGS["config5"]())
+        c.process_block(progs.stimulus(20000, 4))
+        c.set_register_i("u", 5, 0.5)
+        c.process_block(progs.stimulus(20000, 4))
+        c.close()
+    cycle()
+    torch.cuda.synchronize()
+    base, _ = torch.cuda.mem_get_info(0)
+    for _ in range(50):
+        cycle()
+    torch.cuda.synchronize()
+    after, _ = torch.cuda.mem_get_info(0)
+    assert abs(after - base) <= (8 << 20), (base, after)
