@@ -17,17 +17,25 @@
 
 namespace fx {
 using namespace xl;
+
+// the LDS layout of the LOG / EXP tables in force (fx_xlate_emit.hpp).  The diagnostics build can pick the other one
+// (FX_XLATE_LUTWIDE=0 / 1) for an A/B inside one process image; the release library has the default only.
+const LutLdsLayout& xl::lutLds() {
+    static const bool wide = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTWIDE"), 1) != 0;
+    return wide ? kLutWide : kLutNarrow;
+}
+
 namespace {
 
-// the four VGPR constants of the quick LOG/EXP index guess (Translator::lut)
+// the four VGPR constants of the quick LOG/EXP index guess (Translator::lut): cell bytes * 31.5, that - 0.5, the rounding
+// constant and the mask of the cell offset - for 8-byte cells (narrow layout) and 16-byte cells (wide layout)
 struct LutGuessConstants {
-    uint32_t scale = 0x437c0000u;   // 252.0
-    uint32_t bias = 0x437b8000u;    // 251.5
-    uint32_t magic = 0x4b400000u;   // 1.5 * 2^23
-    uint32_t mask = 0x000001f8u;
+    uint32_t scale, bias, magic, mask;
     bool available(const Emitter& e) const { return e.pooled(scale) >= 0 && e.pooled(bias) >= 0 && e.pooled(magic) >= 0 && e.pooled(mask) >= 0; }
 };
-const LutGuessConstants kLutGuess;
+constexpr LutGuessConstants kLutGuessNarrow{0x437c0000u /* 252.0 */, 0x437b8000u /* 251.5 */, 0x4b400000u /* 1.5 * 2^23 */, 0x000001f8u};
+constexpr LutGuessConstants kLutGuessWide{0x43fc0000u /* 504.0 */, 0x43fbc000u /* 503.5 */, 0x4b400000u, 0x000003f0u};
+const LutGuessConstants& lutGuess() { return lutLds().wide ? kLutGuessWide : kLutGuessNarrow; }
 
 class Translator {
   public:
@@ -806,9 +814,9 @@ class Translator {
         site.vA = vA;
         site.lds = lds;
         site.guarded = operandWild || !fast_;
-        site.slopeOff = kLdsTables + (uint32_t)(lds ? ldsTable : 0) * kLdsTableBytes;
+        site.slopeOff = lutLds().tables + (uint32_t)(lds ? ldsTable : 0) * lutLds().tableBytes;
         site.window = (lds && fast_) ? lutGuessWindowHi() : 0;
-        site.quick = site.window != 0 && kLutGuess.available(e_);
+        site.quick = site.window != 0 && lutGuess().available(e_);
         if (fast_ && operandWild && site.quick) {
             // A wild operand is nearly always inside the table too (the PCM input, a wrap-around result): one compare sends the
             // wave to the guarded form - behind the loop, with the out-of-domain flag and the taint check of the result - only
@@ -858,10 +866,10 @@ class Translator {
         // fraction is within 2^-15 of a whole number; at x = +-1, the only floats where the tie can matter, round-to-even
         // picks 504 and 0); q & 0x1f8 is the byte offset of the segment.  Otherwise (x + 1) * 31.5 truncated by v_cvt.
         if (quick) {
-            Src half = vreg(e_.pooled(kLutGuess.bias));
-            e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(6), vreg(vA), vreg(e_.pooled(kLutGuess.scale)), &half);
-            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, vreg(e_.pooled(kLutGuess.magic)), 6);
-            e_.vop2(VOP2_AND_B32, "v_and_b32_e32", 7, vreg(e_.pooled(kLutGuess.mask)), 6);
+            Src half = vreg(e_.pooled(lutGuess().bias));
+            e_.vop3(VOP3_FMA_F32, "v_fma_f32", vreg(6), vreg(vA), vreg(e_.pooled(lutGuess().scale)), &half);
+            e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, vreg(e_.pooled(lutGuess().magic)), 6);
+            e_.vop2(VOP2_AND_B32, "v_and_b32_e32", 7, vreg(e_.pooled(lutGuess().mask)), 6);
         } else {
             e_.vop2(VOP2_ADD_F32, "v_add_f32_e32", 6, imm32(0x3f800000u), vA);
             e_.vop2(VOP2_MUL_F32, "v_mul_f32_e32", 6, imm32(0x41fc0000u), 6);              // * 31.5
@@ -939,11 +947,16 @@ class Translator {
     // thresholds -> v[8:9]
     void lutFetch(const LutSite& s, bool withThresholds, bool offsetReady) {
         if (s.lds) {
-            if (!offsetReady) e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(3), 6);
-            if (withThresholds) e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);   // xthr[g], xthr[g+1]
-            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, kLdsX1);                       // x1[g]
-            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 2, 7, s.slopeOff);
-            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 4, 7, s.slopeOff + 512);
+            const LutLdsLayout& L = lutLds();
+            if (!offsetReady) e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32((uint32_t)L.shift), 6);
+            if (withThresholds) e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, L.thr);     // xthr[g], xthr[g+1]
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 10, 7, L.x1);                         // x1[g]
+            if (L.wide) {
+                e_.dsRead(DS_READ_B128, "ds_read_b128", 4, 2, 7, s.slopeOff);              // {slope, y1} of segment g: one cell
+            } else {
+                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 2, 7, s.slopeOff);
+                e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 4, 7, s.slopeOff + 512);
+            }
         } else {
             if (withThresholds) {
                 e_.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 7, imm32(2), 6);
@@ -966,8 +979,8 @@ class Translator {
         const Src zero = imm32(0), top = imm32(63);
         e_.cold(true);
         if (s.window) {
-            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, kLdsThr);
-            if (s.quick) e_.vop2(VOP2_LSHRREV_B32, "v_lshrrev_b32_e32", 6, imm32(3), 7);
+            e_.dsRead(DS_READ_B64, "ds_read_b64", 2, 8, 7, lutLds().thr);
+            if (s.quick) e_.vop2(VOP2_LSHRREV_B32, "v_lshrrev_b32_e32", 6, imm32((uint32_t)lutLds().shift), 7);
             e_.waitLgkm0();
             e_.vop3cmpTo(VOP3_CMP_LT_F32, "v_cmp_lt_f32_e64", kSTemp, vreg(s.vA), vreg(8));
         }
@@ -2135,9 +2148,11 @@ void xl::emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::st
         e.sop2(SOP2_MIN_I32, "s_min_i32", sreg(kSSliceShift), sreg(kSSliceShift), imm32(20));
     }
     if (!prog.lutTables.empty()) {
+        const LutLdsLayout& L = lutLds();
         e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 2, imm32(2), 0);  // v2 = lane * 4 (v0 = lane)
         e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 3, imm32(3), 0);  // v3 = lane * 8
         e.vop2(VOP2_LSHLREV_B32, "v_lshlrev_b32_e32", 12, imm32(4), 0); // v12 = lane * 16
+        const int cell = L.wide ? 12 : 3;                               // LDS address of lane's cell: lane * 16 / lane * 8
         e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32((uint32_t)kLutXthrOff * 8, true));
         e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
         e.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 4, 2, kSAddr);        // xthr[lane], xthr[lane + 1]
@@ -2145,16 +2160,20 @@ void xl::emitInit(const XlateProgram& prog, std::vector<uint32_t>* code, std::st
         e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
         e.globalLoadWide(GLOBAL_LOAD_DWORDX2, 2, 6, 3, kSAddr);        // x1[lane]
         e.waitVmcnt(0);
-        e.dsWriteB64(3, 4, kLdsThr);
-        e.dsWriteB64(3, 6, kLdsX1);
+        e.dsWriteB64(cell, 4, L.thr);
+        e.dsWriteB64(cell, 6, L.x1);
         for (size_t k = 0; k < prog.lutTables.size(); ++k) {
-            const uint32_t table = kLdsTables + (uint32_t)k * kLdsTableBytes;
+            const uint32_t table = L.tables + (uint32_t)k * L.tableBytes;
             e.sop2(SOP2_ADD_U32, "s_add_u32", sreg(kSAddr), sreg(kSLut), imm32(prog.lutTables[k], true));
             e.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSAddr + 1), sreg(kSLut + 1), imm32(0));
             e.globalLoadWide(GLOBAL_LOAD_DWORDX4, 4, 4, 12, kSAddr);   // {slope, y1} of segment lane
             e.waitVmcnt(0);
-            e.dsWriteB64(3, 4, table);
-            e.dsWriteB64(3, 6, table + 512);
+            if (L.wide) {
+                e.dsWriteB128(12, 4, table);
+            } else {
+                e.dsWriteB64(3, 4, table);
+                e.dsWriteB64(3, 6, table + 512);
+            }
         }
         e.waitLgkm0();
     }
@@ -2441,7 +2460,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
         const int firstFree = kRegFileBase + (int)program.wildRow.size();
         if (!program.lutTables.empty() && tmpl.vgprs - firstFree >= 4 && !(knob && std::atoi(knob) == 0)) {
             int v = tmpl.vgprs;
-            for (uint32_t c : {kLutGuess.scale, kLutGuess.bias, kLutGuess.magic, kLutGuess.mask}) pooledProgram.vconst.emplace_back(c, --v);
+            for (uint32_t c : {lutGuess().scale, lutGuess().bias, lutGuess().magic, lutGuess().mask}) pooledProgram.vconst.emplace_back(c, --v);
         }
     }
     // ... a staged program's spare registers for the next sample's packet and for its PCM input bursts (StageInfo)
@@ -2525,7 +2544,7 @@ bool planXlate(const std::vector<MicroOp>& steadyRecords, const std::vector<Micr
     if (!program.lutTables.empty() || program.hoist.leadCount > 0 || sliceBias >= 0) {
         emitInit(program, &code[4], listing ? &listing[4] : nullptr, sliceBias);
         out->initOff = at;
-        out->ldsBytes = program.lutTables.empty() ? 0 : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
+        out->ldsBytes = program.lutTables.empty() ? 0 : lutLds().bytes(program.lutTables.size());
         at += align64((uint32_t)code[4].size() * 4);
     }
     out->codeBytes = at - tmpl.holeOff;

@@ -433,9 +433,20 @@ constexpr int kVOod = 22;         // v22 = out-of-domain flags of the lane
 constexpr int kVCursor = 16;      // v16..v19 = TRAM cursors: iTRAM write, iTRAM read, xTRAM write, xTRAM read
 constexpr int kSCursor = 80;      // s80..s83 = the same cursors while a stream with uniform cursors runs
 constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRAM code (s[86:87] = slot address)
-// LUT tables in LDS, every array indexed by segment * 8 bytes (ds_read_b64: at most two lanes of a 32-lane group share
-// a bank): {xthr[g], xthr[g+1]} fp32 pairs | x1[64] fp64 | per table slope[64] fp64, y1[64] fp64
-constexpr uint32_t kLdsThr = 0, kLdsX1 = 512, kLdsTables = 1024, kLdsTableBytes = 1024;
+// LUT tables in LDS (the tables a program uses, copied once per workgroup by the run-once code).  Two layouts:
+//   narrow (round 2 .. 4): every array indexed by segment * 8 bytes - {xthr[g], xthr[g+1]} fp32 pairs | x1[64] fp64 | per table
+//           slope[64] fp64, y1[64] fp64: three ds_read_b64 per LOG / EXP (x1, slope, y1);
+//   wide:   every array indexed by segment * 16 bytes - thresholds and x1 in the first half of a 16-byte cell each, per table ONE
+//           array of {slope, y1} cells: a ds_read_b64 (x1) and a ds_read_b128 per LOG / EXP - two LDS instructions instead of
+//           three for the same 24 bytes per lane (measured: DESIGN.md section 5, profiles/r05_lut_wide_ab.txt).
+struct LutLdsLayout {
+    bool wide;
+    uint32_t thr, x1, tables, tableBytes;   // byte offsets of the threshold pairs, of x1[], of the first table; bytes per table
+    int shift;                              // log2 of the bytes per segment cell
+    uint32_t bytes(size_t nTables) const { return tables + (uint32_t)nTables * tableBytes; }
+};
+constexpr LutLdsLayout kLutNarrow{false, 0, 512, 1024, 1024, 3}, kLutWide{true, 0, 1024, 2048, 1024, 4};
+const LutLdsLayout& lutLds();   // the layout in force (fx_xlate.cpp)
 constexpr int kSLut = 40;          // s[40:41] = LUT blob
 constexpr int kSLutXthr = 88, kSLutX1 = 90, kSLutSeg = 92;  // s[88:93]: bases of the fp32 thresholds, x1[] and the current table's segments
 constexpr int kSTramBase[2] = {36, 38}, kSTramSize[2] = {56, 57}, kSTramSlots[2] = {46, 47};  // [iTRAM, xTRAM]

@@ -377,7 +377,7 @@ std::vector<MicroOp> stageRecords(const std::vector<MicroOp>& all, size_t from, 
 // generated code steps through them with an add and an AND: the stride is a power of two), the epilogue's scratch
 bool stageLdsLayout(const XlateProgram& program, const StagePlan& plan, uint32_t ldsBudget, int maxGroup, StageLds* L, int pinGroup) {
     const int K = (int)plan.cuts.size() + 1;
-    const uint32_t tableBytes = program.lutTables.empty() ? 0u : kLdsTables + (uint32_t)program.lutTables.size() * kLdsTableBytes;
+    const uint32_t tableBytes = program.lutTables.empty() ? 0u : lutLds().bytes(program.lutTables.size());
     L->cutOff.clear();
     uint32_t bufStride = 0;
     for (const auto& l : plan.live) { L->cutOff.push_back(bufStride); bufStride += 256u * (uint32_t)l.size(); }
