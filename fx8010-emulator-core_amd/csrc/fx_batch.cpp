@@ -102,6 +102,11 @@ int Batch::fail(int code, const std::string& what) {
     return code;
 }
 int Batch::hipFail(hipError_t e, const char* where) {
+    // The runtime also keeps the error as the calling thread's "last error", and the launch helpers of fx_kernel.hip report
+    // hipGetLastError() after their kernel: an allocation that failed here would come back as the result of the next launch that
+    // works (found by tests/test_gpu_boundary.py::test_delay_memory_that_cannot_be_allocated: fxb_ood_flags said ~0 after a
+    // recovered out-of-memory).  It has been reported: clear it.
+    (void)hipGetLastError();
     return fail(e == hipErrorOutOfMemory ? FX_E_MEMORY : FX_E_NODEVICE, std::string(where) + ": " + hipGetErrorString(e));
 }
 
@@ -753,7 +758,11 @@ Batch::BuildInputs Batch::buildInputs(const std::string& key, int blockClass, bo
 // tier qualifies; whatever else the program would need is left to the caller's thread (FX_E_NOTREADY).
 int Batch::buildCodeInto(Code& c, const BuildInputs& in, bool offline, std::string* err) {
     auto fail = [&](int code, const std::string& what) { *err = what; return code; };
-    auto hipFail = [&](hipError_t e, const char* where) { *err = std::string(where) + ": " + hipGetErrorString(e); return e == hipErrorOutOfMemory ? FX_E_MEMORY : FX_E_NODEVICE; };
+    auto hipFail = [&](hipError_t e, const char* where) {
+        (void)hipGetLastError();   // (reported here: not again by the next launch helper that asks, Batch::hipFail)
+        *err = std::string(where) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? FX_E_MEMORY : FX_E_NODEVICE;
+    };
     const int blockClass = in.blockClass;
     const bool defer = in.defer;
     // Preferred: the hand-written gfx950 interpreter (one instance per lane, bookkeeping in VGPRs).

@@ -678,6 +678,9 @@ hipError_t launchK(const KernelArgs& a, bool multipass, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) return e;
     }
+    // (hipLaunchKernelGGL reports through the thread's "last error": an older one - a failed allocation of this library, or of the
+    // host's own code on this thread - must not be taken for this launch's)
+    (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), ldsBytes, stream, a);
     return hipGetLastError();
 }
@@ -697,6 +700,7 @@ hipError_t launchFillRows(uint32_t* state, long long nPad, const uint32_t* d_row
                           hipStream_t stream) {
     if (nRows <= 0) return hipSuccess;
     dim3 grid((unsigned)((nPad + 255) / 256), (unsigned)(nRows < 64 ? nRows : 64));
+    (void)hipGetLastError();
     hipLaunchKernelGGL(fx_fill_rows, grid, dim3(256), 0, stream, state, nPad, d_rows, d_values, nRows);
     return hipGetLastError();
 }
@@ -706,6 +710,7 @@ hipError_t launchReduceRow(const uint32_t* state, long long nPad, long long n, i
     long long blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(fx_reduce_row, dim3((unsigned)blocks), dim3(256), 0, stream, state, nPad, n, rowLo, rowHi, rowOr, d_sum, d_or);
     return hipGetLastError();
 }

@@ -18,10 +18,13 @@
 namespace fx {
 using namespace xl;
 
-// the LDS layout of the LOG / EXP tables in force (fx_xlate_emit.hpp).  The diagnostics build can pick the other one
-// (FX_XLATE_LUTWIDE=0 / 1) for an A/B inside one process image; the release library has the default only.
+// the LDS layout of the LOG / EXP tables in force (fx_xlate_emit.hpp): the narrow one.  Measured (tools/lut_wide_ab.sh,
+// profiles/r05_lut_wide_ab.txt: config4, alternating runs inside one call): the wide layout issues a third fewer LDS
+// instructions (283 -> 189 per wave-sample) but its 16-byte cells triple the bank-conflict cycles (123 -> 375) and the launch
+// is 0.5 % SLOWER (49.03 -> 49.27 ms; SQ_WAIT_ANY 31 -> 36 % of wavefront time).  The diagnostics build can still pick it
+// (FX_XLATE_LUTWIDE=1) to repeat the A/B; the release library has the default only.
 const LutLdsLayout& xl::lutLds() {
-    static const bool wide = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTWIDE"), 1) != 0;
+    static const bool wide = knobInt(FX_DIAG_KNOB("FX_XLATE_LUTWIDE"), 0) != 0;
     return wide ? kLutWide : kLutNarrow;
 }
 

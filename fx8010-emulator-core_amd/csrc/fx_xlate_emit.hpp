@@ -438,7 +438,8 @@ constexpr int kSPos = 84, kSOod = 85, kSAddr = 86;  // scratch of the inline TRA
 //           slope[64] fp64, y1[64] fp64: three ds_read_b64 per LOG / EXP (x1, slope, y1);
 //   wide:   every array indexed by segment * 16 bytes - thresholds and x1 in the first half of a 16-byte cell each, per table ONE
 //           array of {slope, y1} cells: a ds_read_b64 (x1) and a ds_read_b128 per LOG / EXP - two LDS instructions instead of
-//           three for the same 24 bytes per lane (measured: DESIGN.md section 5, profiles/r05_lut_wide_ab.txt).
+//           three for the same 24 bytes per lane.  Measured 0.5 % slower (three times the bank-conflict cycles:
+//           profiles/r05_lut_wide_ab.txt): the narrow layout stays in force, the wide one is a switch of the diagnostics build.
 struct LutLdsLayout {
     bool wide;
     uint32_t thr, x1, tables, tableBytes;   // byte offsets of the threshold pairs, of x1[], of the first table; bytes per table

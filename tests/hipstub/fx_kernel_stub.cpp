@@ -26,7 +26,7 @@ hipError_t launchStepBlock(const KernelArgs& args, bool, hipStream_t stream) {
         if (a.state && a.nPad > 0) { a.state[0] = a.state[0]; a.state[(size_t)a.nPad - 1] = a.state[(size_t)a.nPad - 1]; }
         (void)sink;
     });
-    return hipSuccess;
+    return hipGetLastError();   // as the real helpers do after hipLaunchKernelGGL: a stale "last error" of the thread comes back here
 }
 
 hipError_t launchFillRows(uint32_t* state, long long nPad, const uint32_t* d_rows, const uint32_t* d_values, int nRows, hipStream_t stream) {
@@ -36,7 +36,7 @@ hipError_t launchFillRows(uint32_t* state, long long nPad, const uint32_t* d_row
             for (long long i = 0; i < nPad; ++i) row[i] = d_values[k];
         }
     });
-    return hipSuccess;
+    return hipGetLastError();   // as the real helpers do after hipLaunchKernelGGL: a stale "last error" of the thread comes back here
 }
 
 hipError_t launchReduceRow(const uint32_t* state, long long nPad, long long n, int rowLo, int rowHi, int rowOr, unsigned long long* d_sum, uint32_t* d_or,
@@ -51,7 +51,7 @@ hipError_t launchReduceRow(const uint32_t* state, long long nPad, long long n, i
         *d_sum += sum;
         *d_or |= all;
     });
-    return hipSuccess;
+    return hipGetLastError();   // as the real helpers do after hipLaunchKernelGGL: a stale "last error" of the thread comes back here
 }
 
 }  // namespace fx

@@ -200,6 +200,9 @@ void scenarioMemory() {
         // xtramsize line said), the accumulated program then fits
         CHECK(fxb_load_text(h, "xtramsize 64 \nend") == 1);
         CHECK(fxb_process_block(h, x.data(), y.data(), 8) == 0);
+        CHECK(fxb_ood_flags(h) == 0);              // (the failed allocation must not come back as a later launch's "last error")
+        CHECK(fxb_instruction_counter(h) >= 0);
+        CHECK(fxb_set_register(h, "a", 0.5f) == 0);
         CHECK(fxb_info(h, FXB_INFO_XTRAM_SLOTS) >= 1 && fxb_info(h, FXB_INFO_XTRAM_SLOTS) <= 64);
         fxb_destroy(h);
     }

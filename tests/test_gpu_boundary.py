@@ -693,6 +693,34 @@ def test_bench_through_rccl_with_one_rank(gpu, tmp_path):
     assert len(d["roofline"]["per_gpu_kernel_ms"]) == 1 and d["roofline"]["per_gpu_kernel_ms"][0] > 0
 
 
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_splits_the_job_over_two_ranks(gpu, scaling):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, two ranks), rehearsed on the one GPU of the test box
+    (FX_BENCH_REHEARSAL=1: the ranks share the device and meet over gloo - RCCL refuses two ranks on one device; same code path
+    otherwise).  strong (the default): the instance count is the WHOLE job - 4 100 instances are 2 050 per rank, rank 1's stimulus
+    starts at instance 2 050, the line totals 4 100; weak: 4 100 per rank, 8 200 in all.  Parity of sampled instances inside the
+    run (rank 0's range) and the exact instruction total of the job (no SKIP in config3: every instance executes all 256)."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FX_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES", "FX_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "config3", "--instances", "4100", "--samples", "128",
+                        "--scaling", scaling, "--parity-instances", "8", "--cpu-seconds", "0", "--no-extras"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
+    total = 4100 if scaling == "strong" else 8200
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["parity"]["parity_ok"]
+    assert d["config"]["instances_total"] == total and d["config"]["per_gpu_instances"] == [total // 2, total // 2]
+    assert len(d["roofline"]["per_gpu_kernel_ms"]) == 2 and min(d["roofline"]["per_gpu_kernel_ms"]) > 0
+    assert abs(d["config"]["instr_per_sample_executed"] - 256.0) < 1e-9
+    # value = executed instructions of BOTH ranks / the slowest rank's time
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 2 - 256.0 * 128 * total * 2) / (256.0 * 128 * total * 2) < 1e-3
+
+
 @pytest.mark.gpu
 def test_tier_note_says_which_tier_runs_and_why(gpu, monkeypatch):
     """fxb_tier_note: the tier in force in words - and, below the translated tier, the reason: a host that finds
