@@ -1465,7 +1465,11 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
 // caller's [sample][channel][all instances] arrays in place (fx_shard.cpp)
 namespace {
 constexpr size_t kPinnedFloats = 512;
-constexpr size_t kPipelinedBytes = (size_t)32 << 20;
+// A host block is cut into pieces (consecutive sample ranges) whose copy-in, kernel and copy-out overlap: one piece per ~3 MiB of
+// PCM each way - what the PCIe link moves in about the 60 us that a piece's launch, prologue and epilogue cost - eight at most
+// (blocks of 32 MiB and more: as since round 2).  A real-time sized block of many instances (32 samples x 65 536 instances = 8 MiB
+// each way) used to go copy -> kernel -> copy in sequence, 458 us; in three pieces ~ 300 (tools/realtime_capacity.py).
+constexpr size_t kBytesPerPiece = (size_t)3 << 20;
 }  // namespace
 
 int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch) {
@@ -1517,9 +1521,9 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
     // Large blocks: copy-in, kernel and copy-out of consecutive pieces overlap.  268 MB each way (tools/host_block_rate.py):
     // pinned caller buffers 6.5 ms instead of 12.7 (both DMA directions at once), pageable ones 9.7 instead of 12.9 (the driver
     // pins them on the fly; a freshly allocated, untouched output buffer costs 2-3 x that in page faults either way).
-    const bool pipelineOff = !knobs_.hostPipeline;
-    if (count * 4 >= kPipelinedBytes && nSamples >= 2 * kHostPieces && !tracksArmed() && !pipelineOff)
-        return processHostPipelined(in, out, nSamples, pitch);
+    const int pieces = (int)std::min<size_t>({(size_t)kHostPieces, (count * 4 + kBytesPerPiece / 2) / kBytesPerPiece, (size_t)nSamples / 2});
+    if (pieces >= 2 && !tracksArmed() && knobs_.hostPipeline)
+        return processHostPipelined(in, out, nSamples, pitch, pieces);
     const size_t rows = (size_t)nSamples * prog_.numChannels, width = (size_t)n_ * 4;
     hipError_t e = pitch == n_ ? hipMemcpyAsync(dIn_, in, count * 4, hipMemcpyHostToDevice, stream_)
                                : hipMemcpy2DAsync(dIn_, width, in, (size_t)pitch * 4, width, rows, hipMemcpyHostToDevice, stream_);
@@ -1542,7 +1546,7 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
 // A large host block in pieces (dIn_ / dOut_ hold the whole block): while the kernel works on piece p, piece p + 1 is on its way
 // in and piece p - 1 on its way out - two copy streams beside the compute stream, ordered by events.  The pieces are
 // consecutive blocks to the kernel: state carries over exactly as between two calls.
-int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64_t pitch) {
+int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64_t pitch, int pieces) {
     if (!copyIn_) {
         hipError_t c = hipStreamCreateWithFlags(&copyIn_, hipStreamNonBlocking);
         if (c == hipSuccess) c = hipStreamCreateWithFlags(&copyOut_, hipStreamNonBlocking);
@@ -1553,7 +1557,7 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
         if (c != hipSuccess) return hipFail(c, "streams for the pipelined host block");
     }
     const size_t ch = (size_t)prog_.numChannels, width = (size_t)n_ * 4;
-    auto lo = [&](int p) { return (int)((int64_t)nSamples * p / kHostPieces); };
+    auto lo = [&](int p) { return (int)((int64_t)nSamples * p / pieces); };
     auto copyIn = [&](int p) {
         const size_t first = (size_t)lo(p) * ch, rows = (size_t)(lo(p + 1) - lo(p)) * ch;
         hipError_t e = pitch == n_ ? hipMemcpyAsync(dIn_ + first * (size_t)n_, in + first * (size_t)n_, rows * width, hipMemcpyHostToDevice, copyIn_)
@@ -1586,7 +1590,7 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
     waitLastLaunch();
     // the block is ONE call to the bookkeeping of control changes and to the lowering (with its real length), not kHostPieces:
     // a translation must not fire between two pieces
-    pendingSamples_ = nSamples / kHostPieces;   // what the kernel is launched with: the class of block lengths is the piece's
+    pendingSamples_ = nSamples / pieces;   // what the kernel is launched with: the class of block lengths is the piece's
     if (controlHeat_ > 0 && --controlHeat_ == 0 && c_.deferred) lowDirty_ = true;
     noteBlockLength(pendingSamples_);
     int rc = ensureLowered();
@@ -1597,8 +1601,8 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
     if (e != hipSuccess) { drain(); return hipFail(e, "H2D"); }
     rc = launch(0);
     if (rc != 0) { drain(); return rc; }
-    for (int p = 0; p < kHostPieces; ++p) {
-        if (p + 1 < kHostPieces) {
+    for (int p = 0; p < pieces; ++p) {
+        if (p + 1 < pieces) {
             if ((e = copyIn(p + 1)) != hipSuccess) { drain(); return hipFail(e, "H2D"); }
             if ((rc = launch(p + 1)) != 0) { drain(); return rc; }
         }

@@ -278,7 +278,7 @@ private:
     static constexpr int kHostPieces = 8;
     hipStream_t copyIn_ = nullptr, copyOut_ = nullptr;
     hipEvent_t evIn_[kHostPieces] = {}, evDone_[kHostPieces] = {};
-    int processHostPipelined(const float* in, float* out, int nSamples, int64_t pitch);
+    int processHostPipelined(const float* in, float* out, int nSamples, int64_t pitch, int pieces);
     unsigned lastGrid_ = 0;
 #ifdef FX_DIAGNOSTICS
   public:

@@ -10,6 +10,7 @@
 //                 values that change the key (eviction), fxb_prepare with and without waiting, a load while builds are queued
 //                 (drainBuilder), destruction with the builder busy
 //   queued        tuner trials with launches queued back to back on device-resident buffers (no sync per block)
+//   hostpipe      a host block cut into pieces on three streams (copy-in, kernel, copy-out overlapping), a launch failing in the middle
 //   shards        a 3-shard handle with two host threads posting: blocks on one, register / counter reads on the other
 //   handles       independent handles on independent threads (process-wide tables: templates, interpreter module, LUTs)
 //   memory        a load whose delay memory cannot be allocated -> FX_E_MEMORY, handle stays usable; 50 create / load / run /
@@ -126,6 +127,36 @@ void scenarioQueued() {
     CHECK(hipStreamDestroy(stream) == hipSuccess);
     CHECK(hipFree(dIn) == hipSuccess);
     CHECK(hipFree(dOut) == hipSuccess);
+}
+
+// a host block large enough to be cut into pieces whose copy-in, kernel and copy-out overlap on three streams
+// (Batch::processHostPipelined): 4 096 instances x 512 samples = 8 MiB each way -> three pieces
+void scenarioHostPipe() {
+    const int64_t N = 4096;
+    const int S = 512;
+    fxb_handle* h = fxb_create(N, 1, 0);
+    CHECK(h != nullptr);
+    if (!h) return;
+    CHECK(fxb_load_text(h, chainProgram(6, true).c_str()) == 1);
+    const std::vector<float> x = ramp((size_t)N * S);
+    for (int it = 0; it < 6; ++it) {
+        std::vector<float> y(x.size(), -7.0f);
+        CHECK(fxb_process_block(h, x.data(), y.data(), S) == 0);
+        CHECK(std::memcmp(x.data(), y.data(), x.size() * 4) == 0);   // every piece came back (the stand-in kernel copies in to out)
+        if (it == 2) CHECK(fxb_set_register(h, "vol", 0.8f) == 0);
+        if (it == 3) CHECK(fxb_process_block(h, x.data(), y.data(), 7) == 0);   // a short block in between: the plain path
+    }
+    // a failing piece: whatever went wrong, no copy may still touch the caller's buffers when the call returns
+    fxstub_fail_launches(1, 1, (int)hipErrorLaunchFailure);
+    {
+        std::vector<float> xin(x), yout(x.size());
+        const int rc = fxb_process_block(h, xin.data(), yout.data(), S);
+        CHECK(rc == FX_E_NODEVICE);
+    }   // (freed here)
+    fxstub_fail_launches(-1, 0, 0);
+    std::vector<float> y(x.size());
+    CHECK(fxb_process_block(h, x.data(), y.data(), S) == 0);
+    fxb_destroy(h);
 }
 
 void scenarioShards() {
@@ -333,7 +364,7 @@ void scenarioImages() {
 
 int main(int argc, char** argv) {
     struct { const char* name; void (*fn)(); } all[] = {
-        {"controls", scenarioControls}, {"queued", scenarioQueued}, {"shards", scenarioShards}, {"handles", scenarioHandles},
+        {"controls", scenarioControls}, {"queued", scenarioQueued}, {"hostpipe", scenarioHostPipe}, {"shards", scenarioShards}, {"handles", scenarioHandles},
         {"memory", scenarioMemory}, {"modules", scenarioModules}, {"images", scenarioImages},
     };
     // arguments: scenario names (none = all) and --kernel-us=N (how long the stand-in kernels take: other interleavings)

@@ -43,7 +43,7 @@ def _host_threads(target, env, runs):
     for args in runs:
         r = subprocess.run([exe] + args, cwd=ROOT, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
         assert r.returncode == 0 and "0 check(s) failed" in r.stdout, "%s %s\n%s\n%s" % (target, args, r.stdout[-2000:], r.stderr[-6000:])
-        for name in ("controls", "queued", "shards", "handles", "memory", "modules", "images"):
+        for name in ("controls", "queued", "hostpipe", "shards", "handles", "memory", "modules", "images"):
             assert "%-9s ok" % name in r.stdout, r.stdout
         assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-6000:]
 

@@ -43,14 +43,18 @@ def percentiles(us):
             "mean_us": round(float(a.mean()), 1), "blocks": int(len(a)), "over_budget": int((a > BUDGET_US).sum())}
 
 
-def measure(torch, A, progs, n, blocks, warm, mode, check=4, config="config5", control="decay"):
-    """one N, one mode ("host": pinned host PCM through fxb_process_block; "device": resident PCM, launch + sync per block)"""
+def measure(torch, A, progs, n, blocks, warm, mode, check=4, config="config5", control="decay", shards=1):
+    """one N, one mode ("host": pinned host PCM through fxb_process_block; "device": resident PCM, launch + sync per block).
+    shards > 1 (host mode): the handle is made of that many shards ON THE SAME GPU (fxb_create_on_devices with the ordinal
+    repeated): each shard has its own host thread and stream and copies its own columns of the caller's [S][N] buffers, so the
+    copy-in of one shard, the kernel of another and the copy-out of a third overlap - the block's PCIe time is no longer
+    serialised around its kernel."""
     import numpy as np
     from pyoracle import Oracle
 
     text = progs.CONFIGS[config]()
     lib = A.load()
-    b = A.Batch(n, 1, 0)
+    b = A.Batch(n, 1, 0) if shards <= 1 else A.Batch(n, 1, devices=[0] * shards)
     if not b.load_text(text):
         raise RuntimeError("load failed: %s" % b.errors())
     ring = [progs.stimulus(n, BLOCK, first_sample=k * BLOCK) for k in range(RING)]
@@ -121,7 +125,7 @@ def measure(torch, A, progs, n, blocks, warm, mode, check=4, config="config5", c
     res = percentiles(times)
     kk = sorted(v for v in kernel if v > 0)
     res.update({
-        "instances": n, "mode": mode, "budget_us": round(BUDGET_US, 3), "within_budget_p999": res["p999_us"] <= BUDGET_US,
+        "instances": n, "mode": mode, "shards_on_the_gpu": shards, "budget_us": round(BUDGET_US, 3), "within_budget_p999": res["p999_us"] <= BUDGET_US,
         "kernel_us_median": round(kk[len(kk) // 2], 1) if kk else None,
         "pcie_GBps_each_way_at_median": round(BLOCK * n * 4 / (res["median_us"] * 1e-6) / 1e9, 2) if mode == "host" else None,
         "realtime_factor_at_median": round(BUDGET_US / res["median_us"], 2),
@@ -142,17 +146,17 @@ def capacity(rows):
     return max(ok) if ok else None
 
 
-def run(torch, A, progs, instances, blocks, warm, modes=("host", "device"), log=None):
+def run(torch, A, progs, instances, blocks, warm, modes=("host", "device"), log=None, shards=1):
     out = {"what": "32-sample blocks at 48 kHz against %.3f us (the reference's own real-time measure, source/main.cpp:99-155); program config5 (512 instructions, "
                    "8192-sample xTRAM); control `decay` takes 0.1 / 0.25 / 0.5 / 1.0 in turn, one step every 8th block; times are call -> output in host memory "
                    "(host mode, pinned buffers) or call -> fxb_sync (device mode), on the caller's clock" % BUDGET_US,
            "budget_us": round(BUDGET_US, 3), "block_samples": BLOCK, "blocks_per_point": blocks, "warmup_blocks": warm, "rows": []}
     for mode in modes:
         for n in instances:
-            r = measure(torch, A, progs, n, blocks, warm, mode)
+            r = measure(torch, A, progs, n, blocks, warm, mode, shards=shards if mode == "host" else 1)
             out["rows"].append(r)
             if log:
-                log("%-6s N=%7d  median %7.1f  p99 %7.1f  p99.9 %7.1f  max %8.1f us  kernel %6.1f us  %s  parity %s" % (
+                log(("%d shards " % shards if shards > 1 and mode == "host" else "") + "%-6s N=%7d  median %7.1f  p99 %7.1f  p99.9 %7.1f  max %8.1f us  kernel %6.1f us  %s  parity %s" % (
                     mode, n, r["median_us"], r["p99_us"], r["p999_us"], r["max_us"], r["kernel_us_median"] or -1,
                     "REAL TIME" if r["within_budget_p999"] else "over budget", "ok" if r["parity_ok"] else "MISMATCH"))
         out["capacity_%s_fed" % mode] = capacity([r for r in out["rows"] if r["mode"] == mode])
@@ -165,6 +169,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--instances", default="4096,8192,16384,32768,65536,98304,131072,196608,262144")
     ap.add_argument("--device-instances", default="", help="instance counts of the device-resident rows (default: the same, plus 393216 and 524288)")
+    ap.add_argument("--shards", default="1", help="host-fed rows: shards on the one GPU, e.g. 1,4 (every value is a sweep of its own)")
+    ap.add_argument("--no-device", action="store_true", help="skip the device-resident rows")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
     import torch  # first: its HIP runtime is the one the library binds to
@@ -174,10 +180,21 @@ def main():
     inst = [int(v) for v in args.instances.split(",") if v]
     dev_inst = [int(v) for v in args.device_instances.split(",") if v] or inst + [393216, 524288]
     log = lambda s: print(s, flush=True)
-    out = run(torch, A, progs, inst, args.blocks, args.warmup, ("host",), log)
-    dev = run(torch, A, progs, dev_inst, args.blocks, args.warmup, ("device",), log)
-    out["rows"] += dev["rows"]
-    out["capacity_device_fed"] = dev["capacity_device_fed"]
+    out = None
+    for k in [int(v) for v in args.shards.split(",") if v]:
+        part = run(torch, A, progs, inst, args.blocks, args.warmup, ("host",), log, shards=k)
+        part["capacity_host_fed_by_shards"] = {str(k): part["capacity_host_fed"]}
+        if out is None:
+            out = part
+        else:
+            out["rows"] += part["rows"]
+            out["capacity_host_fed_by_shards"][str(k)] = part["capacity_host_fed"]
+            out["capacity_host_fed"] = max([v for v in out["capacity_host_fed_by_shards"].values() if v] or [None], key=lambda v: v or 0)
+    out["capacity_device_fed"] = None
+    if not args.no_device:
+        dev = run(torch, A, progs, dev_inst, args.blocks, args.warmup, ("device",), log)
+        out["rows"] += dev["rows"]
+        out["capacity_device_fed"] = dev["capacity_device_fed"]
     out["gpu"] = torch.cuda.get_device_name(0)
     print("largest N within %.3f us at p99.9: host-fed %s, device-resident PCM %s" % (BUDGET_US, out["capacity_host_fed"], out["capacity_device_fed"]))
     if args.json:
