@@ -1465,11 +1465,29 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
 // caller's [sample][channel][all instances] arrays in place (fx_shard.cpp)
 namespace {
 constexpr size_t kPinnedFloats = 512;
-// A host block is cut into pieces (consecutive sample ranges) whose copy-in, kernel and copy-out overlap: one piece per ~3 MiB of
-// PCM each way - what the PCIe link moves in about the 60 us that a piece's launch, prologue and epilogue cost - eight at most
-// (blocks of 32 MiB and more: as since round 2).  A real-time sized block of many instances (32 samples x 65 536 instances = 8 MiB
-// each way) used to go copy -> kernel -> copy in sequence, 458 us; in three pieces ~ 300 (tools/realtime_capacity.py).
-constexpr size_t kBytesPerPiece = (size_t)3 << 20;
+// A host block is cut into P pieces (consecutive sample ranges) whose copy-in, kernel and copy-out overlap on three streams.  With
+// T = the block's PCIe time each way, K its kernel time and a ~ 60 us what every further launch costs (launch, the state rows
+// loaded and stored once more, the gap between dependent launches), a block takes about 2 T / P + max(T, K + P a): more pieces
+// hide more of the copies and lengthen the kernel chain, the best P is about sqrt(2 T / a) = sqrt(bytes / 1.6 MB) at the
+// ~ 53 GB/s this link moves - measured with tools/realtime_capacity.py (32-sample blocks of config5, host-fed): 65 536 instances
+// 458 us in sequence, 348 in 3 pieces; 131 072: 806 / 622 in 6 / see profiles/r05_realtime.json for the pieces this rule picks.
+// Eight at most (blocks of 100 MB and more, as since round 2).
+// Is this host buffer memory the device can address (pinned by hipHostMalloc / hipHostRegister - e.g. a torch pinned tensor)?  Then
+// the kernel reads and writes it in place.  Pageable memory: the runtime says "invalid value" (which must not stay behind as the
+// thread's last error).
+inline bool deviceVisibleHost(const void* host, const void** device) {
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return false;
+    *device = attr.devicePointer;
+    return true;
+}
+
+inline int hostPieces(size_t bytes, int nSamples, int most) {
+    const int p = (int)std::lround(std::sqrt((double)bytes / 1.6e6));
+    return std::max(1, std::min({p, most, nSamples / 2}));
+}
 }  // namespace
 
 int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch) {
@@ -1507,6 +1525,21 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
             return 0;
         }
     }
+    // The caller's buffers are pinned host memory (a real-time host keeps its PCM in such buffers): NO copies at all - the kernel
+    // reads its input from and stores its output to the caller's memory over PCIe, in both directions at once, while it
+    // computes.  One launch, one wait.  Measured (tools/realtime_capacity.py, 32-sample blocks of config5): the staged path's
+    // copy-out is a shader copy (__amd_rocclr_copyBuffer) that slows a kernel running beside it threefold
+    // (profiles/r05_rt_timeline_131072.txt); in place, a block of 131 072 instances takes about what its 16.8 MB each way take the
+    // link.  FX_HOST_PIPELINE=0 keeps the staged copies.
+    if (knobs_.hostPipeline && pitch == n_) {
+        const void *dIn = nullptr, *dOut = nullptr;
+        if (deviceVisibleHost(in, &dIn) && deviceVisibleHost(out, &dOut)) {
+            const int rc = processDevice(static_cast<const float*>(dIn), static_cast<float*>(const_cast<void*>(dOut)), nSamples, stream_);
+            const hipError_t se = hipStreamSynchronize(stream_);   // (also when the call failed: nothing of it may still touch the caller's memory)
+            if (rc != 0) return rc;
+            return se == hipSuccess ? 0 : hipFail(se, "synchronising a block on pinned host buffers");
+        }
+    }
     if (count > ioCap_) {
         (void)hipStreamSynchronize(stream_);
         (void)hipFree(dIn_);
@@ -1521,7 +1554,7 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
     // Large blocks: copy-in, kernel and copy-out of consecutive pieces overlap.  268 MB each way (tools/host_block_rate.py):
     // pinned caller buffers 6.5 ms instead of 12.7 (both DMA directions at once), pageable ones 9.7 instead of 12.9 (the driver
     // pins them on the fly; a freshly allocated, untouched output buffer costs 2-3 x that in page faults either way).
-    const int pieces = (int)std::min<size_t>({(size_t)kHostPieces, (count * 4 + kBytesPerPiece / 2) / kBytesPerPiece, (size_t)nSamples / 2});
+    const int pieces = hostPieces(count * 4, nSamples, kHostPieces);
     if (pieces >= 2 && !tracksArmed() && knobs_.hostPipeline)
         return processHostPipelined(in, out, nSamples, pitch, pieces);
     const size_t rows = (size_t)nSamples * prog_.numChannels, width = (size_t)n_ * 4;

@@ -95,6 +95,7 @@ struct Function { Module* module; std::string name; };
 struct Global {
     std::mutex mu;
     std::map<void*, size_t> allocations;        // device + pinned host
+    std::map<void*, size_t> pinned;             // ... of those, the pinned host ones (start -> bytes)
     size_t used = 0, capacity = (size_t)4 << 30;
     int devices = 1;
     std::vector<std::unique_ptr<Stream>> streams;
@@ -250,8 +251,36 @@ static hipError_t release(void* p) {
 }
 hipError_t hipMalloc(void** p, size_t bytes) { return allocate(p, bytes); }
 hipError_t hipFree(void* p) { return release(p); }
-hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return allocate(p, bytes); }
-hipError_t hipHostFree(void* p) { return release(p); }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+    const hipError_t e = allocate(p, bytes);
+    if (e == hipSuccess) { Global& g = G(); std::lock_guard<std::mutex> lock(g.mu); g.pinned[*p] = bytes; }
+    return e;
+}
+hipError_t hipHostFree(void* p) {
+    { Global& g = G(); std::lock_guard<std::mutex> lock(g.mu); g.pinned.erase(p); }
+    return release(p);
+}
+// pinned host memory (hipHostMalloc above) is device-visible at its own address; anything else the stand-in did not allocate is
+// pageable: "invalid value", as the runtime says
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* ptr) {
+    Global& g = G();
+    std::lock_guard<std::mutex> lock(g.mu);
+    std::memset(attr, 0, sizeof(*attr));
+    for (const auto& a : g.pinned)
+        if (ptr >= a.first && ptr < static_cast<char*>(a.first) + a.second) {
+            attr->type = hipMemoryTypeHost;
+            attr->devicePointer = const_cast<void*>(ptr);
+            attr->hostPointer = const_cast<void*>(ptr);
+            return hipSuccess;
+        }
+    for (const auto& a : g.allocations)
+        if (ptr >= a.first && ptr < static_cast<char*>(a.first) + a.second) {
+            attr->type = hipMemoryTypeDevice;
+            attr->devicePointer = const_cast<void*>(ptr);
+            return hipSuccess;
+        }
+    return fail(hipErrorInvalidValue);
+}
 hipError_t hipMemGetInfo(size_t* freeBytes, size_t* total) {
     Global& g = G();
     std::lock_guard<std::mutex> lock(g.mu);

@@ -146,6 +146,21 @@ void scenarioHostPipe() {
         if (it == 2) CHECK(fxb_set_register(h, "vol", 0.8f) == 0);
         if (it == 3) CHECK(fxb_process_block(h, x.data(), y.data(), 7) == 0);   // a short block in between: the plain path
     }
+    // the caller's buffers in pinned host memory: the kernel works on them in place (no staging copies)
+    {
+        float *px = nullptr, *py = nullptr;
+        CHECK(hipHostMalloc(reinterpret_cast<void**>(&px), x.size() * 4, 0) == hipSuccess);
+        CHECK(hipHostMalloc(reinterpret_cast<void**>(&py), x.size() * 4, 0) == hipSuccess);
+        std::memcpy(px, x.data(), x.size() * 4);
+        const long before = fxstub_kernels_run();
+        CHECK(fxb_process_block(h, px, py, S) == 0);
+        CHECK(fxstub_kernels_run() == before + 1);                   // one launch for the whole block
+        CHECK(std::memcmp(px, py, x.size() * 4) == 0);
+        CHECK(fxb_process_block(h, px, py, 32) == 0);
+        CHECK(fxb_process_block(h, px + 64, py + 64, 32) == 0);     // (any address inside a pinned allocation)
+        CHECK(hipHostFree(px) == hipSuccess);
+        CHECK(hipHostFree(py) == hipSuccess);
+    }
     // a failing piece: whatever went wrong, no copy may still touch the caller's buffers when the call returns
     fxstub_fail_launches(1, 1, (int)hipErrorLaunchFailure);
     {
