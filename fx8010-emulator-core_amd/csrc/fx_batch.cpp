@@ -1465,13 +1465,14 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
 // caller's [sample][channel][all instances] arrays in place (fx_shard.cpp)
 namespace {
 constexpr size_t kPinnedFloats = 512;
-// A host block is cut into P pieces (consecutive sample ranges) whose copy-in, kernel and copy-out overlap on three streams.  With
-// T = the block's PCIe time each way, K its kernel time and a ~ 60 us what every further launch costs (launch, the state rows
-// loaded and stored once more, the gap between dependent launches), a block takes about 2 T / P + max(T, K + P a): more pieces
-// hide more of the copies and lengthen the kernel chain, the best P is about sqrt(2 T / a) = sqrt(bytes / 1.6 MB) at the
-// ~ 53 GB/s this link moves - measured with tools/realtime_capacity.py (32-sample blocks of config5, host-fed): 65 536 instances
-// 458 us in sequence, 348 in 3 pieces; 131 072: 806 / 622 in 6 / see profiles/r05_realtime.json for the pieces this rule picks.
-// Eight at most (blocks of 100 MB and more, as since round 2).
+// A host block of 32 MiB and more is cut into eight pieces (consecutive sample ranges) whose copy-in, kernel and copy-out overlap
+// on three streams (round 2: 268 MB each way in 6.5 instead of 12.7 ms from pinned buffers).  Smaller blocks were tried in pieces in
+// round 5 (by size, 2-8 of them) for real-time callers and gained little - 32 samples x 131 072 instances: 806 -> 622 us - because
+// the runtime's copy-OUT is a shader copy that slows a kernel running beside it threefold (profiles/r05_rt_timeline_131072.txt),
+// and pieces are not timed by the stage tuner; what serves those callers is the in-place path above (pinned buffers: 486 us).
+constexpr size_t kPipelinedBytes = (size_t)32 << 20;
+inline int hostPieces(size_t bytes, int nSamples, int most) { return (bytes >= kPipelinedBytes && nSamples >= 2 * most) ? most : 1; }
+
 // Is this host buffer memory the device can address (pinned by hipHostMalloc / hipHostRegister - e.g. a torch pinned tensor)?  Then
 // the kernel reads and writes it in place.  Pageable memory: the runtime says "invalid value" (which must not stay behind as the
 // thread's last error).
@@ -1482,11 +1483,6 @@ inline bool deviceVisibleHost(const void* host, const void** device) {
     if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return false;
     *device = attr.devicePointer;
     return true;
-}
-
-inline int hostPieces(size_t bytes, int nSamples, int most) {
-    const int p = (int)std::lround(std::sqrt((double)bytes / 1.6e6));
-    return std::max(1, std::min({p, most, nSamples / 2}));
 }
 }  // namespace
 

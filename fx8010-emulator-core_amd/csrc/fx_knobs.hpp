@@ -36,7 +36,7 @@ struct ReleaseKnobs {
     bool stagesTune = true;      // FX_STAGES_TUNE=0: the planner's model decides, nothing is timed
     bool builder = true;         // FX_BUILDER=0: no builder thread
     int xlatePrio = -1;          // FX_XLATE_PRIO: 0 never / 1 always (unstaged) the priority turns; -1: unset
-    bool hostPipeline = true;    // FX_HOST_PIPELINE=0: large host blocks in one piece
+    bool hostPipeline = true;    // FX_HOST_PIPELINE=0: host blocks through staged copies in one piece (no in-place processing of pinned buffers, no pieces)
 
     bool kernelIs(const char* exact) const { return kernel == exact; }
     bool kernelStartsWith(const char* prefix) const { return kernel.compare(0, std::strlen(prefix), prefix) == 0; }

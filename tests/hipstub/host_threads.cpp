@@ -130,10 +130,10 @@ void scenarioQueued() {
 }
 
 // a host block large enough to be cut into pieces whose copy-in, kernel and copy-out overlap on three streams
-// (Batch::processHostPipelined): 4 096 instances x 512 samples = 8 MiB each way -> three pieces
+// (Batch::processHostPipelined): 4 096 instances x 2 048 samples = 32 MiB each way -> eight pieces
 void scenarioHostPipe() {
     const int64_t N = 4096;
-    const int S = 512;
+    const int S = 2048;
     fxb_handle* h = fxb_create(N, 1, 0);
     CHECK(h != nullptr);
     if (!h) return;

@@ -470,9 +470,11 @@ def test_schedules_in_small_host_blocks_on_the_tiers_that_cut_the_block(gpu, tra
 
 @pytest.mark.parametrize("shards", [1, 2])
 def test_large_host_block_in_pinned_buffers_is_processed_in_overlapping_pieces(gpu, shards):
-    """fxb_process_block on pinned caller buffers of >= 32 MB copies, runs and returns the block in eight pieces on three
-    streams (fx_batch.cpp processHostPipelined).  The pieces are consecutive blocks to the kernel: state, delay lines and
-    counters must come out exactly as from one block through pageable buffers, and as the oracle says."""
+    """fxb_process_block on large host blocks: pageable caller buffers go through staged copies in overlapping pieces on three
+    streams (fx_batch.cpp processHostPipelined: 42 MB each way = five pieces), pinned buffers of a single-shard handle are
+    processed in place (no copies), the shards of a multi-shard handle copy their columns of the caller's rows (2-D copies, in
+    pieces).  All of them are consecutive blocks to the kernel: state, delay lines and counters must come out exactly alike, and
+    as the oracle says."""
     torch = pytest.importorskip("torch")
     n, s = 65536, 160 * shards                      # 42 MB each way per shard (a shard copies its columns: 2-D copies)
     text = progs.config3()
@@ -957,3 +959,64 @@ def test_delay_memory_that_cannot_be_allocated(gpu):
     torch.cuda.synchronize()
     after, _ = torch.cuda.mem_get_info(0)
     assert abs(after - base) <= (8 << 20), (base, after)
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_pinned_caller_buffers_are_processed_in_place(gpu, channels, monkeypatch):
+    """A real-time host keeps its PCM in pinned memory; fxb_process_block then runs the kernel on the caller's buffers themselves
+    (hipPointerGetAttributes says they are device-visible: no staging copies, one launch - fx_batch.cpp processHost).  Same words
+    as through pageable buffers (staged copies) and as with FX_HOST_PIPELINE=0 (the knob that turns the in-place path off):
+    uneven blocks from 1 sample up, a slider moving in between, a buffer that starts in the middle of a pinned allocation, input
+    and output in ONE buffer (in place in the caller's sense too), mono and stereo; the mono run against the oracle."""
+    import torch
+    for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_HOST_PIPELINE"):
+        monkeypatch.delenv(k, raising=False)
+    N, cuts = 20000, [0, 1, 33, 65, 600, 640]
+    if channels == 1:
+        text = progs.config5()
+    else:
+        text = ("itramsize 100 \ninput inl 0\ninput inr 1\noutput outl 0\noutput outr 1\ncontrol decay = 0.45\nstatic rd\nstatic a\nstatic b\n"
+                "idelay read, rd, at, 0\nmacs a, inl, rd, decay\nmacs b, inr, a, 0.5\nidelay write, b, at, 0\ninterp outl, outl, 0.25, a\nmacs outr, b, inl, 0.125\nend")
+    S = cuts[-1]
+    x = progs.stimulus(N * channels, S).reshape(S, channels, N)
+    pin = torch.empty((S + 3, channels, N), dtype=torch.float32).pin_memory()
+    xin = pin.numpy()[3:]                       # (a view that does not start at the allocation's base)
+    xin[...] = x
+    pout = torch.empty((S, channels, N), dtype=torch.float32).pin_memory()
+    def run(env, pinned, alias=False):
+        if env:
+            monkeypatch.setenv("FX_HOST_PIPELINE", env)
+        b = gpu.Batch(N, channels, 0)
+        monkeypatch.delenv("FX_HOST_PIPELINE", raising=False)
+        assert b.load_text(text), b.errors()
+        xin[...] = x                                # (the aliasing run below leaves its outputs in this buffer)
+        out = []
+        for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+            if k == 3:
+                b.set_register("decay", 0.3)
+            if pinned and alias:
+                buf = pin.numpy()[3 + lo:3 + hi]
+                buf[...] = x[lo:hi]
+                out.append(b.process_block(buf, buf).copy())
+            elif pinned:
+                out.append(b.process_block(xin[lo:hi], pout.numpy()[lo:hi]).copy())
+            else:
+                out.append(b.process_block(x[lo:hi].copy()))
+        return np.concatenate(out, axis=0), b
+    y_staged, _ = run(None, False)
+    y_place, b = run(None, True)
+    y_alias, _ = run(None, True, alias=True)
+    y_off, _ = run("0", True)
+    assert np.array_equal(bits(y_place), bits(y_staged)) and np.array_equal(bits(y_off), bits(y_staged)) and np.array_equal(bits(y_alias), bits(y_staged))
+    assert b.ood_flags() == 0
+    if channels == 1:
+        for inst in (0, 63, 64, N - 1):
+            o = Oracle(1)
+            assert o.load_text(text)
+            ref = []
+            for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+                if k == 3:
+                    o.set_register("decay", 0.3)
+                ref.append(o.process_block(x[lo:hi, 0, inst].copy()))
+            assert np.array_equal(bits(np.concatenate(ref)), bits(y_place[:, 0, inst])), inst
+            assert b.instruction_counter_i(inst) == o.instruction_counter()
