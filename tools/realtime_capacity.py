@@ -141,9 +141,14 @@ def measure(torch, A, progs, n, blocks, warm, mode, check=4, config="config5", c
 
 
 def capacity(rows):
-    """largest N whose p99.9 block time is within the budget (None when even the smallest is not)"""
-    ok = [r["instances"] for r in rows if r["within_budget_p999"] and r["parity_ok"]]
-    return max(ok) if ok else None
+    """largest N such that it AND every smaller N measured keep their p99.9 block time within the budget (None when even the
+    smallest does not): a lucky row above a failing one does not count"""
+    best = None
+    for r in sorted(rows, key=lambda r: r["instances"]):
+        if not (r["within_budget_p999"] and r["parity_ok"]):
+            break
+        best = r["instances"]
+    return best
 
 
 def run(torch, A, progs, instances, blocks, warm, modes=("host", "device"), log=None, shards=1):
