@@ -38,7 +38,7 @@ def _host_threads(target, env, runs):
     """build tests/hipstub/host_threads.cpp against the library's host sources (csrc/Makefile `tsan` / `stubasan`) and run it"""
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("no ROCm clang on this machine")
-    subprocess.check_call(["make", "-s", "-C", CSRC, target])
+    subprocess.check_call(["make", "-s", "-j6", "-C", CSRC, target])
     exe = os.path.join(CSRC, "build", target, "host_threads")
     for args in runs:
         r = subprocess.run([exe] + args, cwd=ROOT, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)

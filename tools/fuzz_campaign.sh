@@ -1,19 +1,24 @@
 #!/bin/bash
 # The differential fuzzers back to back on the GPU box (gpurun): one summary line per run under gpurun_out/<tag>/campaign.txt.
-#   tools/fuzz_campaign.sh <tag> [scale]      scale multiplies the program counts (default 1)
+#   tools/fuzz_campaign.sh <tag> [scale] [part/parts]     scale multiplies the program counts (default 1); "1/2" runs every second
+#   line starting with the first, "2/2" the others (one gpurun call has 20 minutes)
 TAG=${1:-campaign}
 K=${2:-1}
+PART=${3:-1/1}
+PART_I=${PART%%/*}; PART_N=${PART##*/}; LINE=0
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 run() { # label, env..., command
   local label=$1; shift
+  LINE=$((LINE+1))
+  [ $(( (LINE - 1) % PART_N + 1 )) -eq $PART_I ] || return 0
   local line
   line=$(env "$@" 2>&1 | tail -1 | cut -c1-240)
-  echo "$label: $line" | tee -a "$OUT/campaign.txt"
+  echo "$label: $line" | tee -a "$OUT/campaign_$PART_I.txt"
 }
-: > "$OUT/campaign.txt"
+: > "$OUT/campaign_$PART_I.txt"
 run "sweep default"            timeout -k 10 900 python3 tools/fuzz_sweep.py 2000000 $((6000*K))
 run "sweep inputs x3 + ood"    FX_FUZZ_SCALE=3 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/fuzz_sweep.py 2100000 $((4000*K))
 run "sweep non-finite inputs"  FX_FUZZ_NAN=0.03 FX_FUZZ_OOD=1 timeout -k 10 900 python3 tools/fuzz_sweep.py 2200000 $((4000*K))
