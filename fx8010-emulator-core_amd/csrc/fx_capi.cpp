@@ -192,6 +192,20 @@ int fxb_set_register_track(fxb_handle* h, const char* key, const float* values, 
     return (h && key) ? guardCode(&h->batch.front(), [&] { return h->batch.setRegisterTrack(key, values, n_steps, period, per_instance != 0); }) : 1;
 }
 int fxb_seed_noise_i(fxb_handle* h, int64_t inst, int32_t x1, int32_t x2) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.seedNoiseAt(inst, x1, x2); }) : FX_E_ARG; }
+void* fxb_host_alloc(int64_t bytes) {
+    if (bytes <= 0) { g_createError = "fxb_host_alloc: bytes must be positive"; return nullptr; }
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_createError = std::string("fxb_host_alloc: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    return p;
+}
+void fxb_host_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
 int fxb_process_block(fxb_handle* h, const float* in, float* out, int n) { return h ? guardCode(&h->batch.front(), [&] { return h->batch.processHost(in, out, n); }) : FX_E_ARG; }
 int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n, void* stream) {
     return h ? guardCode(&h->batch.front(), [&] { return h->batch.processDevice(d_in, d_out, n, static_cast<hipStream_t>(stream)); }) : FX_E_ARG;

@@ -239,6 +239,29 @@ public:
     int channels() const { return ch_; }
     fxb_handle* handle() { return h_; }
 
+    // A PCM buffer [nSamples][channels][instances] in pinned host memory (fxb_host_alloc): process() on such buffers runs in place -
+    // no staging copies - which is what a host with a deadline per block wants.  Owns its memory; movable, not copyable.
+    class PcmBuffer {
+    public:
+        PcmBuffer() = default;
+        PcmBuffer(int64_t instances, int channels, int nSamples)
+            : floats_((size_t)instances * (size_t)channels * (size_t)nSamples), p_(static_cast<float*>(fxb_host_alloc((int64_t)floats_ * 4))) {
+            if (!p_) throw std::runtime_error(std::string("FX8010Batch::PcmBuffer: ") + fx_last_create_error());
+        }
+        ~PcmBuffer() { fxb_host_free(p_); }
+        PcmBuffer(PcmBuffer&& o) noexcept : floats_(o.floats_), p_(o.p_) { o.p_ = nullptr; o.floats_ = 0; }
+        PcmBuffer& operator=(PcmBuffer&& o) noexcept { if (this != &o) { fxb_host_free(p_); p_ = o.p_; floats_ = o.floats_; o.p_ = nullptr; o.floats_ = 0; } return *this; }
+        PcmBuffer(const PcmBuffer&) = delete;
+        PcmBuffer& operator=(const PcmBuffer&) = delete;
+        float* data() { return p_; }
+        const float* data() const { return p_; }
+        size_t size() const { return floats_; }
+    private:
+        size_t floats_ = 0;
+        float* p_ = nullptr;
+    };
+    PcmBuffer pcmBuffer(int nSamples) const { return PcmBuffer(n_, ch_, nSamples); }
+
 private:
     int64_t n_;
     int ch_;

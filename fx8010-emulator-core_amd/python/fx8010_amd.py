@@ -35,7 +35,7 @@ SYMBOLS = [
     "fxb_get_register_i", "fxb_set_register_track", "fxb_set_register_array", "fxb_get_register_array", "fxb_seed_noise_i", "fxb_prepare", "fxb_state_size", "fxb_save_state", "fxb_load_state", "fxb_get_tram_i", "fxb_get_cursors_i", "fxb_process_block", "fxb_process_block_dev", "fxb_sync",
     "fxb_instruction_counter", "fxb_instruction_counter_i", "fxb_ood_flags", "fxb_error_count", "fxb_error_desc",
     "fxb_error_row", "fxb_control_count", "fxb_control_at", "fxb_meta_get", "fxb_ready", "fxb_last_error", "fxb_tier_note",
-    "fxb_last_kernel_ms", "fxb_info", "fxb_device_count", "fxb_version",
+    "fxb_last_kernel_ms", "fxb_info", "fxb_device_count", "fxb_version", "fxb_host_alloc", "fxb_host_free",
     "fxp_create", "fxp_destroy", "fxp_load_file", "fxp_load_text", "fxp_num_registers", "fxp_register_name",
     "fxp_register_type", "fxp_register_ioindex", "fxp_register_value", "fxp_num_instructions", "fxp_instruction",
     "fxp_itram_size", "fxp_xtram_size", "fxp_error_count", "fxp_error_desc", "fxp_error_row", "fxp_control_count",
@@ -87,6 +87,7 @@ def load():
     sig("fxb_ood_flags", C.c_uint32, vp); sig("fxb_ready", i32, vp); sig("fxb_last_error", cp, vp); sig("fxb_tier_note", i32, vp, C.c_char_p, i32)
     sig("fxb_last_kernel_ms", f32, vp); sig("fxb_info", i64, vp, i32)
     sig("fxb_device_count", i32); sig("fxb_version", cp)
+    sig("fxb_host_alloc", vp, i64); sig("fxb_host_free", None, vp)
     for pfx in ("fx_", "fxb_", "fxp_"):
         sig(pfx + "error_count", i32, vp); sig(pfx + "error_desc", cp, vp, i32); sig(pfx + "error_row", i32, vp, i32)
         sig(pfx + "control_count", i32, vp); sig(pfx + "control_at", cp, vp, i32)
@@ -108,6 +109,27 @@ def load():
 
 def device_count():
     return int(load().fxb_device_count())
+
+
+class HostBuffer:
+    """float32 numpy array in pinned, device-visible host memory (fxb_host_alloc): blocks on such buffers are processed in place"""
+
+    def __init__(self, shape):
+        self._lib = load()
+        self.shape = tuple(int(v) for v in shape)
+        n = int(np.prod(self.shape))
+        self._p = self._lib.fxb_host_alloc(n * 4)
+        if not self._p:
+            raise RuntimeError(self._lib.fx_last_create_error().decode("latin-1"))
+        self.array = np.ctypeslib.as_array(C.cast(self._p, _f32p), shape=(n,)).reshape(self.shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._lib.fxb_host_free(self._p)
+            self._p = None
+
+    __del__ = close
 
 
 class _Reports:

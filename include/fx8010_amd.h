@@ -189,11 +189,18 @@ int fxb_load_state(fxb_handle* h, const void* buf, int64_t bytes);
  * (reference smallDelayWritePos ... largeDelayReadPos, include/FX8010.h:214-217) */
 int fxb_get_tram_i(fxb_handle* h, int which, int64_t instance, float* out, int n_slots);
 int fxb_get_cursors_i(fxb_handle* h, int64_t instance, int32_t* out4);
-/* S sample periods for all N instances.  Host buffers: synchronous (returns with `out` filled).  Blocks of a few KB are read
- * and written by the kernel in pinned memory of the library (no staged copies); blocks of >= 32 MB are copied in, processed and
- * copied out in overlapping pieces (fastest from pinned caller buffers: both DMA directions at once); everything else is H2D,
- * kernel, D2H in sequence. */
+/* S sample periods for all N instances.  Host buffers: synchronous (returns with `out` filled).  Caller buffers in PINNED host
+ * memory (fxb_host_alloc below, hipHostMalloc / hipHostRegister, a torch pinned tensor) are processed IN PLACE: the kernel reads
+ * and writes them over PCIe, no staging copies, one launch - what a real-time host wants (32-sample blocks of the 512-instruction
+ * reverb: 163 840 instances inside 666.667 us; tools/realtime_capacity.py).  Pageable buffers: blocks of a few KB go through
+ * pinned memory of the library, blocks of >= 32 MB are copied in, processed and copied out in overlapping pieces, everything else
+ * is H2D, kernel, D2H in sequence.  `in` and `out` may be the same buffer. */
 int fxb_process_block(fxb_handle* h, const float* in, float* out, int n_samples);
+/* Pinned, device-visible host memory for PCM buffers - for hosts that do not link the HIP runtime themselves (the reference's
+ * callers keep their audio in plain vectors: include/FX8010.h:57; such a buffer is what to copy it into once per block).
+ * NULL when the allocation fails (fx_last_create_error says why).  Free with fxb_host_free; both are thread-safe. */
+void* fxb_host_alloc(int64_t bytes);
+void fxb_host_free(void* p);
 /* Same with device-resident buffers (hipMalloc'ed, on h's device); asynchronous on `stream`
  * (a hipStream_t, NULL = the handle's own stream).  Pair with fxb_sync(). */
 int fxb_process_block_dev(fxb_handle* h, const float* d_in, float* d_out, int n_samples, void* stream);

@@ -160,6 +160,20 @@ void scenarioHostPipe() {
         CHECK(fxb_process_block(h, px + 64, py + 64, 32) == 0);     // (any address inside a pinned allocation)
         CHECK(hipHostFree(px) == hipSuccess);
         CHECK(hipHostFree(py) == hipSuccess);
+        // ... and the library's own allocator for hosts without the HIP runtime (fxb_host_alloc)
+        float* qx = static_cast<float*>(fxb_host_alloc((int64_t)N * 32 * 4));
+        float* qy = static_cast<float*>(fxb_host_alloc((int64_t)N * 32 * 4));
+        CHECK(qx && qy);
+        if (qx && qy) {
+            std::memcpy(qx, x.data(), (size_t)N * 32 * 4);
+            const long launches = fxstub_kernels_run();
+            CHECK(fxb_process_block(h, qx, qy, 32) == 0);
+            CHECK(fxstub_kernels_run() == launches + 1 && std::memcmp(qx, qy, (size_t)N * 32 * 4) == 0);
+        }
+        fxb_host_free(qx);
+        fxb_host_free(qy);
+        fxb_host_free(nullptr);
+        CHECK(fxb_host_alloc(0) == nullptr && fxb_host_alloc(-5) == nullptr);
     }
     // a failing piece: whatever went wrong, no copy may still touch the caller's buffers when the call returns
     fxstub_fail_launches(1, 1, (int)hipErrorLaunchFailure);

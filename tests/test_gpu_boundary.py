@@ -1020,3 +1020,33 @@ def test_pinned_caller_buffers_are_processed_in_place(gpu, channels, monkeypatch
                 ref.append(o.process_block(x[lo:hi, 0, inst].copy()))
             assert np.array_equal(bits(np.concatenate(ref)), bits(y_place[:, 0, inst])), inst
             assert b.instruction_counter_i(inst) == o.instruction_counter()
+
+
+def test_host_alloc_gives_buffers_that_are_processed_in_place(gpu):
+    """fxb_host_alloc / fxb_host_free: pinned PCM buffers for hosts that do not link the HIP runtime themselves (the reference's
+    callers hold their audio in std::vector<float>, include/FX8010.h:57).  Blocks on them equal blocks on pageable arrays bit for
+    bit, input and output may be one buffer, a freed buffer's size comes back to the device's host-visible pool (200 cycles)."""
+    text = progs.config3()
+    N, S = 5000, 70
+    x = progs.stimulus(N, 2 * S)
+    a = gpu.Batch(N, 1, 0)
+    b = gpu.Batch(N, 1, 0)
+    assert a.load_text(text) and b.load_text(text)
+    bin_, bout = gpu.HostBuffer((S, N)), gpu.HostBuffer((S, N))
+    for k in range(2):
+        ref = a.process_block(x[k * S:(k + 1) * S].copy())
+        bin_.array[...] = x[k * S:(k + 1) * S]
+        if k == 0:
+            got = b.process_block(bin_.array, bout.array)
+        else:
+            got = b.process_block(bin_.array, bin_.array)          # in place in the caller's sense too
+        assert np.array_equal(bits(ref), bits(got)), k
+    assert a.instruction_counter() == b.instruction_counter()
+    bin_.close()
+    bout.close()
+    for _ in range(200):
+        h = gpu.HostBuffer((1024, 1024))
+        h.array[0, 0] = 1.0
+        h.close()
+    with pytest.raises(RuntimeError):
+        gpu.HostBuffer((0,))
