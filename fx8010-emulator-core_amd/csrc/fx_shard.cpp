@@ -71,7 +71,13 @@ void Sharded::stopThreads() {
     }
 }
 
-Sharded::~Sharded() { stopThreads(); }
+Sharded::~Sharded() {
+    stopThreads();
+    // the batches are destroyed on this (the caller's) thread, and a Batch selects its own device to free what it holds: the
+    // caller's current device is restored afterwards (found by the stand-in's multi-device scenario, tests/hipstub)
+    DeviceGuard guard;
+    shards_.clear();
+}
 
 void Sharded::loop(Worker* w) {
     std::unique_lock<std::mutex> lock(w->mu);

@@ -46,6 +46,7 @@ struct Event {
 };
 
 struct Stream {
+    int device = 0;            // the device that was current when the stream was created
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::function<void()>> q;
@@ -89,13 +90,15 @@ struct Stream {
     }
 };
 
-struct Module { std::string tag; };
+struct Module { std::string tag; int device = 0; };   // a module belongs to the device it was loaded on
 struct Function { Module* module; std::string name; };
 
 struct Global {
     std::mutex mu;
     std::map<void*, size_t> allocations;        // device + pinned host
     std::map<void*, size_t> pinned;             // ... of those, the pinned host ones (start -> bytes)
+    std::map<void*, int> deviceOf;              // device allocations: the device that was current at hipMalloc
+    long crossDevice = 0;                       // launches / accesses that mixed devices (each also fails the call)
     size_t used = 0, capacity = (size_t)4 << 30;
     int devices = 1;
     std::vector<std::unique_ptr<Stream>> streams;
@@ -199,6 +202,7 @@ long fxstub_live_allocations(void) { Global& g = G(); std::lock_guard<std::mutex
 long fxstub_module_loads(void) { Global& g = G(); std::lock_guard<std::mutex> l(g.mu); return g.moduleLoads; }
 long fxstub_live_modules(void) { Global& g = G(); std::lock_guard<std::mutex> l(g.mu); return (long)g.modules.size(); }
 long fxstub_kernels_run(void) { return G().kernelsRun.load(); }
+long fxstub_cross_device_errors(void) { Global& g = G(); std::lock_guard<std::mutex> l(g.mu); return g.crossDevice; }
 }
 
 // what fx_kernel_stub.cpp needs: run a host function in stream order
@@ -249,8 +253,15 @@ static hipError_t release(void* p) {
     std::free(p);
     return hipSuccess;
 }
-hipError_t hipMalloc(void** p, size_t bytes) { return allocate(p, bytes); }
-hipError_t hipFree(void* p) { return release(p); }
+hipError_t hipMalloc(void** p, size_t bytes) {
+    const hipError_t e = allocate(p, bytes);
+    if (e == hipSuccess) { Global& g = G(); std::lock_guard<std::mutex> lock(g.mu); g.deviceOf[*p] = tlsDevice; }
+    return e;
+}
+hipError_t hipFree(void* p) {
+    { Global& g = G(); std::lock_guard<std::mutex> lock(g.mu); g.deviceOf.erase(p); }
+    return release(p);
+}
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
     const hipError_t e = allocate(p, bytes);
     if (e == hipSuccess) { Global& g = G(); std::lock_guard<std::mutex> lock(g.mu); g.pinned[*p] = bytes; }
@@ -292,6 +303,7 @@ hipError_t hipMemGetInfo(size_t* freeBytes, size_t* total) {
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
     Global& g = G();
     std::unique_ptr<Stream> st(new Stream);
+    st->device = tlsDevice;
     *s = reinterpret_cast<hipStream_t>(st.get());
     std::lock_guard<std::mutex> lock(g.mu);
     g.streams.push_back(std::move(st));
@@ -441,6 +453,7 @@ hipError_t hipModuleLoadData(hipModule_t* module, const void* image) {
     for (int k = 0; k < 64; ++k) sink = sink + bytes[k];
     (void)sink;
     std::unique_ptr<Module> m(new Module);
+    m->device = tlsDevice;
     *module = reinterpret_cast<hipModule_t>(m.get());
     g.modules.push_back(std::move(m));
     return hipSuccess;
@@ -478,9 +491,36 @@ hipError_t hipModuleLaunchKernel(hipFunction_t fn, unsigned gx, unsigned, unsign
         const long nth = g.launches++;
         if (g.failLaunchFrom >= 0 && nth >= g.failLaunchFrom && nth < g.failLaunchFrom + g.failLaunchCount) return fail((hipError_t)g.failLaunchCode);
         bool found = false;
+        int moduleDevice = 0;
         for (auto& f : g.functions)
-            if (f.get() == reinterpret_cast<Function*>(fn)) { name = f->name; found = true; }
+            if (f.get() == reinterpret_cast<Function*>(fn)) { name = f->name; moduleDevice = f->module->device; found = true; }
         if (!found) return fail(hipErrorInvalidValue);   // (a function of an unloaded module)
+        // a kernel runs on the device its module was loaded on: the stream must be that device's, and so must the calling
+        // thread's current device (a module of device 0 launched for a shard of device 2 is the multi-GPU bug this catches)
+        const int streamDevice = s ? reinterpret_cast<Stream*>(s)->device : tlsDevice;
+        if (moduleDevice != streamDevice || moduleDevice != tlsDevice) { ++g.crossDevice; return fail(hipErrorInvalidResourceHandle); }
+        // ... and every device pointer of its argument block must be memory of that device
+        if (extra) {
+            const void* ptr = nullptr;
+            size_t size = 0;
+            for (int k = 0; extra[k] != HIP_LAUNCH_PARAM_END && k < 8; k += 2) {
+                if (extra[k] == HIP_LAUNCH_PARAM_BUFFER_POINTER) ptr = extra[k + 1];
+                else if (extra[k] == HIP_LAUNCH_PARAM_BUFFER_SIZE) size = *static_cast<size_t*>(extra[k + 1]);
+            }
+            if (ptr && size >= sizeof(AsmArgsView)) {
+                AsmArgsView a;
+                std::memcpy(&a, ptr, sizeof(a));
+                for (const void* q : {(const void*)a.rowTable, (const void*)a.state, (const void*)a.in, (const void*)a.out, (const void*)a.itram, (const void*)a.xtram,
+                                      (const void*)a.lut, (const void*)a.tracks}) {
+                    if (!q) continue;
+                    for (const auto& d : g.deviceOf)
+                        if (q >= d.first && q < static_cast<const char*>(d.first) + g.allocations[d.first] && d.second != moduleDevice) {
+                            ++g.crossDevice;
+                            return fail(hipErrorInvalidValue);
+                        }
+                }
+            }
+        }
     }
     if (gx == 0 || bx == 0 || bx > 1024 || sharedBytes > 160u * 1024u) return fail(hipErrorInvalidValue);
     std::vector<unsigned char> kernarg;

@@ -21,6 +21,7 @@
 // Exit code 0 = every check held (a sanitizer report turns it non-zero by itself).
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -188,9 +189,11 @@ void scenarioHostPipe() {
     fxb_destroy(h);
 }
 
-void scenarioShards() {
+// distinct: the three shards on three different devices (the stand-in has four: FXSTUB_DEVICES, set in main) - every module, stream
+// and buffer of a shard must then be its own device's: the stand-in refuses a launch that mixes devices and counts it
+void shardsOn(const int devices[3]) {
     const int64_t N = 300;
-    const int devices[3] = {0, 0, 0};
+    const long mixed = fxstub_cross_device_errors();
     fxb_handle* h = fxb_create_on_devices(N, 1, devices, 3);
     CHECK(h != nullptr);
     if (!h) return;
@@ -217,7 +220,40 @@ void scenarioShards() {
     ui.join();
     std::vector<float> values((size_t)N);
     CHECK(fxb_get_register_array(h, "mix", values.data()) == 0);
+    // a state image taken from three devices loads back, and into a single-device handle
+    const int64_t bytes = fxb_state_size(h);
+    std::vector<unsigned char> img((size_t)std::max<int64_t>(bytes, 0));
+    CHECK(bytes > 0 && fxb_save_state(h, img.data(), bytes) == 0 && fxb_load_state(h, img.data(), bytes) == 0);
+    int dev = -1;
+    int64_t first = -1, count = -1;
+    CHECK(fxb_shard_info(h, 2, &dev, &first, &count) == 0 && dev == devices[2] && first == 256 && count == 44);
     fxb_destroy(h);
+    CHECK(fxstub_cross_device_errors() == mixed);
+}
+
+void scenarioShards() {
+    const int same[3] = {0, 0, 0}, distinct[3] = {1, 3, 2};
+    shardsOn(same);
+    shardsOn(distinct);
+    // the caller's current device is its own business: a multi-shard handle must leave it alone
+    int before = -1, after = -1;
+    CHECK(hipSetDevice(3) == hipSuccess && hipGetDevice(&before) == hipSuccess);
+    shardsOn(distinct);
+    CHECK(hipGetDevice(&after) == hipSuccess && after == before);
+    CHECK(hipSetDevice(0) == hipSuccess);
+    // fxb_create_sharded by device mask: devices 0, 1 and 3
+    fxb_handle* h = fxb_create_sharded(1000, 1, 0xbull);
+    CHECK(h != nullptr);
+    if (h) {
+        CHECK(fxb_shard_count(h) == 3);
+        CHECK(fxb_load_text(h, chainProgram(5, true).c_str()) == 1);
+        const std::vector<float> x = ramp(1000 * 40);
+        std::vector<float> y(x.size());
+        for (int it = 0; it < 6; ++it) CHECK(fxb_process_block(h, x.data(), y.data(), 40) == 0);
+        CHECK(std::memcmp(x.data(), y.data(), x.size() * 4) == 0);   // every shard's columns came back
+        fxb_destroy(h);
+    }
+    CHECK(fxstub_cross_device_errors() == 0);
 }
 
 void scenarioHandles() {
@@ -392,6 +428,7 @@ void scenarioImages() {
 }  // namespace
 
 int main(int argc, char** argv) {
+    setenv("FXSTUB_DEVICES", "4", 1);   // (read by the stand-in at its first call)
     struct { const char* name; void (*fn)(); } all[] = {
         {"controls", scenarioControls}, {"queued", scenarioQueued}, {"hostpipe", scenarioHostPipe}, {"shards", scenarioShards}, {"handles", scenarioHandles},
         {"memory", scenarioMemory}, {"modules", scenarioModules}, {"images", scenarioImages},

@@ -23,7 +23,7 @@ def test_host_code_under_asan_and_ubsan():
     rt = _runtime()
     if rt is None or not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no ROCm clang with an ASan runtime on this machine")
-    subprocess.check_call(["make", "-s", "-C", CSRC, "asan"])
+    subprocess.check_call(["make", "-s", "-j6", "-C", CSRC, "asan"])
     lib = os.path.join(CSRC, "build", "asan", "libfx8010_amd.so")
     env = dict(os.environ, FX8010_AMD_LIB=lib, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
