@@ -1,10 +1,13 @@
 // fx8010_demo.cpp — console harness over the drop-in class, in the spirit of the reference's
 // source/main.cpp: build a test signal, step a .da program one AUDIOBLOCKSIZE block, change a
 // control every 8 samples, print timing, instruction count, a register, metadata and controls.
-// A second part steps a batch of instances through FX8010Batch and prints its throughput.
+// A second part steps a batch of instances through FX8010Batch and prints its throughput; a third one is the reference's
+// real-time question asked of a batch: AUDIOBLOCKSIZE-sample blocks against the 666.667 us budget the harness prints
+// (source/main.cpp:155), a slider moving every 8th block, PCM in pinned host buffers (processed in place).
 //
 //   make -C fx8010-emulator-core_amd/csrc demo     (plain g++: the header needs no HIP toolchain)
-//   fx8010-emulator-core_amd/host/fx8010_demo program.da [instances]
+//   fx8010-emulator-core_amd/host/fx8010_demo program.da [instances [realtime-blocks [control]]]
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +61,30 @@ int main(int argc, char** argv) {
         const double ms = batch.lastKernelMs();
         const double instr = (double)(batch.getInstructionCounter() - c0);
         std::cout << n << " instances x " << S << " samples: kernel " << ms << " ms, " << instr / (ms * 1e-3) / 1e6 << " emulated MIPS\n";
+        // ---- real time: blocks of AUDIOBLOCKSIZE samples, each done before the next one is due?
+        const int blocks = argc > 3 ? std::atoi(argv[3]) : 0;
+        if (blocks > 0) {
+            const std::string control = argc > 4 ? argv[4] : "volume";
+            const int B = Klangraum::kAudioBlockSize;
+            const double budgetUs = 1e6 * B / Klangraum::kSampleRate;
+            auto pin = batch.pcmBuffer(B), pout = batch.pcmBuffer(B);       // pinned host memory: no staging copies
+            for (int s = 0; s < B; ++s)
+                for (int64_t k = 0; k < n; ++k) pin.data()[(size_t)s * n + k] = ramp[(s + k) % B] * 0.9f;
+            batch.prepare(B);                                                // the code for B-sample blocks exists before the stream starts
+            std::vector<double> us2;
+            for (int k = 0; k < blocks + 100; ++k) {
+                const auto b0 = std::chrono::steady_clock::now();
+                if (k % 8 == 0) batch.setRegisterValue(control, sliders[(k / 8) % 4]);
+                batch.process(pin.data(), pout.data(), B);
+                const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - b0).count();
+                if (k >= 100) us2.push_back(t);                              // (the first hundred: first control touch, clocks)
+            }
+            std::sort(us2.begin(), us2.end());
+            auto at = [&](double q) { return us2[std::min(us2.size() - 1, (size_t)(q * us2.size()))]; };
+            const size_t late = us2.end() - std::upper_bound(us2.begin(), us2.end(), budgetUs);
+            std::cout << "real time: " << n << " instances, " << blocks << " blocks of " << B << " samples from pinned host buffers: median " << at(0.5) << " us, p99 "
+                      << at(0.99) << " us, max " << us2.back() << " us, budget " << budgetUs << " us, " << late << " late (" << batch.tierNote() << ")\n";
+        }
     } catch (const std::exception& e) {
         std::cerr << e.what() << "\n";
         return 1;

@@ -919,7 +919,7 @@ def test_cpp_drop_in_class_harness(gpu):
     pkg = os.path.join(root, "fx8010-emulator-core_amd")
     subprocess.check_call(["make", "-s", "-C", os.path.join(pkg, "csrc"), "demo"])
     prog = os.path.join(pkg, "programs", "config1_shipped.da")
-    out = subprocess.run([os.path.join(pkg, "host", "fx8010_demo"), prog, "4096"], stdout=subprocess.PIPE, text=True, check=True).stdout
+    out = subprocess.run([os.path.join(pkg, "host", "fx8010_demo"), prog, "4096", "300"], stdout=subprocess.PIPE, text=True, check=True).stdout
     lines = out.strip().split("\n")
     pairs = [tuple(float(v) for v in l.split(",")) for l in lines[:32]]
     o = Oracle(1)
@@ -931,6 +931,9 @@ def test_cpp_drop_in_class_harness(gpu):
         ref = o.process_block(np.array([xin], dtype=np.float32))[0]
         assert abs(ref - yout) <= 1e-6 * max(1.0, abs(ref)), i  # printed with 6 significant digits
     assert "64 instructions" in out and "emulated MIPS" in out and "control: volume" in out
+    # the third part: the reference's real-time question (source/main.cpp:155) asked of the batch, PCM in pinned buffers (in place)
+    rt = [l for l in lines if l.startswith("real time:")]
+    assert len(rt) == 1 and "4096 instances, 300 blocks of 32 samples" in rt[0] and " 0 late" in rt[0], out[-600:]
 
 
 def test_wav_front_end(gpu, tmp_path):
