@@ -70,7 +70,7 @@ def test_the_diagnostics_build_is_where_the_knobs_live(tmp_path):
     leaves the release library's untouched"""
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc on this machine")
-    subprocess.check_call(["make", "-s", "-C", CSRC, "diag"])
+    subprocess.check_call(["make", "-s", "-j6", "-C", CSRC, "diag"])
     diag = os.path.join(CSRC, "build", "diag", "libfx8010_amd.so")
     assert "FX_XLATE_LUTPROBE_WRONG_RESULTS" in _fx_names(diag) and b"fxb_diag_read_end_stamps" in open(diag, "rb").read()
     code = ("import sys; sys.path[:0] = [%r, %r]\n"

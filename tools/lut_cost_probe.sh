@@ -4,7 +4,7 @@
 # all.  One call on the GPU box: tools/lut_cost_probe.sh > gpurun_out/lut_cost_probe.txt
 # (the knobs used here exist only in the DIAGNOSTICS build of the library: fx_knobs.hpp)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-make -s -C $ROOT/fx8010-emulator-core_amd/csrc diag || exit 1
+make -s -j8 -C $ROOT/fx8010-emulator-core_amd/csrc diag || exit 1
 export FX8010_AMD_LIB=$ROOT/fx8010-emulator-core_amd/csrc/build/diag/libfx8010_amd.so
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 run() {

@@ -4,7 +4,7 @@
 # The switch (FX_XLATE_LUTWIDE) exists in the DIAGNOSTICS build only; both variants compute the same words (parity checked in
 # every run).  Alternating runs, then the SQ counter pass of each.      tools/lut_wide_ab.sh > gpurun_out/r05_lut_wide_ab.txt
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-make -s -C $ROOT/fx8010-emulator-core_amd/csrc diag || exit 1
+make -s -j8 -C $ROOT/fx8010-emulator-core_amd/csrc diag || exit 1
 export FX8010_AMD_LIB=$ROOT/fx8010-emulator-core_amd/csrc/build/diag/libfx8010_amd.so
 OUT=$ROOT/gpurun_out/lut_wide_ab
 mkdir -p $OUT

@@ -3,7 +3,7 @@
 # DIAGNOSTICS build, FX_XLATE_NT=mask (1 TRAM loads, 2 TRAM stores, 4 PCM loads, 8 PCM stores; the release default for the shard: 3),
 # alternating runs inside one call.     tools/nt_clock_ab.sh > gpurun_out/r05_nt_clock_ab.txt
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-make -s -C $ROOT/fx8010-emulator-core_amd/csrc diag || exit 1
+make -s -j8 -C $ROOT/fx8010-emulator-core_amd/csrc diag || exit 1
 export FX8010_AMD_LIB=$ROOT/fx8010-emulator-core_amd/csrc/build/diag/libfx8010_amd.so
 cd $ROOT
 for round in 1 2; do

@@ -15,7 +15,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, os.path.join(ROOT, "fx8010-emulator-core_amd/python"))
 DIAG = os.path.join(ROOT, "fx8010-emulator-core_amd", "csrc", "build", "diag", "libfx8010_amd.so")
 if not os.path.exists(DIAG):
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fx8010-emulator-core_amd", "csrc"), "diag"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "fx8010-emulator-core_amd", "csrc"), "diag"])
 os.environ["FX8010_AMD_LIB"] = DIAG          # before the binding is imported: it reads the variable once
 os.environ["FX_XLATE_ENDSTAMP"] = "1"
 import numpy as np  # noqa: E402
