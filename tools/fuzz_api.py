@@ -17,7 +17,14 @@ import stress_fuzz  # noqa: E402
 from pyoracle import Oracle  # noqa: E402
 
 
+# FX_FUZZ_NOCOMPARE=1: the call sequences only, nothing compared - for the stand-in build of the library (tests/hipstub: no real
+# kernel runs there), where the point is the host engine under AddressSanitizer (tests/test_host_sanitizers.py)
+NOCOMPARE = os.environ.get("FX_FUZZ_NOCOMPARE") == "1"
+
+
 def same(ref, got):
+    if NOCOMPARE:
+        return True
     ref = np.asarray(ref, dtype=np.float32).reshape(-1)
     got = np.asarray(got, dtype=np.float32).reshape(-1)
     return np.array_equal(ref.view(np.uint32), got.view(np.uint32))  # NaN words included, on every tier
@@ -158,13 +165,13 @@ def run(seed, verbose=False):
             for n in check:
                 for r in names + ["ccr"]:
                     gb, rb = b.get_register_bits_i(r, n), oracles[n].get_register_bits(r)
-                    if gb != rb:
+                    if gb != rb and not NOCOMPARE:
                         print("REGISTER seed %d step %d %s[%d] %08x %08x kernel %d" % (seed, step, r, n, gb, rb, b.info("kernel")))
                         return False
     for n in check:
         if verbose:
             print("counter", n, b.instruction_counter_i(n), oracles[n].instruction_counter())
-        if b.instruction_counter_i(n) != oracles[n].instruction_counter():
+        if b.instruction_counter_i(n) != oracles[n].instruction_counter() and not NOCOMPARE:
             print("COUNTER seed %d instance %d" % (seed, n))
             return False
     return True
