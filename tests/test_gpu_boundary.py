@@ -966,7 +966,7 @@ def test_pinned_caller_buffers_are_processed_in_place(gpu, channels, monkeypatch
     """A real-time host keeps its PCM in pinned memory; fxb_process_block then runs the kernel on the caller's buffers themselves
     (hipPointerGetAttributes says they are device-visible: no staging copies, one launch - fx_batch.cpp processHost).  Same words
     as through pageable buffers (staged copies) and as with FX_HOST_PIPELINE=0 (the knob that turns the in-place path off):
-    uneven blocks from 1 sample up, a slider moving in between, a buffer that starts in the middle of a pinned allocation, input
+    uneven blocks from 1 sample up, a slider moving in between, a control schedule inside a block, a buffer that starts in the middle of a pinned allocation, input
     and output in ONE buffer (in place in the caller's sense too), mono and stereo; the mono run against the oracle."""
     import torch
     for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_HOST_PIPELINE"):
@@ -992,8 +992,10 @@ def test_pinned_caller_buffers_are_processed_in_place(gpu, channels, monkeypatch
         xin[...] = x                                # (the aliasing run below leaves its outputs in this buffer)
         out = []
         for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
-            if k == 3:
+            if k == 2:
                 b.set_register("decay", 0.3)
+            if k == 3:                                  # a schedule inside the longest block (applied by the generated loop itself)
+                b.set_register_track("decay", np.array([0.2, 0.5, 0.1, 0.4], dtype=np.float32), 100)
             if pinned and alias:
                 buf = pin.numpy()[3 + lo:3 + hi]
                 buf[...] = x[lo:hi]
@@ -1015,8 +1017,13 @@ def test_pinned_caller_buffers_are_processed_in_place(gpu, channels, monkeypatch
             assert o.load_text(text)
             ref = []
             for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
-                if k == 3:
+                if k == 2:
                     o.set_register("decay", 0.3)
+                if k == 3:
+                    for t, v in enumerate((0.2, 0.5, 0.1, 0.4)):
+                        o.set_register("decay", v)
+                        ref.append(o.process_block(x[lo + 100 * t:(lo + 100 * (t + 1) if t < 3 else hi), 0, inst].copy()))
+                    continue
                 ref.append(o.process_block(x[lo:hi, 0, inst].copy()))
             assert np.array_equal(bits(np.concatenate(ref)), bits(y_place[:, 0, inst])), inst
             assert b.instruction_counter_i(inst) == o.instruction_counter()
