@@ -69,7 +69,8 @@ def test_host_logic_and_error_paths_under_asan_without_a_device():
 def test_random_host_call_sequences_under_asan_without_a_device():
     """tools/fuzz_api.py - random programs x random host call sequences: blocks of 1-40 samples, broadcast / per-instance / array
     register writes, control schedules (broadcast and per instance, up to five per block), noise seeds, reads, fxb_prepare, the
-    whole state through an image into a NEW handle - through the batch engine under AddressSanitizer + UBSan, single handles and
+    whole state through an image into a NEW handle, PCM in pageable arrays or in pinned buffers of the library (processed in place,
+    half of the blocks with input and output in ONE buffer) - through the batch engine under AddressSanitizer + UBSan, single handles and
     two-shard handles, with nothing compared (FX_FUZZ_NOCOMPARE: the stand-in kernel computes nothing; on the GPU the same
     sequences are compared with the oracle word for word).  What is under test is the host's memory discipline on paths only
     call SEQUENCES reach: rows that come and go, schedules re-armed, code cached and evicted, images loaded into fresh handles."""
@@ -81,7 +82,7 @@ def test_random_host_call_sequences_under_asan_without_a_device():
     base = {k: v for k, v in os.environ.items() if not k.startswith("FX_")}
     base.update(FX8010_AMD_LIB=lib, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                 FX_FUZZ_NOCOMPARE="1")
-    for extra, first, count in (({}, 7000, 120), ({"FX_FUZZ_SHARDS": "2"}, 7100, 50), ({"FX_FUZZ_WILD": "1", "FX_BUILDER": "0"}, 7200, 40)):
+    for extra, first, count in (({}, 7000, 120), ({"FX_FUZZ_SHARDS": "2"}, 7100, 50), ({"FX_FUZZ_WILD": "1", "FX_BUILDER": "0"}, 7200, 40), ({"FX_FUZZ_PINNED": "1"}, 7300, 60)):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_api.py"), str(first), str(count)], cwd=ROOT, env=dict(base, **extra),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0 and "failures []" in r.stdout, r.stdout[-6000:]

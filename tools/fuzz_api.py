@@ -31,6 +31,7 @@ def same(ref, got):
 
 
 WILD = os.environ.get("FX_FUZZ_WILD") == "1"  # register values beyond [-1, 1] (state that breaks the bounded-row class)
+PINNED = os.environ.get("FX_FUZZ_PINNED") == "1"  # PCM in pinned host buffers (fxb_host_alloc): blocks are processed in place, half of them with in == out
 
 
 def value(rng):
@@ -57,6 +58,18 @@ def run(seed, verbose=False):
         oracles[n] = o
     x = P.stimulus(N, 1200)
     pos = 0
+    pin_in = A.HostBuffer((40, N)) if PINNED else None
+    pin_out = A.HostBuffer((40, N)) if PINNED else None
+
+    def process(handle, xs):
+        if not PINNED:
+            return handle.process_block(xs)
+        S = xs.shape[0]
+        pin_in.array[:S] = xs
+        if rng.integers(0, 2):
+            return handle.process_block(pin_in.array[:S], pin_in.array[:S]).copy()
+        return handle.process_block(pin_in.array[:S], pin_out.array[:S]).copy()
+
     names = ["c", "r0", "r1", "r%d" % (n_regs - 1), "out"]
     if verbose:
         print(text)
@@ -105,7 +118,7 @@ def run(seed, verbose=False):
                 plans.append((str(name), period, vals))
                 if verbose:
                     print("  track", name, "period", period, "steps", steps, "per-instance" if vals.ndim == 2 else "broadcast", "S", S)
-            y = b.process_block(xs)
+            y = process(b, xs)
             if verbose:
                 for name, period, vals in plans:
                     print("   ", name, "schedule for instance", check[0], [float(v if vals.ndim == 1 else v[check[0]]) for v in vals],
@@ -127,7 +140,7 @@ def run(seed, verbose=False):
             S = int(rng.choice([1, 3, 8, 16, 40]))
             xs = x[pos:pos + S]
             pos += S
-            y = b.process_block(xs)
+            y = process(b, xs)
             for n in check:
                 ref = oracles[n].process_block(xs[:, n].copy())
                 if oracles[n].ood_flags():
