@@ -12,6 +12,7 @@
 #include "fx_batch.hpp"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -1484,6 +1485,31 @@ inline bool deviceVisibleHost(const void* host, const void** device) {
     *device = attr.devicePointer;
     return true;
 }
+
+// ... the whole of [host, host + bytes) inside ONE pinned mapping: the runtime's own record of the allocation the address belongs
+// to; where it keeps none for registered memory, both ends pinned with one address offset between them.  A caller that registered
+// part of a buffer takes the staged copies.
+inline bool deviceVisibleRange(const void* host, size_t bytes, const void** device) {
+    if (!deviceVisibleHost(host, device)) return false;
+    if (bytes <= 1) return true;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void*>(*device)) == hipSuccess && base && size) {
+        const char *lo = static_cast<const char*>(base), *at = static_cast<const char*>(*device);
+        return at >= lo && bytes <= size && static_cast<size_t>(at - lo) <= size - bytes;
+    }
+    (void)hipGetLastError();
+    const void* last = nullptr;
+    if (!deviceVisibleHost(static_cast<const char*>(host) + (bytes - 1), &last)) return false;
+    return static_cast<const char*>(last) - static_cast<const char*>(*device) == static_cast<std::ptrdiff_t>(bytes - 1);
+}
+
+// in == out is fine in place (an instance reads its sample before it writes it, and no other instance touches that word); ranges
+// that overlap in any other way need the whole input read before the first output is written: the staged copies do that.
+inline bool overlapButNotEqual(const void* a, const void* b, size_t bytes) {
+    const char *x = static_cast<const char*>(a), *y = static_cast<const char*>(b);
+    return x != y && x < y + bytes && y < x + bytes;
+}
 }  // namespace
 
 int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch) {
@@ -1529,7 +1555,8 @@ int Batch::processHost(const float* in, float* out, int nSamples, int64_t pitch)
     // link.  FX_HOST_PIPELINE=0 keeps the staged copies.
     if (knobs_.hostPipeline && pitch == n_) {
         const void *dIn = nullptr, *dOut = nullptr;
-        if (deviceVisibleHost(in, &dIn) && deviceVisibleHost(out, &dOut)) {
+        if (!overlapButNotEqual(in, out, count * 4) && deviceVisibleRange(in, count * 4, &dIn) &&
+            (static_cast<const void*>(out) == in ? (dOut = dIn, true) : deviceVisibleRange(out, count * 4, &dOut))) {
             const int rc = processDevice(static_cast<const float*>(dIn), static_cast<float*>(const_cast<void*>(dOut)), nSamples, stream_);
             const hipError_t se = hipStreamSynchronize(stream_);   // (also when the call failed: nothing of it may still touch the caller's memory)
             if (rc != 0) return rc;

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -99,6 +100,7 @@ struct Global {
     std::map<void*, size_t> pinned;             // ... of those, the pinned host ones (start -> bytes)
     std::map<void*, int> deviceOf;              // device allocations: the device that was current at hipMalloc
     long crossDevice = 0;                       // launches / accesses that mixed devices (each also fails the call)
+    std::atomic<long> badPcm{0};                // launches whose PCM was not wholly device-addressable, or overlapped without being one buffer
     size_t used = 0, capacity = (size_t)4 << 30;
     int devices = 1;
     std::vector<std::unique_ptr<Stream>> streams;
@@ -183,7 +185,30 @@ void runAsmKernel(const std::string& name, const std::vector<unsigned char>& ker
     if (a.stages && a.nStages > 1)
         for (int k = 0; k < a.nStages * 8; ++k) sink = sink + a.stages[k];
     if (a.state && a.nPad > 0) { a.state[0] = a.state[0]; a.state[(size_t)a.nPad - 1] = a.state[(size_t)a.nPad - 1]; }
-    if (a.in && a.out && count) std::memcpy(a.out, a.in, count * sizeof(float));   // "out = in": data does flow through a launch
+    if (a.in && a.out && count) {
+        // the PCM of a launch: wholly inside memory the device can address (a device allocation, pinned host memory - a real GPU
+        // faults on anything else), and either one buffer or two that do not overlap (instances read and write sample by sample)
+        const size_t bytes = count * sizeof(float);
+        const char *pi = reinterpret_cast<const char*>(a.in), *po = reinterpret_cast<const char*>(a.out);
+        bool ok = pi == po || pi + bytes <= po || po + bytes <= pi;
+        {
+            std::lock_guard<std::mutex> lock(g.mu);
+            for (const char* p : {pi, po}) {
+                bool inside = false;
+                for (const auto& m : g.allocations) inside = inside || (p >= static_cast<char*>(m.first) && p + bytes <= static_cast<char*>(m.first) + m.second);
+                for (const auto& m : g.pinned) inside = inside || (p >= static_cast<char*>(m.first) && p + bytes <= static_cast<char*>(m.first) + m.second);
+                ok = ok && inside;
+            }
+        }
+        if (!ok) {
+            g.badPcm.fetch_add(1);
+            if (std::getenv("FXSTUB_ABORT_ON_BAD_PCM")) {   // (drivers that do not read the counter: the API fuzzer)
+                std::fprintf(stderr, "hip stub: a launch on PCM the device cannot address, or on overlapping input and output ranges\n");
+                std::abort();
+            }
+        }
+        else if (pi != po) std::memcpy(a.out, a.in, bytes);   // "out = in": data does flow through a launch
+    }
     (void)sink;
     g.kernelsRun.fetch_add(1);
 }
@@ -202,6 +227,7 @@ long fxstub_live_allocations(void) { Global& g = G(); std::lock_guard<std::mutex
 long fxstub_module_loads(void) { Global& g = G(); std::lock_guard<std::mutex> l(g.mu); return g.moduleLoads; }
 long fxstub_live_modules(void) { Global& g = G(); std::lock_guard<std::mutex> l(g.mu); return (long)g.modules.size(); }
 long fxstub_kernels_run(void) { return G().kernelsRun.load(); }
+long fxstub_bad_pcm_launches(void) { return G().badPcm.load(); }
 long fxstub_cross_device_errors(void) { Global& g = G(); std::lock_guard<std::mutex> l(g.mu); return g.crossDevice; }
 }
 
@@ -271,6 +297,22 @@ hipError_t hipHostFree(void* p) {
     { Global& g = G(); std::lock_guard<std::mutex> lock(g.mu); g.pinned.erase(p); }
     return release(p);
 }
+// caller memory pinned after the fact: device-visible like hipHostMalloc's, not the stand-in's to free
+hipError_t hipHostRegister(void* p, size_t bytes, unsigned) {
+    if (!p || !bytes) return fail(hipErrorInvalidValue);
+    Global& g = G();
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (g.pinned.count(p)) return fail(hipErrorHostMemoryAlreadyRegistered);
+    g.pinned[p] = bytes;
+    return hipSuccess;
+}
+hipError_t hipHostUnregister(void* p) {
+    Global& g = G();
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (!g.pinned.count(p) || g.allocations.count(p)) return fail(hipErrorHostMemoryNotRegistered);
+    g.pinned.erase(p);
+    return hipSuccess;
+}
 // pinned host memory (hipHostMalloc above) is device-visible at its own address; anything else the stand-in did not allocate is
 // pageable: "invalid value", as the runtime says
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* ptr) {
@@ -290,6 +332,18 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* ptr)
             attr->devicePointer = const_cast<void*>(ptr);
             return hipSuccess;
         }
+    return fail(hipErrorInvalidValue);
+}
+hipError_t hipMemGetAddressRange(hipDeviceptr_t* base, size_t* size, hipDeviceptr_t ptr) {
+    Global& g = G();
+    std::lock_guard<std::mutex> lock(g.mu);
+    for (const auto* m : {&g.pinned, &g.allocations})
+        for (const auto& a : *m)
+            if (static_cast<char*>(ptr) >= static_cast<char*>(a.first) && static_cast<char*>(ptr) < static_cast<char*>(a.first) + a.second) {
+                *base = a.first;
+                *size = a.second;
+                return hipSuccess;
+            }
     return fail(hipErrorInvalidValue);
 }
 hipError_t hipMemGetInfo(size_t* freeBytes, size_t* total) {

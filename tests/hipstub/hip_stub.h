@@ -16,6 +16,7 @@ long fxstub_live_allocations(void);
 long fxstub_module_loads(void);
 long fxstub_live_modules(void);
 long fxstub_kernels_run(void);
+long fxstub_bad_pcm_launches(void);        /* launches whose PCM buffers were not wholly device-addressable, or overlapped without being one buffer */
 long fxstub_cross_device_errors(void);     /* launches that mixed devices: a module, a stream, the current device or a buffer of another device */
 #ifdef __cplusplus
 }

@@ -159,6 +159,29 @@ void scenarioHostPipe() {
         CHECK(std::memcmp(px, py, x.size() * 4) == 0);
         CHECK(fxb_process_block(h, px, py, 32) == 0);
         CHECK(fxb_process_block(h, px + 64, py + 64, 32) == 0);     // (any address inside a pinned allocation)
+        // ranges that overlap without being one buffer, and buffers only part of which is pinned: the staged copies (the whole
+        // input is read before the first output is written; the kernel never sees memory it cannot address)
+        {
+            std::memcpy(px, x.data(), x.size() * 4);
+            CHECK(fxb_process_block(h, px, px + N, 32) == 0);                                  // output one sample period behind the input
+            CHECK(std::memcmp(px + N, x.data(), (size_t)N * 32 * 4) == 0);
+            std::memcpy(px, x.data(), x.size() * 4);
+            CHECK(fxb_process_block(h, px + 5 * N, px, 32) == 0);                              // ... five in front of it
+            CHECK(std::memcmp(px, x.data() + 5 * N, (size_t)N * 32 * 4) == 0);
+            CHECK(fxb_process_block(h, px, px, 32) == 0);                                      // one buffer: in place
+            std::vector<float> half(x.begin(), x.begin() + (size_t)N * 64), back((size_t)N * 64, -3.0f);
+            CHECK(hipHostRegister(half.data(), (size_t)N * 32 * 4, 0) == hipSuccess);           // the first 32 sample periods only
+            CHECK(hipHostRegister(back.data(), back.size() * 4, 0) == hipSuccess);
+            long launches = fxstub_kernels_run();
+            CHECK(fxb_process_block(h, half.data(), back.data(), 32) == 0);                    // inside the registration: in place
+            CHECK(fxstub_kernels_run() == launches + 1 && std::memcmp(half.data(), back.data(), (size_t)N * 32 * 4) == 0);
+            CHECK(fxb_process_block(h, half.data(), back.data(), 64) == 0);                    // beyond it: staged
+            CHECK(std::memcmp(half.data(), back.data(), half.size() * 4) == 0);
+            CHECK(fxb_process_block(h, half.data() + (size_t)N * 16, back.data(), 32) == 0);   // straddling its end
+            CHECK(std::memcmp(half.data() + (size_t)N * 16, back.data(), (size_t)N * 32 * 4) == 0);
+            CHECK(hipHostUnregister(half.data()) == hipSuccess && hipHostUnregister(back.data()) == hipSuccess);
+            CHECK(fxstub_bad_pcm_launches() == 0);
+        }
         CHECK(hipHostFree(px) == hipSuccess);
         CHECK(hipHostFree(py) == hipSuccess);
         // ... and the library's own allocator for hosts without the HIP runtime (fxb_host_alloc)

@@ -1029,6 +1029,54 @@ def test_pinned_caller_buffers_are_processed_in_place(gpu, channels, monkeypatch
             assert b.instruction_counter_i(inst) == o.instruction_counter()
 
 
+def test_overlapping_and_partly_pinned_buffers_take_the_staged_copies(gpu, monkeypatch):
+    """The in-place path is for buffers the kernel can work on sample by sample: one buffer (in == out) or two that do not
+    overlap, each WHOLLY inside one pinned mapping.  An output range shifted against the input by a few sample periods would be
+    overwritten while other wavefronts still read it, and a buffer only the front of which is registered would fault the GPU at its
+    first unpinned page: both take the staged copies (fx_batch.cpp processHost: overlapButNotEqual, deviceVisibleRange), so the
+    words are those of pageable buffers.  The reference's caller owns one float per call (/root/reference/include/FX8010.h:57);
+    blocks and their aliasing rules are this library's, written in include/fx8010_amd.h."""
+    import torch
+    for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_HOST_PIPELINE"):
+        monkeypatch.delenv(k, raising=False)
+    N, S, text = 20000, 48, progs.config5()
+    x = progs.stimulus(N, S).reshape(S, 1, N)
+    def fresh():
+        b = gpu.Batch(N, 1, 0)
+        assert b.load_text(text), b.errors()
+        return b
+    want = fresh().process_block(x.copy()).copy()
+    pin = torch.empty((S + 7, 1, N), dtype=torch.float32).pin_memory().numpy()
+    for shift_in, shift_out in ((0, 1), (5, 0), (0, 7), (2, 2)):       # output behind the input, in front of it, ..., one buffer
+        pin[...] = 0
+        pin[shift_in:shift_in + S] = x
+        got = fresh().process_block(pin[shift_in:shift_in + S], pin[shift_out:shift_out + S]).copy()
+        assert np.array_equal(bits(got), bits(want)), (shift_in, shift_out)
+    cudart = torch.cuda.cudart()
+    if not hasattr(cudart, "cudaHostRegister"):
+        pytest.skip("this torch does not expose hipHostRegister")
+    page = 4096
+    raw = np.zeros(2 * S * N * 4 + 2 * page, dtype=np.uint8)
+    base = (raw.ctypes.data + page - 1) // page * page
+    buf = np.frombuffer(raw, dtype=np.float32, count=2 * S * N, offset=base - raw.ctypes.data).reshape(2 * S, 1, N)
+    out = np.zeros((S, 1, N), dtype=np.float32)
+    registered = (S * N * 4) // page * page                              # the front of the buffer: a little less than S sample periods
+    assert int(cudart.cudaHostRegister(base, registered, 0)) == 0
+    try:
+        for lo in (0, S // 2, S):                                          # ends just past the registration, straddles its end, wholly outside
+            buf[...] = 0
+            buf[lo:lo + S] = x
+            got = fresh().process_block(buf[lo:lo + S], out).copy()
+            assert np.array_equal(bits(got), bits(want)), lo
+        # wholly inside it (and the output pinned as well): in place, the same words
+        pout = torch.empty((S // 2, 1, N), dtype=torch.float32).pin_memory().numpy()
+        buf[:S] = x
+        got = fresh().process_block(buf[:S // 2], pout).copy()
+        assert np.array_equal(bits(got), bits(want[:S // 2]))
+    finally:
+        assert int(cudart.cudaHostUnregister(base)) == 0
+
+
 def test_host_alloc_gives_buffers_that_are_processed_in_place(gpu):
     """fxb_host_alloc / fxb_host_free: pinned PCM buffers for hosts that do not link the HIP runtime themselves (the reference's
     callers hold their audio in std::vector<float>, include/FX8010.h:57).  Blocks on them equal blocks on pageable arrays bit for

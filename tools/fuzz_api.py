@@ -31,7 +31,7 @@ def same(ref, got):
 
 
 WILD = os.environ.get("FX_FUZZ_WILD") == "1"  # register values beyond [-1, 1] (state that breaks the bounded-row class)
-PINNED = os.environ.get("FX_FUZZ_PINNED") == "1"  # PCM in pinned host buffers (fxb_host_alloc): blocks are processed in place, half of them with in == out
+PINNED = os.environ.get("FX_FUZZ_PINNED") == "1"  # PCM in pinned host buffers (fxb_host_alloc): blocks are processed in place (in == out among them); overlapping input and output ranges take the staged copies
 
 
 def value(rng):
@@ -58,15 +58,22 @@ def run(seed, verbose=False):
         oracles[n] = o
     x = P.stimulus(N, 1200)
     pos = 0
-    pin_in = A.HostBuffer((40, N)) if PINNED else None
+    pin_in = A.HostBuffer((44, N)) if PINNED else None
     pin_out = A.HostBuffer((40, N)) if PINNED else None
 
     def process(handle, xs):
         if not PINNED:
             return handle.process_block(xs)
         S = xs.shape[0]
+        how = rng.integers(0, 4)
+        if how == 2:      # the output a few sample periods behind the input in one buffer: overlapping ranges take the staged copies
+            pin_in.array[:S] = xs
+            return handle.process_block(pin_in.array[:S], pin_in.array[3:3 + S]).copy()
+        if how == 3:      # ... in front of it
+            pin_in.array[4:4 + S] = xs
+            return handle.process_block(pin_in.array[4:4 + S], pin_in.array[:S]).copy()
         pin_in.array[:S] = xs
-        if rng.integers(0, 2):
+        if how == 1:
             return handle.process_block(pin_in.array[:S], pin_in.array[:S]).copy()
         return handle.process_block(pin_in.array[:S], pin_out.array[:S]).copy()
 
