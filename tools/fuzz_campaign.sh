@@ -14,8 +14,15 @@ run() { # label, env..., command
   local label=$1; shift
   LINE=$((LINE+1))
   [ $(( (LINE - 1) % PART_N + 1 )) -eq $PART_I ] || return 0
-  local line
-  line=$(env "$@" 2>&1 | tail -1 | cut -c1-240)
+  local line log="$OUT/run_${PART_I}_$LINE.log"
+  # (each run is bounded by its own `timeout`; the box takes 7 minutes without output for a hang, and a fuzzer prints one line
+  # at its end: a heartbeat beside it says which run is on and for how long)
+  ( while sleep 60; do echo "$(date +%T) $label running" >> "$OUT/heartbeat_$PART_I.txt"; done ) &
+  local beat=$!
+  env "$@" > "$log" 2>&1
+  kill $beat 2>/dev/null; wait $beat 2>/dev/null
+  line=$(tail -1 "$log" | cut -c1-240)
+  rm -f "$log"
   echo "$label: $line" | tee -a "$OUT/campaign_$PART_I.txt"
 }
 : > "$OUT/campaign_$PART_I.txt"
