@@ -195,7 +195,9 @@ int fxb_get_cursors_i(fxb_handle* h, int64_t instance, int32_t* out4);
  * reverb: 163 840 instances inside 666.667 us; tools/realtime_capacity.py).  Pageable buffers: blocks of a few KB go through
  * pinned memory of the library, blocks of >= 32 MB are copied in, processed and copied out in overlapping pieces, everything else
  * is H2D, kernel, D2H in sequence.  `in` and `out` may be the same buffer; buffers that overlap in any other way, and buffers only
- * part of which is pinned, take the staged copies (the whole input is read before the first output is written). */
+ * part of which is pinned, take the staged copies (the whole input is read before the first output is written; a buffer that
+ * straddles the end of a hipHostRegister range is refused by the runtime's copy itself: FX_E_NODEVICE with its message;
+ * the handle stays usable). */
 int fxb_process_block(fxb_handle* h, const float* in, float* out, int n_samples);
 /* Pinned, device-visible host memory for PCM buffers - for hosts that do not link the HIP runtime themselves (the reference's
  * callers keep their audio in plain vectors: include/FX8010.h:57; such a buffer is what to copy it into once per block).

@@ -124,6 +124,13 @@ def measure(torch, A, progs, n, blocks, warm, mode, check=4, config="config5", c
         ok = ok and b.instruction_counter_i(inst) == o.instruction_counter()
     res = percentiles(times)
     kk = sorted(v for v in kernel if v > 0)
+    # what the slider costs: the blocks that start with a control write beside the others
+    moved = [t for k, t in zip(range(warm, total), times) if k % SLIDER_EVERY == 0]
+    plain = [t for k, t in zip(range(warm, total), times) if k % SLIDER_EVERY != 0]
+    if moved and plain:
+        pm, pp = percentiles(moved), percentiles(plain)
+        res.update({"control_blocks": {"median_us": pm["median_us"], "p99_us": pm["p99_us"], "max_us": pm["max_us"], "blocks": pm["blocks"]},
+                    "other_blocks": {"median_us": pp["median_us"], "p99_us": pp["p99_us"], "p999_us": pp["p999_us"], "max_us": pp["max_us"], "blocks": pp["blocks"]}})
     res.update({
         "instances": n, "mode": mode, "shards_on_the_gpu": shards, "budget_us": round(BUDGET_US, 3), "within_budget_p999": res["p999_us"] <= BUDGET_US,
         "kernel_us_median": round(kk[len(kk) // 2], 1) if kk else None,
@@ -163,7 +170,9 @@ def run(torch, A, progs, instances, blocks, warm, modes=("host", "device"), log=
             if log:
                 log(("%d shards " % shards if shards > 1 and mode == "host" else "") + "%-6s N=%7d  median %7.1f  p99 %7.1f  p99.9 %7.1f  max %8.1f us  kernel %6.1f us  %s  parity %s" % (
                     mode, n, r["median_us"], r["p99_us"], r["p999_us"], r["max_us"], r["kernel_us_median"] or -1,
-                    "REAL TIME" if r["within_budget_p999"] else "over budget", "ok" if r["parity_ok"] else "MISMATCH"))
+                    "REAL TIME" if r["within_budget_p999"] else "over budget", "ok" if r["parity_ok"] else "MISMATCH")
+                    + ("  (blocks that move the slider: median %.1f, the others %.1f, p99.9 %.1f)" % (
+                        r["control_blocks"]["median_us"], r["other_blocks"]["median_us"], r["other_blocks"]["p999_us"]) if "control_blocks" in r else ""))
         out["capacity_%s_fed" % mode] = capacity([r for r in out["rows"] if r["mode"] == mode])
     return out
 
