@@ -1,11 +1,12 @@
 #!/bin/bash
 # The differential fuzzers back to back on the GPU box (gpurun): one summary line per run under gpurun_out/<tag>/campaign.txt.
 #   tools/fuzz_campaign.sh <tag> [scale] [part/parts]     scale multiplies the program counts (default 1); "1/2" runs every second
-#   line starting with the first, "2/2" the others (one gpurun call has 20 minutes)
+#   line starting with the first, "2/2" the others (one gpurun call has 20 minutes); "L:3,9,37" runs those lines of the list below
 TAG=${1:-campaign}
 K=${2:-1}
 PART=${3:-1/1}
 PART_I=${PART%%/*}; PART_N=${PART##*/}; LINE=0
+case "$PART" in L:*) PICK=",${PART#L:},"; PART_I=$(echo "${PART#L:}" | tr , _);; *) PICK="";; esac   # "L:3,9,37": those lines only
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -13,7 +14,8 @@ cd "$ROOT"
 run() { # label, env..., command
   local label=$1; shift
   LINE=$((LINE+1))
-  [ $(( (LINE - 1) % PART_N + 1 )) -eq $PART_I ] || return 0
+  if [ -n "$PICK" ]; then case "$PICK" in *",$LINE,"*) ;; *) return 0;; esac
+  else [ $(( (LINE - 1) % PART_N + 1 )) -eq $PART_I ] || return 0; fi
   local line log="$OUT/run_${PART_I}_$LINE.log"
   # (each run is bounded by its own `timeout`; the box takes 7 minutes without output for a hang, and a fuzzer prints one line
   # at its end: a heartbeat beside it says which run is on and for how long)
