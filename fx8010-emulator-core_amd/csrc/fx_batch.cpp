@@ -141,6 +141,15 @@ int Batch::afterLoad(bool ok) {
     // property of the program, valid until the next load
     intrinsicLane_.assign(prog_.regs.size(), 0);
     readByProgram_.assign(prog_.regs.size(), 0);
+    declared_.assign(prog_.regs.size(), 0);
+    for (const std::string& name : prog_.controls) {
+        const int r = prog_.findRegister(name);
+        if (r >= 0) declared_[(size_t)r] = 1;
+    }
+    hotControl_.assign(prog_.regs.size(), 0);   // (nothing has moved since THIS load)
+    leanActive_ = leanPending_ = false;
+    leanStale_ = controlMode_;
+    leanKey_.clear();
     if (!prog_.instrs.empty()) {   // (also after a load that failed: its registers and instructions have been appended, as in the reference)
         const Lowered probe = lowerProgram(prog_, hostValue_, std::vector<uint8_t>(prog_.regs.size(), 0), 1, false, 1);
         for (size_t r = 0; r < probe.rowOfReg.size() && r < intrinsicLane_.size(); ++r) intrinsicLane_[r] = probe.rowOfReg[r] >= 0;
@@ -364,7 +373,8 @@ std::string Batch::codeKeyFor(const std::vector<uint8_t>& forced, int blockClass
     // (the release knobs are fixed for the life of the handle - fx_knobs.hpp ReleaseKnobs - and so not part of the key)
     for (size_t r = 0; r < hostValue_.size(); ++r) {
         const bool f = r < forced.size() && forced[r];
-        const uint32_t w = f ? 0x7fc0f0f0u : bitsOf(hostValue_[r]);
+        // (a register no instruction reads as an operand: its value lives in its state row and cannot reach the code)
+        const uint32_t w = f ? 0x7fc0f0f0u : (readByProgram((int)r) ? bitsOf(hostValue_[r]) : 0x7fc0f0f1u);
         k.push_back(f ? 1 : 0);
         k.append(reinterpret_cast<const char*>(&w), 4);
     }
@@ -1028,11 +1038,7 @@ void Batch::markControls() {
 
 bool Batch::readByProgram(int reg) const { return reg >= 0 && (size_t)reg < readByProgram_.size() && readByProgram_[(size_t)reg] != 0; }
 
-bool Batch::declaredControl(int reg) const {
-    if (reg < 0) return false;
-    const std::string& name = prog_.regs[(size_t)reg].name;
-    return std::find(prog_.controls.begin(), prog_.controls.end(), name) != prog_.controls.end();
-}
+bool Batch::declaredControl(int reg) const { return reg >= 0 && (size_t)reg < declared_.size() && declared_[(size_t)reg] != 0; }
 
 int Batch::setRegister(const std::string& key, float v) {
     (void)hipSetDevice(device_);
@@ -1042,6 +1048,10 @@ int Batch::setRegister(const std::string& key, float v) {
     if (tracked(r) || intrinsicLane(r)) {
         // the register lives in a row whatever the host does (a schedule, or the program writes it): the fill below is all there is to do
     } else if (forcedLane_[r]) {
+        if (controlMode_ && declaredControl(r) && !hotControl_[r]) {   // a control that had its row for company starts moving itself
+            coldSetChanged();
+            hotControl_[r] = 1;
+        }
         // a row from an earlier write.  One that only per-instance writes asked for is given back now that every instance holds
         // the same value again (the register file does not grow with every register a host has ever touched) - unless it is a
         // moving control, whose next change should stay a fill
@@ -1056,6 +1066,8 @@ int Batch::setRegister(const std::string& key, float v) {
         if (declaredControl(r)) {
             controlMode_ = true;
             markControls();
+            coldSetChanged();
+            hotControl_[r] = 1;
         }
         forcedLane_[r] = 1;
         lowDirty_ = true;
@@ -1082,6 +1094,7 @@ int Batch::setRegisterAt(const std::string& key, int64_t inst, float v) {
     if (inst < 0 || inst >= n_) return fail(FX_E_ARG, "instance out of range");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
     waitLastLaunch();
+    if (coldControl(r)) coldSetChanged();
     if (!forcedLane_[r] && !intrinsicLane(r) && readByProgram(r)) {  // (the row is valid, see setRegister; the next lowering keeps the register per-lane)
         forcedLane_[r] = 1;
         lowDirty_ = true;
@@ -1099,6 +1112,7 @@ int Batch::setRegisterArray(const std::string& key, const float* values) {
     if (!values) return fail(FX_E_ARG, "null buffer");
     if (!dState_) return fail(FX_E_NOTREADY, "no program loaded");
     waitLastLaunch();
+    if (coldControl(r)) coldSetChanged();
     if (!forcedLane_[r] && !intrinsicLane(r) && readByProgram(r)) {  // from now on a per-instance row (every lane is overwritten below)
         forcedLane_[r] = 1;
         lowDirty_ = true;
@@ -1146,11 +1160,82 @@ int Batch::seedNoiseAt(int64_t inst, int32_t x1, int32_t x2) {
 
 bool Batch::tracked(int reg) const { return std::find(trackRegs_.begin(), trackRegs_.end(), reg) != trackRegs_.end(); }
 
-std::vector<uint8_t> Batch::laneForced() const {
+std::vector<uint8_t> Batch::laneForcedFull() const {
     std::vector<uint8_t> f = forcedLane_;
     for (int reg : trackRegs_)
         if ((size_t)reg < f.size()) f[(size_t)reg] = 1;
     return f;
+}
+
+// a declared control that has a row only because ANOTHER control moved (markControls): every instance holds hostValue_ of it,
+// and nothing but setRegister / setRegisterAt / setRegisterArray / a schedule / a state image can change that - each of which
+// calls coldSetChanged() first
+bool Batch::coldControl(int reg) const {
+    const size_t r = (size_t)reg;
+    return controlMode_ && reg >= 0 && r < forcedLane_.size() && r < declared_.size() && r < hotControl_.size() && declared_[r] && forcedLane_[r] && !hotControl_[r] &&
+           !laneWritten_[r] && !tracked(reg) && !intrinsicLane(reg);
+}
+
+std::vector<uint8_t> Batch::laneForcedLean() const {
+    std::vector<uint8_t> f = laneForcedFull();
+    for (size_t r = 0; r < f.size(); ++r)
+        if (f[r] && coldControl((int)r)) f[r] = 0;
+    return f;
+}
+
+std::vector<uint8_t> Batch::laneForced() const { return leanActive_ ? laneForcedLean() : laneForcedFull(); }
+
+// the set of cold controls is about to change (or may have): the lean code in force has one of them folded in - back to the
+// full variant (in the cache: it ran until the lean one was adopted) for the next block, and a new lean one is asked for then
+void Batch::coldSetChanged() {
+    if (!controlMode_) return;
+    if (leanActive_) {
+        leanActive_ = false;
+        lowDirty_ = true;
+    }
+    leanPending_ = false;
+    leanStale_ = true;
+}
+
+// Head of a block, code in force and clean: ask the builder thread for the lean variant of the current hot set, or - when it has
+// arrived - make it the code wanted (the lowering that follows finds it in the cache).
+void Batch::leanStep() {
+    if (!controlMode_ || leanActive_ || lowDirty_ || (!leanStale_ && !leanPending_)) return;
+    if (!builderWanted() || c_.key.empty() || !c_.useXlate || c_.deferred || tracksArmed()) return;
+    const std::vector<uint8_t> lean = laneForcedLean();
+    if (lean == laneForcedFull()) {   // every declared control has moved: the full variant is the lean one
+        leanStale_ = leanPending_ = false;
+        return;
+    }
+    const int cls = keyClass();
+    const std::string key = codeKeyFor(lean, cls, false, pickFor(cls));
+    if (leanPending_ && key == leanKey_) {
+        collectBuilt();
+        if (cachedCode(key)) {
+            leanPending_ = false;
+            leanActive_ = true;
+            lowDirty_ = true;
+            ++leanAdoptions_;
+        } else if (!buildPending(key)) {
+            leanPending_ = false;   // (the builder could not make it: the full variant stays)
+        }
+        return;
+    }
+    leanStale_ = false;
+    leanPending_ = false;
+    if (cachedCode(key)) {
+        leanActive_ = true;
+        lowDirty_ = true;
+        ++leanAdoptions_;
+        return;
+    }
+    if (buildFailed(key) && builder_) return;
+    BuildInputs in = buildInputs(key, cls, false);
+    in.forced = lean;
+    in.stagePick = pickFor(cls);
+    requestBuild(std::move(in));
+    leanKey_ = key;
+    leanPending_ = true;
 }
 
 int Batch::setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance, int64_t pitch) {
@@ -1165,6 +1250,7 @@ int Batch::setRegisterTrack(const std::string& key, const float* values, int nSt
     while (slot < trackRegs_.size() && trackRegs_[slot] != r) ++slot;
     if (slot == trackRegs_.size()) {
         if (trackRegs_.size() >= (size_t)kMaxTracks) return fail(FX_E_ARG, "track: at most " + std::to_string(kMaxTracks) + " registers can have schedules");
+        coldSetChanged();
         trackRegs_.push_back(r);
         pendingTracks_.resize(trackRegs_.size());
         lowDirty_ = true;  // the register gets a row of its own and the generated loop the code to re-load it
@@ -1324,6 +1410,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
         if (controlHeat_ > 0 && --controlHeat_ == 0 && c_.deferred) lowDirty_ = true;  // quiet again: translate
         noteLaunchTime();
         noteBlockLength(nSamples);
+        leanStep();
     }
     int rc = ensureLowered();
     if (rc != 0) return rc;
@@ -1777,6 +1864,7 @@ int Batch::loadStateColumns(const uint8_t* image, const SnapshotHeader& hdr, int
     if (e != hipSuccess) return hipFail(e, "snapshot: state rows");
     // what the host knows about the registers follows the image: a register every instance holds the same value of is a
     // broadcast write of that value, any other one a per-instance write (as if the caller had made them)
+    coldSetChanged();
     for (int r = 0; r < hdr.nRegs; ++r) {
         if (tracked(r) || intrinsicLane(r)) continue;
         const uint32_t* row = reinterpret_cast<const uint32_t*>(rows + ((size_t)r * (size_t)hdr.n + (size_t)first) * 4);
@@ -1945,6 +2033,12 @@ int64_t Batch::info(int what) {
         case FXB_INFO_XLATE_CALLED: return c_.useXlate ? c_.called : 0;
         case FXB_INFO_XLATE_BUILDS: return xlateBuilds_;
         case FXB_INFO_XLATE_BACKGROUND_BUILDS: return backgroundBuilds_;
+        case FXB_INFO_CONTROL_ROWS: {
+            if (c_.key.empty() || lowDirty_) return -1;   // (nothing in force yet / about to change)
+            int64_t rows = 0;
+            for (size_t r = 0; r < declared_.size() && r < c_.low.rowOfReg.size(); ++r) rows += declared_[r] && !intrinsicLane((int)r) && c_.low.rowOfReg[r] >= 0;
+            return rows;
+        }
         case FXB_INFO_STAGE_TRIALS: { int64_t n = 0; for (const Tuner& t : tune_) n += t.trials; return n; }
         case FXB_INFO_XLATE_CODE_HASH: return c_.useXlate ? (int64_t)c_.codeHash : 0;
         case FXB_INFO_CODE_CACHE_HITS: return cacheHits_;

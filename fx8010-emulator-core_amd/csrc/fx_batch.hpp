@@ -104,7 +104,9 @@ private:
     int uploadTracks(int nSamples, hipStream_t s);   // translated tier: header + values -> dTracks_
     int processWithTrackFallback(const float* dIn, float* dOut, int nSamples, hipStream_t stream);  // other tiers: cut the block
     bool tracked(int reg) const;
-    std::vector<uint8_t> laneForced() const;      // forcedLane_ plus the trackable registers
+    std::vector<uint8_t> laneForced() const;      // the registers with rows in the code that is wanted now: laneForcedLean() once that variant exists, else laneForcedFull()
+    std::vector<uint8_t> laneForcedFull() const;  // forcedLane_ plus the trackable registers
+    std::vector<uint8_t> laneForcedLean() const;  // ... minus the declared controls that have a row only because another control moved (coldControl)
     int fillRows(const std::vector<uint32_t>& rows, const std::vector<uint32_t>& values);
     bool laneResident(int reg) const;
     bool intrinsicLane(int reg) const;
@@ -220,6 +222,22 @@ private:
     void markControls();
     std::vector<uint8_t> intrinsicLane_, readByProgram_;   // per register, as of the last load
     bool controlMode_ = false;                   // the declared controls have rows (the host has moved one)
+    // Control mode puts EVERY declared control in a row at the first touch of one (one change of code for the panel, built ahead:
+    // no stall).  A row costs what the value folded into the code saves - config5 with `damp` in a row: 100 INTERPs that convert X
+    // and form 1 - X every sample and keep their saturation, +33 % per block - so the controls that actually move ("hot": written
+    // since the load) keep their rows and the others go back into the code: the LEAN variant, built on the builder thread while
+    // the full one runs, adopted at a block boundary (a pointer swap), dropped for the full one (cached) the moment another
+    // control moves.  Same words either way (tests: the knob / control-variant parity tests, tests/hipstub controls scenario).
+    std::vector<uint8_t> declared_;              // per register: a declared control (as of the last load)
+    std::vector<uint8_t> hotControl_;            // ... that the host has written since the load
+    bool leanActive_ = false;                    // the lean variant is the code wanted now
+    bool leanPending_ = false;                   // ... has been asked of the builder thread (leanKey_)
+    bool leanStale_ = false;                     // the set of hot controls has changed since it was last asked for
+    std::string leanKey_;
+    int leanAdoptions_ = 0;
+    bool coldControl(int reg) const;
+    void coldSetChanged();
+    void leanStep();                             // head of a block: ask for / adopt the lean variant
 
     // ---- how many stages (rankStages: the planner's costs; noteLaunchTime: options the model cannot tell apart are measured)
     bool stagingPossible() const { return stagingPossibleGiven(stagingOff_); }

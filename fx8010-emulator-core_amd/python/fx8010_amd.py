@@ -23,7 +23,7 @@ INFO = {
     "num_instructions": 0, "num_registers": 1, "num_lane_regs": 2, "num_uniform_regs": 3, "lds_bytes_per_wg": 4,
     "waves_per_wg": 5, "num_microops": 6, "itram_slots": 7, "xtram_slots": 8, "tram_ops": 9, "multipass": 10,
     "num_shadowed": 11, "num_ccr_live": 12, "device": 13, "grid": 14, "inst_per_lane": 15, "kernel": 16, "num_rows": 17,
-    "xlate_code_bytes": 18, "xlate_inlined": 19, "xlate_called": 20, "xlate_unsaturated": 21, "xlate_valu": 22, "xlate_valu_slow": 23, "xlate_valu_clocks": 24, "xlate_vgpr_constants": 25, "xlate_builds": 26, "code_cache_hits": 27, "code_cached": 28, "xlate_background_builds": 29, "xlate_code_hash": 30, "stage_trials": 31,
+    "xlate_code_bytes": 18, "xlate_inlined": 19, "xlate_called": 20, "xlate_unsaturated": 21, "xlate_valu": 22, "xlate_valu_slow": 23, "xlate_valu_clocks": 24, "xlate_vgpr_constants": 25, "xlate_builds": 26, "code_cache_hits": 27, "code_cached": 28, "xlate_background_builds": 29, "xlate_code_hash": 30, "stage_trials": 31, "control_rows": 32,
 }
 
 # every symbol include/fx8010_amd.h declares (tests check that the library exports them all)

@@ -81,6 +81,58 @@ def scenario_controls_and_code_cache(builder):
     assert b.get_register_i("unused", 7) == np.float32(0.2)
 
 
+def scenario_lean_control_variant():
+    """control mode puts every declared control in a row at the first touch of one (a pointer swap to code built ahead); the
+    controls that have NOT moved go back into the code a few blocks later (the lean variant, from the builder thread, another
+    swap); a second control that starts moving, a per-instance write or a state image brings the full variant back at once -
+    never a translation on the caller's thread (FXB_INFO_CONTROL_ROWS says which variant is in force)"""
+    n = 262144 // 64      # (the plain program, no stages)
+    b = A.Batch(n, 1, 0)
+    assert b.load_text(P.config5()), b.errors()           # controls damp, decay, diff
+    x = P.stimulus(n, 32)
+    b.prepare(32, True)
+    b.process_block(x)
+    assert b.info("control_rows") == 0 and b.info("xlate_builds") == 1
+    def settle(want):
+        for _ in range(3):
+            b.prepare(32, True)                            # (the builder's queue is empty)
+            b.process_block(x)
+        assert b.info("control_rows") == want, (b.info("control_rows"), want)
+    b.set_register("decay", 0.4)
+    b.process_block(x)
+    assert b.info("control_rows") == 3                    # the whole panel, at once
+    settle(1)                                              # ... then only the one that moves
+    hits = b.info("code_cache_hits")
+    for k in range(20):                                    # the slider keeps moving: fills of its row, no change of code
+        b.set_register("decay", 0.1 + 0.01 * k)
+        b.process_block(x)
+    assert b.info("control_rows") == 1 and b.info("code_cache_hits") == hits
+    b.set_register("damp", 0.2)                            # a second control starts moving: the full variant is still there
+    b.process_block(x)
+    assert b.info("control_rows") == 3
+    settle(2)
+    b.set_register_i("diff", 5, 0.55)                      # the cold one gets per-instance values: it needs its row NOW
+    b.process_block(x)
+    assert b.info("control_rows") == 3
+    settle(3)
+    assert b.get_register_i("diff", 5) == np.float32(0.55) and b.get_register_i("diff", 6) == np.float32(0.6)
+    assert b.info("xlate_builds") == 1, b.info("xlate_builds")   # every other build came from the builder thread
+    # a state image into a fresh handle in control mode: whatever was lean is full again until the builder has caught up
+    c = A.Batch(n, 1, 0)
+    assert c.load_text(P.config5())
+    c.process_block(x)
+    c.set_register("decay", 0.4)
+    c.process_block(x)
+    for _ in range(3):
+        c.prepare(32, True)
+        c.process_block(x)
+    assert c.info("control_rows") == 1
+    img = b.save_state()
+    c.load_state(img)
+    c.process_block(x)
+    assert c.info("control_rows") == 3 and c.get_register_i("diff", 5) == np.float32(0.55)
+
+
 def scenario_block_classes():
     """code is generated for a class of block lengths; a host that alternates between two classes translates each once"""
     b = A.Batch(300, 1, 0)
@@ -214,7 +266,8 @@ def main():
     lib = A.load()
     assert "stub" in os.path.abspath(A.LIB_PATH), "run with FX8010_AMD_LIB = the stand-in build (csrc/build/stub)"
     scenarios = [("registers", scenario_registers), ("controls, builder thread", lambda: scenario_controls_and_code_cache(True)),
-                 ("controls, no builder", lambda: scenario_controls_and_code_cache(False)), ("block classes", scenario_block_classes),
+                 ("controls, no builder", lambda: scenario_controls_and_code_cache(False)), ("lean control variant", scenario_lean_control_variant),
+                 ("block classes", scenario_block_classes),
                  ("tiers", scenario_tiers), ("state images", scenario_state_images), ("shards", scenario_shards), ("errors", scenario_errors)]
     wanted = sys.argv[1:]
     for name, fn in scenarios:

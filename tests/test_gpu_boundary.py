@@ -865,6 +865,92 @@ def test_no_release_knob_changes_a_bit(gpu, monkeypatch):
     assert len(seen) >= 4, seen   # the knobs did reach other tiers and builds
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [300, 20000], ids=["staged", "plain"])
+def test_controls_that_stay_put_go_back_into_the_code(gpu, n, monkeypatch):
+    """A host moves ONE slider of config5's three (the reference's harness: setRegisterValue("volume", ...) between blocks,
+    /root/reference/source/main.cpp:107-114).  The first touch switches to code with every declared control in a row (built
+    ahead: a pointer swap); a few blocks later the controls that have not moved are folded back into the code (the lean variant,
+    from the builder thread: a constant X makes an INTERP 16 issue clocks cheaper than a row) - and the full variant comes back
+    at once when a second slider starts moving, when a cold control gets per-instance values or a schedule.  Whatever variant
+    runs, every word equals the oracle's for the same calls; no variant is ever translated on the caller's thread."""
+    for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_BUILDER", "FX_STAGES"):
+        monkeypatch.delenv(k, raising=False)
+    text, S = progs.config5(), 32
+    b = gpu.Batch(n, 1, 0)
+    assert b.load_text(text), b.errors()
+    blocks = 40
+    x = progs.stimulus(n, S * blocks).reshape(blocks, S, n)
+    watch = sorted({0, 5, 63, 64, n // 2, n - 1})
+    oracles = {}
+    for i in watch:
+        oracles[i] = Oracle(1)
+        assert oracles[i].load_text(text)
+
+    def both(name, v, inst=None):
+        if inst is None:
+            b.set_register(name, v)
+            for o in oracles.values():
+                o.set_register(name, v)
+        else:
+            b.set_register_i(name, inst, v)
+            if inst in oracles:
+                oracles[inst].set_register(name, v)
+
+    rows, k = [], 0
+    def step(times=1, settle=False):
+        nonlocal k
+        for _ in range(times):
+            if settle:
+                b.prepare(S, True)      # (the builder thread has finished what it was asked for: the next block can adopt it)
+            y = b.process_block(x[k].copy())
+            for i, o in oracles.items():
+                ref = o.process_block(x[k][:, i].copy())
+                assert np.array_equal(bits(ref), bits(y[:, i])), (k, i, b.info("control_rows"))
+            rows.append(b.info("control_rows"))
+            k += 1
+
+    b.prepare(S, True)
+    step(2)
+    assert rows[-1] == 0
+    both("decay", 0.4)
+    step()
+    assert rows[-1] == 3                                   # the whole panel at the first touch
+    step(3, settle=True)
+    assert rows[-1] == 1                                   # ... then only the slider that moves
+    for v in (0.1, 0.25, 0.5, 1.0, 0.3):                   # (the harness's values, main.cpp:80)
+        both("decay", v)
+        step()
+    assert rows[-1] == 1
+    both("damp", 0.2)                                      # a second slider: its value is folded into the lean code
+    step()
+    assert rows[-1] == 3
+    step(3, settle=True)
+    assert rows[-1] == 2
+    both("diff", 0.55, inst=5)                             # per-instance values for the control that never moved
+    step()
+    assert rows[-1] == 3
+    step(3, settle=True)
+    both("diff", 0.6)                                      # levelled again by a broadcast write: it has moved now, the row stays
+    both("decay", 0.45)
+    step(2)
+    # a schedule inside a block on a control (applied by the generated loop itself)
+    b.set_register_track("damp", np.array([0.3, 0.1], dtype=np.float32), 16)
+    y = b.process_block(x[k].copy())
+    for i, o in oracles.items():
+        o.set_register("damp", 0.3)
+        r0 = o.process_block(x[k][:16, i].copy())
+        o.set_register("damp", 0.1)
+        r1 = o.process_block(x[k][16:, i].copy())
+        assert np.array_equal(bits(np.concatenate([r0, r1])), bits(y[:, i])), i
+    k += 1
+    step(2)
+    assert b.ood_flags() == 0 and b.tier_note().startswith("translated to gfx950 code")
+    for i, o in oracles.items():
+        assert b.instruction_counter_i(i) == o.instruction_counter()
+    assert b.info("xlate_builds") <= 2, b.info("xlate_builds")     # (the first code; the schedule's code)
+
+
 def test_damaged_state_images_are_refused_before_any_address_is_computed(gpu):
     """fxb_load_state reads a header the CALLER supplies (a checkpoint file): every field is validated before it enters pointer
     arithmetic - negative or absurd slot counts (which would make the size check accept a short buffer and the section

@@ -693,7 +693,9 @@ def test_moving_controls_become_rows_once(gpu, monkeypatch, builder):
         rows.append(b.info("num_rows"))
     assert all(t >= 9 for t in tiers), tiers                 # the translated tier on every block
     if builder:
-        assert builds[-1] == 1 and b.info("xlate_background_builds") == 1 and b.info("code_cache_hits") == 1, builds
+        # (the variant with the panel in rows, and - while only `vol` has moved - the lean one with `mix` folded back in:
+        # both from the builder thread, each adopted by a pointer swap; tests/test_gpu_boundary.py has the lean variant's own test)
+        assert builds[-1] == 1 and b.info("xlate_background_builds") in (1, 2) and 1 <= b.info("code_cache_hits") <= 3, (builds, b.info("code_cache_hits"))
     else:
         assert builds[2] == 1 and builds[3] == 2 and builds[-1] == 2, builds   # the first change of vol: one more translation (mix joins it), then none
     assert rows[3] == rows[2] + 2 and rows[-1] == rows[3], rows   # vol and mix; `unused` never gets a row
