@@ -82,7 +82,7 @@ def test_random_host_call_sequences_under_asan_without_a_device():
     base = {k: v for k, v in os.environ.items() if not k.startswith("FX_")}
     base.update(FX8010_AMD_LIB=lib, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                 FX_FUZZ_NOCOMPARE="1", FXSTUB_ABORT_ON_BAD_PCM="1")
-    for extra, first, count in (({}, 7000, 120), ({"FX_FUZZ_SHARDS": "2"}, 7100, 50), ({"FX_FUZZ_WILD": "1", "FX_BUILDER": "0"}, 7200, 40), ({"FX_FUZZ_PINNED": "1"}, 7300, 60)):
+    for extra, first, count in (({}, 7000, 120), ({"FX_FUZZ_SHARDS": "2"}, 7100, 50), ({"FX_FUZZ_WILD": "1", "FX_BUILDER": "0"}, 7200, 40), ({"FX_FUZZ_PINNED": "1"}, 7300, 60), ({"FX_FUZZ_PANEL": "1"}, 7400, 60)):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_api.py"), str(first), str(count)], cwd=ROOT, env=dict(base, **extra),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0 and "failures []" in r.stdout, r.stdout[-6000:]

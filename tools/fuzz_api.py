@@ -34,6 +34,26 @@ WILD = os.environ.get("FX_FUZZ_WILD") == "1"  # register values beyond [-1, 1] (
 PINNED = os.environ.get("FX_FUZZ_PINNED") == "1"  # PCM in pinned host buffers (fxb_host_alloc): blocks are processed in place (in == out among them); overlapping input and output ranges take the staged copies
 
 
+PANEL = os.environ.get("FX_FUZZ_PANEL") == "1"  # three more declared controls in operand positions, and the builder thread waited for before half of the blocks: control variants come and go (all controls in rows / only the ones that have moved / folded in)
+
+
+def with_panel(rng, text):
+    """declare c2, c3, c4 and put them where registers or literals stood as A / X / Y operands of arithmetic instructions"""
+    lines = text.split("\n")
+    out = []
+    for line in lines:
+        parts = line.split(None, 1)
+        if len(parts) == 2 and parts[0] in ("macs", "macsn", "interp", "acc3", "macw", "macwn", "macints", "macintw", "limit", "limitn", "tstneg", "andxor", "macmv") and rng.uniform() < 0.35:
+            ops = [o.strip() for o in parts[1].split(",")]
+            if len(ops) == 4:
+                ops[int(rng.integers(1, 4))] = str(rng.choice(["c2", "c3", "c4"]))
+                line = parts[0] + " " + ", ".join(ops)
+        out.append(line)
+    at = next(i for i, l in enumerate(out) if l.startswith("control c"))
+    out[at + 1:at + 1] = ["control c2 = 0.5", "control c3 = -0.25", "control c4 = 0.125"]
+    return "\n".join(out)
+
+
 def value(rng):
     if WILD and rng.uniform() < 0.3:
         return float(np.float32(rng.choice([2.5, -3.0, 1.0000001, 100.0, 1e30, -1e-40])))
@@ -45,6 +65,8 @@ def run(seed, verbose=False):
     gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
     n_regs = int(rng.integers(3, 30))
     text = gen(rng, int(rng.integers(6, 70)), n_regs)
+    if PANEL:
+        text = with_panel(rng, text)
     N = int(rng.choice([1, 63, 64, 65, 130, 200]))
     check = sorted(set([0, N - 1, N // 2]))
     shards = int(os.environ.get("FX_FUZZ_SHARDS", "1"))   # > 1: the same call sequence through a multi-shard handle (all shards on device 0)
@@ -62,6 +84,8 @@ def run(seed, verbose=False):
     pin_out = A.HostBuffer((40, N)) if PINNED else None
 
     def process(handle, xs):
+        if PANEL and rng.integers(0, 2):
+            handle.prepare(xs.shape[0], True)      # (what the builder thread was asked for is there: the block below may adopt it)
         if not PINNED:
             return handle.process_block(xs)
         S = xs.shape[0]
@@ -77,7 +101,7 @@ def run(seed, verbose=False):
             return handle.process_block(pin_in.array[:S], pin_in.array[:S]).copy()
         return handle.process_block(pin_in.array[:S], pin_out.array[:S]).copy()
 
-    names = ["c", "r0", "r1", "r%d" % (n_regs - 1), "out"]
+    names = ["c", "r0", "r1", "r%d" % (n_regs - 1), "out"] + (["c2", "c3", "c4", "c2", "c"] if PANEL else [])
     if verbose:
         print(text)
         print("N", N, "check", check, "names", names)

@@ -63,4 +63,6 @@ run "benchmark programs"       timeout -k 10 900 python3 tools/stress_scale.py 3
 run "stages"                 timeout -k 10 900 python3 tools/fuzz_stages.py 2000000 $((1500*K))
 run "stages, interpreter off" FX_STAGES=4 timeout -k 10 900 python3 tools/fuzz_sweep.py 2700000 $((1500*K))
 run "api pinned buffers"       FX_FUZZ_PINNED=1 timeout -k 10 900 python3 tools/fuzz_api.py 2500000 $((1500*K))
+run "api control panel"        FX_FUZZ_PANEL=1 timeout -k 10 900 python3 tools/fuzz_api.py 2600000 $((2000*K))
+run "api control panel, interpreter"  FX_FUZZ_PANEL=1 FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_api.py 2700000 $((600*K))
 echo done
