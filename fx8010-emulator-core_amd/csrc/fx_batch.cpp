@@ -147,9 +147,12 @@ int Batch::afterLoad(bool ok) {
         if (r >= 0) declared_[(size_t)r] = 1;
     }
     hotControl_.assign(prog_.regs.size(), 0);   // (nothing has moved since THIS load)
+    lastControlWrite_.assign(prog_.regs.size(), 0);
     leanActive_ = leanPending_ = false;
     leanStale_ = controlMode_;
     leanKey_.clear();
+    leanForced_.clear();
+    leanWant_.clear();
     if (!prog_.instrs.empty()) {   // (also after a load that failed: its registers and instructions have been appended, as in the reference)
         const Lowered probe = lowerProgram(prog_, hostValue_, std::vector<uint8_t>(prog_.regs.size(), 0), 1, false, 1);
         for (size_t r = 0; r < probe.rowOfReg.size() && r < intrinsicLane_.size(); ++r) intrinsicLane_[r] = probe.rowOfReg[r] >= 0;
@@ -412,9 +415,7 @@ void Batch::stashCode() {
     cache_.push_back(std::make_unique<Code>(std::move(c_)));
     c_ = Code();
     if (cache_.size() > kCodeCache) {
-        size_t lru = 0;
-        for (size_t k = 1; k < cache_.size(); ++k)
-            if (cache_[k]->lastUse < cache_[lru]->lastUse) lru = k;
+        const size_t lru = lruVictim();
         waitLastLaunch();
         releaseCode(*cache_[lru]);
         cache_.erase(cache_.begin() + (long)lru);
@@ -657,9 +658,7 @@ void Batch::collectBuilt() {
         c->lastUse = ++useClock_;
         cache_.push_back(std::move(c));
         if (cache_.size() > kCodeCache) {
-            size_t lru = 0;
-            for (size_t k = 1; k < cache_.size(); ++k)
-                if (cache_[k]->lastUse < cache_[lru]->lastUse) lru = k;
+            const size_t lru = lruVictim();
             waitLastLaunch();
             releaseCode(*cache_[lru]);
             cache_.erase(cache_.begin() + (long)lru);
@@ -1048,10 +1047,7 @@ int Batch::setRegister(const std::string& key, float v) {
     if (tracked(r) || intrinsicLane(r)) {
         // the register lives in a row whatever the host does (a schedule, or the program writes it): the fill below is all there is to do
     } else if (forcedLane_[r]) {
-        if (controlMode_ && declaredControl(r) && !hotControl_[r]) {   // a control that had its row for company starts moving itself
-            coldSetChanged();
-            hotControl_[r] = 1;
-        }
+        if (controlMode_ && declaredControl(r)) controlWritten(r);   // (a control that had its row for company starts moving itself: lean code with its value folded in goes)
         // a row from an earlier write.  One that only per-instance writes asked for is given back now that every instance holds
         // the same value again (the register file does not grow with every register a host has ever touched) - unless it is a
         // moving control, whose next change should stay a fill
@@ -1067,7 +1063,7 @@ int Batch::setRegister(const std::string& key, float v) {
             controlMode_ = true;
             markControls();
             coldSetChanged();
-            hotControl_[r] = 1;
+            controlWritten(r);
         }
         forcedLane_[r] = 1;
         lowDirty_ = true;
@@ -1183,10 +1179,10 @@ std::vector<uint8_t> Batch::laneForcedLean() const {
     return f;
 }
 
-std::vector<uint8_t> Batch::laneForced() const { return leanActive_ ? laneForcedLean() : laneForcedFull(); }
+std::vector<uint8_t> Batch::laneForced() const { return leanActive_ ? leanForced_ : laneForcedFull(); }
 
-// the set of cold controls is about to change (or may have): the lean code in force has one of them folded in - back to the
-// full variant (in the cache: it ran until the lean one was adopted) for the next block, and a new lean one is asked for then
+// Something is about to change that the lean code in force (or on order) may have folded in: back to the full variant (in the
+// cache, never evicted while controls have rows: lruVictim) for the next block; a new lean one is asked for then.
 void Batch::coldSetChanged() {
     if (!controlMode_) return;
     if (leanActive_) {
@@ -1197,45 +1193,95 @@ void Batch::coldSetChanged() {
     leanStale_ = true;
 }
 
-// Head of a block, code in force and clean: ask the builder thread for the lean variant of the current hot set, or - when it has
-// arrived - make it the code wanted (the lowering that follows finds it in the cache).
+// a declared control is being written (broadcast): it is hot from now on; lean code that has its old value folded in goes
+void Batch::controlWritten(int reg) {
+    const size_t r = (size_t)reg;
+    if (!controlMode_ || r >= hotControl_.size()) return;
+    hotControl_[r] = 1;
+    lastControlWrite_[r] = sampleClock_;
+    if (leanActive_ && r < leanForced_.size() && !leanForced_[r]) coldSetChanged();
+    else leanStale_ = true;
+}
+
+// Head of a block, code in force and clean.  Controls that have not been written for kCoolSamples sample periods cool down (a
+// slider is at rest most of the time; a preset recall writes the whole panel once); when the set of hot controls differs from
+// the rows of the code in force, the variant for it is asked of the builder thread, and adopted - a pointer swap in the
+// lowering that follows - once it has arrived and is still what is wanted.
 void Batch::leanStep() {
-    if (!controlMode_ || leanActive_ || lowDirty_ || (!leanStale_ && !leanPending_)) return;
+    if (!controlMode_ || lowDirty_) return;
     if (!builderWanted() || c_.key.empty() || !c_.useXlate || c_.deferred || tracksArmed()) return;
-    const std::vector<uint8_t> lean = laneForcedLean();
-    if (lean == laneForcedFull()) {   // every declared control has moved: the full variant is the lean one
-        leanStale_ = leanPending_ = false;
-        return;
+    if (sampleClock_ - lastCoolCheck_ >= kCoolSamples / 8) {
+        lastCoolCheck_ = sampleClock_;
+        for (size_t r = 0; r < hotControl_.size(); ++r)
+            if (hotControl_[r] && sampleClock_ - lastControlWrite_[r] >= kCoolSamples) {
+                hotControl_[r] = 0;
+                leanStale_ = true;
+            }
     }
+    if (!leanStale_ && !leanPending_) return;
     const int cls = keyClass();
-    const std::string key = codeKeyFor(lean, cls, false, pickFor(cls));
-    if (leanPending_ && key == leanKey_) {
-        collectBuilt();
-        if (cachedCode(key)) {
+    const int pick = pickFor(cls);
+    if (leanPending_) {
+        if (codeKeyFor(leanWant_, cls, false, pick) != leanKey_) {   // (a folded value, the class or the stage count has changed meanwhile)
             leanPending_ = false;
-            leanActive_ = true;
+            leanStale_ = true;
+        } else {
+            collectBuilt();
+            if (cachedCode(leanKey_)) {
+                leanPending_ = false;
+                leanForced_ = leanWant_;
+                leanActive_ = true;
+                lowDirty_ = true;
+                ++leanAdoptions_;
+                return;
+            }
+            if (buildPending(leanKey_)) return;
+            leanPending_ = false;   // (the builder could not make it: what runs stays)
+        }
+    }
+    if (!leanStale_) return;
+    leanStale_ = false;
+    const std::vector<uint8_t> full = laneForcedFull(), want = laneForcedLean();
+    if (want == (leanActive_ ? leanForced_ : full)) return;
+    if (want == full) {   // every control with a row is hot again: the full variant is the lean one
+        if (leanActive_) {
+            leanActive_ = false;
             lowDirty_ = true;
-            ++leanAdoptions_;
-        } else if (!buildPending(key)) {
-            leanPending_ = false;   // (the builder could not make it: the full variant stays)
         }
         return;
     }
-    leanStale_ = false;
-    leanPending_ = false;
+    const std::string key = codeKeyFor(want, cls, false, pick);
     if (cachedCode(key)) {
+        leanForced_ = want;
         leanActive_ = true;
         lowDirty_ = true;
         ++leanAdoptions_;
         return;
     }
-    if (buildFailed(key) && builder_) return;
+    if (builder_ && buildFailed(key)) return;
     BuildInputs in = buildInputs(key, cls, false);
-    in.forced = lean;
-    in.stagePick = pickFor(cls);
+    in.forced = want;
+    in.stagePick = pick;
     requestBuild(std::move(in));
+    leanWant_ = want;
     leanKey_ = key;
     leanPending_ = true;
+}
+
+// the cache entry to give up when it is full: the least recently used - but never the full control variant while controls have
+// rows (the code every first touch, per-instance write and state image falls back to without a translation)
+size_t Batch::lruVictim() const {
+    std::string keep;
+    if (controlMode_) {
+        const int cls = keyClass();
+        keep = codeKeyFor(laneForcedFull(), cls, false, pickFor(cls));
+    }
+    size_t lru = cache_.size();
+    for (size_t k = 0; k < cache_.size(); ++k) {
+        if (!keep.empty() && cache_[k]->key == keep) continue;
+        if (lru == cache_.size() || cache_[k]->lastUse < cache_[lru]->lastUse) lru = k;
+    }
+    return lru == cache_.size() ? 0 : lru;
 }
 
 int Batch::setRegisterTrack(const std::string& key, const float* values, int nSteps, int period, bool perInstance, int64_t pitch) {
@@ -1411,6 +1457,7 @@ int Batch::processDevice(const float* dIn, float* dOut, int nSamples, hipStream_
         noteLaunchTime();
         noteBlockLength(nSamples);
         leanStep();
+        sampleClock_ += nSamples;
     }
     int rc = ensureLowered();
     if (rc != 0) return rc;

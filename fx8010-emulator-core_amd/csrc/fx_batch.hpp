@@ -226,18 +226,27 @@ private:
     // no stall).  A row costs what the value folded into the code saves - config5 with `damp` in a row: 100 INTERPs that convert X
     // and form 1 - X every sample and keep their saturation, +33 % per block - so the controls that actually move ("hot": written
     // since the load) keep their rows and the others go back into the code: the LEAN variant, built on the builder thread while
-    // the full one runs, adopted at a block boundary (a pointer swap), dropped for the full one (cached) the moment another
-    // control moves.  Same words either way (tests: the knob / control-variant parity tests, tests/hipstub controls scenario).
+    // the full one runs, adopted at a block boundary (a pointer swap), dropped for the full one (cached, never evicted) the moment
+    // a folded control moves.  Same words either way (tests: the knob / control-variant parity tests, tests/hipstub controls scenario).
+    // A control is hot from a write until it has been left alone for kCoolSamples sample periods (a slider rests most of the
+    // time; a preset recall writes the whole panel once): then its value is folded back in as well.
     std::vector<uint8_t> declared_;              // per register: a declared control (as of the last load)
-    std::vector<uint8_t> hotControl_;            // ... that the host has written since the load
-    bool leanActive_ = false;                    // the lean variant is the code wanted now
-    bool leanPending_ = false;                   // ... has been asked of the builder thread (leanKey_)
-    bool leanStale_ = false;                     // the set of hot controls has changed since it was last asked for
+    std::vector<uint8_t> hotControl_;            // ... that the host has written lately
+    std::vector<int64_t> lastControlWrite_;      // sampleClock_ of that write
+    int64_t sampleClock_ = 0, lastCoolCheck_ = 0;   // sample periods processed by this handle
+    static constexpr int64_t kCoolSamples = 8192;   // 171 ms at 48 kHz
+    bool leanActive_ = false;                    // a lean variant is the code wanted now: laneForced() == leanForced_
+    std::vector<uint8_t> leanForced_;            // its registers with rows
+    bool leanPending_ = false;                   // a lean variant has been asked of the builder thread: leanWant_, leanKey_
+    std::vector<uint8_t> leanWant_;
     std::string leanKey_;
+    bool leanStale_ = false;                     // the set of hot controls may differ from the rows of the code in force / on order
     int leanAdoptions_ = 0;
     bool coldControl(int reg) const;
     void coldSetChanged();
-    void leanStep();                             // head of a block: ask for / adopt the lean variant
+    void controlWritten(int reg);
+    void leanStep();                             // head of a block: cool controls down, ask for / adopt the lean variant
+    size_t lruVictim() const;
 
     // ---- how many stages (rankStages: the planner's costs; noteLaunchTime: options the model cannot tell apart are measured)
     bool stagingPossible() const { return stagingPossibleGiven(stagingOff_); }

@@ -274,8 +274,9 @@ enum {
                                       rows, the lean variant, code for another class of block lengths); FX_BUILDER=0 in the environment turns the thread off */
     FXB_INFO_CONTROL_ROWS = 32     /* declared controls that have a register row in the code in force: 0 until the host moves one (their values are
                                       folded into the code), then all of them (one change of code for the whole panel, generated ahead of time), then
-                                      - a few blocks later, a pointer swap - only the ones that have actually moved since the load (the others go back
-                                      into the code, where a constant is cheaper than a row: e.g. INTERP with a constant X).  Same results in all three. */
+                                      - a few blocks later, a pointer swap - only the ones that have been written lately (within 8192 sample periods;
+                                      the others go back into the code, where a constant is cheaper than a row: e.g. INTERP with a constant X).  Same
+                                      results in all three. */
 };
 int64_t fxb_info(fxb_handle* h, int what);
 /* Which tier runs the program as it stands, in words - "translated to gfx950 code (fx_xlate_v128, 8 stages)", "interpreter

@@ -83,7 +83,7 @@ def scenario_controls_and_code_cache(builder):
 
 def scenario_lean_control_variant():
     """control mode puts every declared control in a row at the first touch of one (a pointer swap to code built ahead); the
-    controls that have NOT moved go back into the code a few blocks later (the lean variant, from the builder thread, another
+    controls that have NOT moved lately go back into the code a few blocks later (the lean variant, from the builder thread, another
     swap); a second control that starts moving, a per-instance write or a state image brings the full variant back at once -
     never a translation on the caller's thread (FXB_INFO_CONTROL_ROWS says which variant is in force)"""
     n = 262144 // 64      # (the plain program, no stages)
@@ -117,6 +117,21 @@ def scenario_lean_control_variant():
     settle(3)
     assert b.get_register_i("diff", 5) == np.float32(0.55) and b.get_register_i("diff", 6) == np.float32(0.6)
     assert b.info("xlate_builds") == 1, b.info("xlate_builds")   # every other build came from the builder thread
+    # controls that are left alone cool down (8192 sample periods): their values go back into the code as well - `diff` keeps
+    # its row while its instances hold different values, and loses it after a broadcast write has levelled them and time has passed
+    for _ in range(8192 // 32 + 40):
+        b.process_block(x)
+    settle(1)
+    b.set_register("diff", 0.6)
+    b.process_block(x)
+    assert b.info("control_rows") in (1, 3)               # (the row was there: a fill)
+    for _ in range(8192 // 32 + 40):
+        b.process_block(x)
+    settle(0)
+    b.set_register("decay", 0.33)                          # ... and the first touch after a rest is the full variant again, at once
+    b.process_block(x)
+    assert b.info("control_rows") == 3
+    assert b.info("xlate_builds") == 1, b.info("xlate_builds")
     # a state image into a fresh handle in control mode: whatever was lean is full again until the builder has caught up
     c = A.Batch(n, 1, 0)
     assert c.load_text(P.config5())
@@ -127,6 +142,8 @@ def scenario_lean_control_variant():
         c.prepare(32, True)
         c.process_block(x)
     assert c.info("control_rows") == 1
+    b.set_register_i("diff", 5, 0.55)
+    b.process_block(x)
     img = b.save_state()
     c.load_state(img)
     c.process_block(x)

@@ -872,14 +872,15 @@ def test_controls_that_stay_put_go_back_into_the_code(gpu, n, monkeypatch):
     /root/reference/source/main.cpp:107-114).  The first touch switches to code with every declared control in a row (built
     ahead: a pointer swap); a few blocks later the controls that have not moved are folded back into the code (the lean variant,
     from the builder thread: a constant X makes an INTERP 16 issue clocks cheaper than a row) - and the full variant comes back
-    at once when a second slider starts moving, when a cold control gets per-instance values or a schedule.  Whatever variant
-    runs, every word equals the oracle's for the same calls; no variant is ever translated on the caller's thread."""
+    at once when a second slider starts moving, when a cold control gets per-instance values or a schedule.  Controls that are
+    left alone for 8192 sample periods cool down and are folded in again.  Whatever variant runs, every word equals the
+    oracle's for the same calls; no control variant is ever translated on the caller's thread."""
     for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_BUILDER", "FX_STAGES"):
         monkeypatch.delenv(k, raising=False)
     text, S = progs.config5(), 32
     b = gpu.Batch(n, 1, 0)
     assert b.load_text(text), b.errors()
-    blocks = 40
+    blocks = 48
     x = progs.stimulus(n, S * blocks).reshape(blocks, S, n)
     watch = sorted({0, 5, 63, 64, n // 2, n - 1})
     oracles = {}
@@ -945,10 +946,23 @@ def test_controls_that_stay_put_go_back_into_the_code(gpu, n, monkeypatch):
         assert np.array_equal(bits(np.concatenate([r0, r1])), bits(y[:, i])), i
     k += 1
     step(2)
+    # controls that are left alone cool down (8192 sample periods without a write): one long block, then their values are folded
+    # in again (`diff` was levelled by its broadcast write) - and the first touch after the rest is a swap once more
+    rest = progs.stimulus(n, 8192 + 64, first_sample=S * blocks)
+    y = b.process_block(rest)
+    for i, o in oracles.items():
+        assert np.array_equal(bits(o.process_block(rest[:, i].copy())), bits(y[:, i])), i
+    step(3, settle=True)
+    assert rows[-1] == 1, rows                             # (`damp` keeps the row its schedule needs: the loop re-loads it by itself)
+    both("decay", 0.2)
+    step()
+    assert rows[-1] == 3
+    step(3, settle=True)
+    assert rows[-1] == 2
     assert b.ood_flags() == 0 and b.tier_note().startswith("translated to gfx950 code")
     for i, o in oracles.items():
         assert b.instruction_counter_i(i) == o.instruction_counter()
-    assert b.info("xlate_builds") <= 2, b.info("xlate_builds")     # (the first code; the schedule's code)
+    assert b.info("xlate_builds") <= 3, b.info("xlate_builds")     # (the first code; the schedule's code; the long block's class of block lengths when staged)
 
 
 def test_damaged_state_images_are_refused_before_any_address_is_computed(gpu):
