@@ -573,7 +573,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import realtime_capacity as rt
                 rows = []
-                for mode, counts in (("host", (98304, 131072, 147456, 163840)), ("device", (262144, 327680, 393216))):
+                for mode, counts in (("host", (131072, 147456, 163840, 180224)), ("device", (393216, 458752, 524288))):
                     for n in counts:
                         r = rt.measure(torch, fx8010_amd, progs, n, 4000, 400, mode)
                         rows.append({k: r[k] for k in ("instances", "mode", "median_us", "p99_us", "p999_us", "max_us", "kernel_us_median", "within_budget_p999",
