@@ -1814,11 +1814,15 @@ int Batch::prepare(int nSamples, bool wait) {
     int rc = ensureLowered();
     if (rc != 0) return rc;
     everLowered_ = true;
+    leanStep();   // (controls have rows and some of them rest: their variant is asked for now)
     if (wait && builder_) {
         std::unique_lock<std::mutex> lock(builder_->mu);
         builder_->cv.wait(lock, [&] { return builder_->running.empty() && builder_->jobs.empty(); });
         lock.unlock();
         collectBuilt();
+        leanStep();   // ... and in force when this returns
+        rc = ensureLowered();
+        if (rc != 0) return rc;
     }
     return 0;
 }

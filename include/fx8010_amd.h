@@ -170,7 +170,8 @@ int fxb_set_register_track(fxb_handle* h, const char* key, const float* values, 
 int fxb_seed_noise_i(fxb_handle* h, int64_t instance, int32_t x1, int32_t x2);
 /* Generate the code blocks of n_samples samples will run, now: the translation (4-9 ms) otherwise falls into the first
  * fxb_process_block* call after a load.  wait != 0: also until the handle's builder thread has finished what follows a first
- * build (the variant with the declared controls in rows; stage counts on trial).  For callers with a deadline per block (the
+ * build (the variant with the declared controls in rows; stage counts on trial; the variant for the controls that rest, which
+ * is then in force on return: FXB_INFO_CONTROL_ROWS).  For callers with a deadline per block (the
  * reference's caller has 667 us, include/FX8010.h:38): load, prepare, then start the stream.  0 or FX_E_*. */
 int fxb_prepare(fxb_handle* h, int n_samples, int wait);
 /* State snapshot.  The reference keeps all DSP state in plain members (include/FX8010.h:162-217, 288-291: register values, output
