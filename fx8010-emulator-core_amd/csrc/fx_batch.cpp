@@ -151,7 +151,7 @@ int Batch::afterLoad(bool ok) {
     leanActive_ = leanPending_ = false;
     leanStale_ = controlMode_;
     leanKey_.clear();
-    leanForced_.clear();
+    leanFolded_.clear();
     leanWant_.clear();
     if (!prog_.instrs.empty()) {   // (also after a load that failed: its registers and instructions have been appended, as in the reference)
         const Lowered probe = lowerProgram(prog_, hostValue_, std::vector<uint8_t>(prog_.regs.size(), 0), 1, false, 1);
@@ -1172,14 +1172,24 @@ bool Batch::coldControl(int reg) const {
            !laneWritten_[r] && !tracked(reg) && !intrinsicLane(reg);
 }
 
-std::vector<uint8_t> Batch::laneForcedLean() const {
+// the controls that could be folded into the code right now
+std::vector<uint8_t> Batch::coldControls() const {
+    std::vector<uint8_t> cold(forcedLane_.size(), 0);
+    for (size_t r = 0; r < cold.size(); ++r) cold[r] = coldControl((int)r);
+    return cold;
+}
+
+// laneForcedFull() minus a set of folded controls.  (The set is remembered, not the result: rows that other registers get
+// meanwhile - a per-instance write, a schedule - must show up in the key of the next lowering; found by the API fuzzer's control
+// panel, seed 2600545.)
+std::vector<uint8_t> Batch::forcedWithout(const std::vector<uint8_t>& folded) const {
     std::vector<uint8_t> f = laneForcedFull();
-    for (size_t r = 0; r < f.size(); ++r)
-        if (f[r] && coldControl((int)r)) f[r] = 0;
+    for (size_t r = 0; r < f.size() && r < folded.size(); ++r)
+        if (folded[r]) f[r] = 0;
     return f;
 }
 
-std::vector<uint8_t> Batch::laneForced() const { return leanActive_ ? leanForced_ : laneForcedFull(); }
+std::vector<uint8_t> Batch::laneForced() const { return leanActive_ ? forcedWithout(leanFolded_) : laneForcedFull(); }
 
 // Something is about to change that the lean code in force (or on order) may have folded in: back to the full variant (in the
 // cache, never evicted while controls have rows: lruVictim) for the next block; a new lean one is asked for then.
@@ -1199,14 +1209,14 @@ void Batch::controlWritten(int reg) {
     if (!controlMode_ || r >= hotControl_.size()) return;
     hotControl_[r] = 1;
     lastControlWrite_[r] = sampleClock_;
-    if (leanActive_ && r < leanForced_.size() && !leanForced_[r]) coldSetChanged();
+    if (leanActive_ && r < leanFolded_.size() && leanFolded_[r]) coldSetChanged();
     else leanStale_ = true;
 }
 
 // Head of a block, code in force and clean.  Controls that have not been written for kCoolSamples sample periods cool down (a
-// slider is at rest most of the time; a preset recall writes the whole panel once); when the set of hot controls differs from
-// the rows of the code in force, the variant for it is asked of the builder thread, and adopted - a pointer swap in the
-// lowering that follows - once it has arrived and is still what is wanted.
+// slider is at rest most of the time; a preset recall writes the whole panel once); when the set of controls that could be
+// folded differs from what the code in force has folded, the variant for it is asked of the builder thread, and adopted - a
+// pointer swap in the lowering that follows - once it has arrived and is still what is wanted.
 void Batch::leanStep() {
     if (!controlMode_ || lowDirty_) return;
     if (!builderWanted() || c_.key.empty() || !c_.useXlate || c_.deferred || tracksArmed()) return;
@@ -1222,14 +1232,14 @@ void Batch::leanStep() {
     const int cls = keyClass();
     const int pick = pickFor(cls);
     if (leanPending_) {
-        if (codeKeyFor(leanWant_, cls, false, pick) != leanKey_) {   // (a folded value, the class or the stage count has changed meanwhile)
+        if (codeKeyFor(forcedWithout(leanWant_), cls, false, pick) != leanKey_) {   // (a folded value, another register's row, the class or the stage count has changed meanwhile)
             leanPending_ = false;
             leanStale_ = true;
         } else {
             collectBuilt();
             if (cachedCode(leanKey_)) {
                 leanPending_ = false;
-                leanForced_ = leanWant_;
+                leanFolded_ = leanWant_;
                 leanActive_ = true;
                 lowDirty_ = true;
                 ++leanAdoptions_;
@@ -1241,18 +1251,18 @@ void Batch::leanStep() {
     }
     if (!leanStale_) return;
     leanStale_ = false;
-    const std::vector<uint8_t> full = laneForcedFull(), want = laneForcedLean();
-    if (want == (leanActive_ ? leanForced_ : full)) return;
-    if (want == full) {   // every control with a row is hot again: the full variant is the lean one
-        if (leanActive_) {
-            leanActive_ = false;
-            lowDirty_ = true;
-        }
+    const std::vector<uint8_t> want = coldControls();
+    const bool none = std::find(want.begin(), want.end(), (uint8_t)1) == want.end();
+    if (leanActive_ ? want == leanFolded_ : none) return;
+    if (none) {   // every control with a row is hot again: the full variant is the lean one
+        leanActive_ = false;
+        lowDirty_ = true;
         return;
     }
-    const std::string key = codeKeyFor(want, cls, false, pick);
+    const std::vector<uint8_t> forced = forcedWithout(want);
+    const std::string key = codeKeyFor(forced, cls, false, pick);
     if (cachedCode(key)) {
-        leanForced_ = want;
+        leanFolded_ = want;
         leanActive_ = true;
         lowDirty_ = true;
         ++leanAdoptions_;
@@ -1260,7 +1270,7 @@ void Batch::leanStep() {
     }
     if (builder_ && buildFailed(key)) return;
     BuildInputs in = buildInputs(key, cls, false);
-    in.forced = want;
+    in.forced = forced;
     in.stagePick = pick;
     requestBuild(std::move(in));
     leanWant_ = want;
@@ -1783,6 +1793,8 @@ int Batch::processHostPipelined(const float* in, float* out, int nSamples, int64
     pendingSamples_ = nSamples / pieces;   // what the kernel is launched with: the class of block lengths is the piece's
     if (controlHeat_ > 0 && --controlHeat_ == 0 && c_.deferred) lowDirty_ = true;
     noteBlockLength(pendingSamples_);
+    leanStep();
+    sampleClock_ += nSamples;
     int rc = ensureLowered();
     if (rc != 0) return rc;
     piecewise_ = true;

@@ -104,9 +104,10 @@ private:
     int uploadTracks(int nSamples, hipStream_t s);   // translated tier: header + values -> dTracks_
     int processWithTrackFallback(const float* dIn, float* dOut, int nSamples, hipStream_t stream);  // other tiers: cut the block
     bool tracked(int reg) const;
-    std::vector<uint8_t> laneForced() const;      // the registers with rows in the code that is wanted now: laneForcedLean() once that variant exists, else laneForcedFull()
+    std::vector<uint8_t> laneForced() const;      // the registers with rows in the code that is wanted now: laneForcedFull(), minus the controls a lean variant in force has folded in
     std::vector<uint8_t> laneForcedFull() const;  // forcedLane_ plus the trackable registers
-    std::vector<uint8_t> laneForcedLean() const;  // ... minus the declared controls that have a row only because another control moved (coldControl)
+    std::vector<uint8_t> coldControls() const;    // the declared controls that have a row only for company and could be folded into the code (coldControl)
+    std::vector<uint8_t> forcedWithout(const std::vector<uint8_t>& folded) const;   // laneForcedFull() minus those
     int fillRows(const std::vector<uint32_t>& rows, const std::vector<uint32_t>& values);
     bool laneResident(int reg) const;
     bool intrinsicLane(int reg) const;
@@ -235,9 +236,9 @@ private:
     std::vector<int64_t> lastControlWrite_;      // sampleClock_ of that write
     int64_t sampleClock_ = 0, lastCoolCheck_ = 0;   // sample periods processed by this handle
     static constexpr int64_t kCoolSamples = 8192;   // 171 ms at 48 kHz
-    bool leanActive_ = false;                    // a lean variant is the code wanted now: laneForced() == leanForced_
-    std::vector<uint8_t> leanForced_;            // its registers with rows
-    bool leanPending_ = false;                   // a lean variant has been asked of the builder thread: leanWant_, leanKey_
+    bool leanActive_ = false;                    // a lean variant is the code wanted now: laneForced() == forcedWithout(leanFolded_)
+    std::vector<uint8_t> leanFolded_;            // the controls it has folded in
+    bool leanPending_ = false;                   // a lean variant has been asked of the builder thread: leanWant_ folded, leanKey_
     std::vector<uint8_t> leanWant_;
     std::string leanKey_;
     bool leanStale_ = false;                     // the set of hot controls may differ from the rows of the code in force / on order

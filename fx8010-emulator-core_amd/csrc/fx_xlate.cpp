@@ -93,6 +93,9 @@ class Translator {
             }
             hoistOmx = simple && any;
             if (hoistOmx) {
+                omxHoisted_ = true;
+                hoistedLo_ = omxLo;
+                hoistedHi_ = omxHi;
                 known_[6] = known_[7] = true;
                 value_[6] = omxLo;
                 value_[7] = omxHi;
@@ -163,7 +166,7 @@ class Translator {
             for (int k = 0; k < H.leadCount; ++k) taintCheckRow(vrow(records[(size_t)k].w[5]));
         if (usesSkipCounter) e_.vop1(VOP1_MOV, "v_mov_b32_e32", vreg(kVNumSkip), imm32(0));  // numSkip is local to process() (FX8010.cpp:1030)
         index_ = records.size();
-        returns_[syncIndex(0)] = base_ + (uint32_t)e_.bytes();
+        syncPoint(syncIndex(0), base_ + (uint32_t)e_.bytes());
         // (a later stage of a pipelined program has nothing at its head that could taint it: its flag check sits behind the barriers)
         const bool cleanHead = staged && G.index > 0 && H.leadCount == 0 && !ring && prog_.trackRows.empty();
         if (fast_ && !cleanHead && !leaveIfTainted((*exactReturns_)[syncIndex(0)])) { if (err) *err = err_; return false; }
@@ -537,7 +540,7 @@ class Translator {
     bool stageFlagCheck(int key) {
         const StageInfo& G = prog_.stage;
         if (G.index == 0) return true;
-        if (!fast_) { returns_[syncIndex(key)] = base_ + (uint32_t)e_.bytes(); return true; }
+        if (!fast_) { syncPoint(syncIndex(key), base_ + (uint32_t)e_.bytes()); return true; }
         flagAccess(true, 2, G.flagBase + 256u * (uint32_t)(G.index - 1), 3);
         e_.waitLgkm0();
         e_.vopc(VOPC_CMP_NE_U32, "v_cmp_ne_u32_e32", imm32(0), 2);
@@ -748,7 +751,7 @@ class Translator {
     bool flush(int key = 0) {
         if (pending_.empty()) return true;
         e_.waitVmcnt(0);
-        returns_[syncIndex(key)] = base_ + (uint32_t)e_.bytes();
+        syncPoint(syncIndex(key), base_ + (uint32_t)e_.bytes());
         if (fast_) {
             plainMode();
             for (int v : pending_) taintCheckRow(v);
@@ -842,13 +845,13 @@ class Translator {
                 if (!leaveIfTainted(exactSync)) deferredFailed_ = true;
                 e_.cold(false);
             });
-            returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+            syncPoint(syncIndex(1), base_ + (uint32_t)e_.bytes());
             return true;
         }
         if (site.guarded) site.window = 0, site.quick = false;
         lutBody(site);
         e_.vop1(VOP1_CVT_F32_F64, "v_cvt_f32_f64_e32", vreg(vR), vreg64(12));
-        returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+        syncPoint(syncIndex(1), base_ + (uint32_t)e_.bytes());
         if (operandWild && fast_) {  // a wild operand can be Inf / NaN, and then so is the result
             taintIfNonFinite(vR);
             if (!leaveIfTainted((*exactReturns_)[syncIndex(1)])) return false;
@@ -1196,7 +1199,7 @@ class Translator {
         }
         // what arrived (and what the interpolation made of it) is checked like any value from memory; both streams define the
         // sync point
-        returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+        syncPoint(syncIndex(1), base_ + (uint32_t)e_.bytes());
         if (fast_) {
             taintCheckRow(vR);
             if (!leaveIfTainted((*exactReturns_)[syncIndex(1)])) return false;
@@ -1723,6 +1726,20 @@ class Translator {
         return (dbits & 0xffffffull) == 0;
     }
 
+    // A sync point: where a wavefront of the FAST stream may arrive in the exact stream (a lane met a non-finite value).  What the
+    // record words s16..s23 hold there is what the fast stream left in them - and the two streams do not set them alike (the
+    // fast stream drops a dead INTERP whose (1 - X) the exact stream had counted on: API fuzz, control panel, seed 2605911) - so
+    // the exact stream forgets what it knew about them.  (The pair a staged program's cold entries load once is the same in both.)
+    void syncPoint(size_t index, uint32_t at) {
+        returns_[index] = at;
+        if (fast_) return;
+        for (int k = 0; k < 8; ++k) known_[k] = false;
+        if (omxHoisted_) {
+            known_[6] = known_[7] = true;
+            value_[6] = hoistedLo_;
+            value_[7] = hoistedHi_;
+        }
+    }
     // s(16+k) = word k of the record, unless it holds that value already
     void setRecordWord(int k, uint32_t value) {
         if (known_[k] && value_[k] == value) return;
@@ -1803,7 +1820,7 @@ class Translator {
             e_.vop2(slot == AS_MACW ? VOP2_ADD_F32 : VOP2_SUB_F32, slot == AS_MACW ? "v_add_f32_e32" : "v_sub_f32_e32", vR, a, 3);
         }
         if (ccrLive) ccrFrom(vR);
-        returns_[syncIndex(1)] = base_ + (uint32_t)e_.bytes();
+        syncPoint(syncIndex(1), base_ + (uint32_t)e_.bytes());
         taintIfNonFinite(vR);
         return leaveIfTainted((*exactReturns_)[syncIndex(1)]);
     }
@@ -1822,7 +1839,7 @@ class Translator {
         e_.sop2(SOP2_ADDC_U32, "s_addc_u32", sreg(kSTemp + 1), sreg(kSEntry + 1), imm32(0));
         e_.sop1NoDst(SOP1_SETPC, "s_setpc_b64", sreg64(kSTemp));
         if (base_ + (uint32_t)e_.bytes() != ret) return fail("internal: call sequence length");
-        returns_[syncIndex(1)] = ret;
+        syncPoint(syncIndex(1), ret);
         indexModeUnknown_ = true;
         ++stats_.called;
         const bool canTaint = slot == AS_MACW || slot == AS_MACWN || slot == AS_MACINTW || slot == AS_LUT || slot == AS_TRAM_IR || slot == AS_TRAM_XR;
@@ -2120,6 +2137,8 @@ class Translator {
     bool nonFinite_ = false;
     bool indexModeUnknown_ = false;  // the per-sample frame enters the stream with index mode off
     bool known_[8] = {};
+    bool omxHoisted_ = false;
+    uint32_t hoistedLo_ = 0, hoistedHi_ = 0;
     uint32_t value_[8] = {};
 };
 

@@ -107,6 +107,10 @@ def scenario_lean_control_variant():
         b.set_register("decay", 0.1 + 0.01 * k)
         b.process_block(x)
     assert b.info("control_rows") == 1 and b.info("code_cache_hits") == hits
+    held = b.info("num_rows")
+    b.set_register_i("w0", 3, 0.1)                        # (a register the program writes anyway: nothing changes)
+    b.process_block(x)
+    assert b.info("num_rows") == held and b.info("control_rows") == 1
     b.set_register("damp", 0.2)                            # a second control starts moving: the full variant is still there
     b.process_block(x)
     assert b.info("control_rows") == 3

@@ -877,7 +877,9 @@ def test_controls_that_stay_put_go_back_into_the_code(gpu, n, monkeypatch):
     oracle's for the same calls; no control variant is ever translated on the caller's thread."""
     for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_BUILDER", "FX_STAGES"):
         monkeypatch.delenv(k, raising=False)
-    text, S = progs.config5(), 32
+    # (config5 with its output gain in a register of its own, `g`, that no instruction writes: folded into the code like a control)
+    text, S = progs.config5().replace("static u\n", "static u\nstatic g = 0.5\n").replace("macs out, 0, m, 0.5", "macs out, 0, m, g"), 32
+    assert "static g = 0.5" in text and "macs out, 0, m, g" in text
     b = gpu.Batch(n, 1, 0)
     assert b.load_text(text), b.errors()
     blocks = 48
@@ -923,6 +925,13 @@ def test_controls_that_stay_put_go_back_into_the_code(gpu, n, monkeypatch):
         both("decay", v)
         step()
     assert rows[-1] == 1
+    # another register gets per-instance values while the lean code runs: it needs a row of its own in the NEXT block's code (the
+    # lean variant remembers which controls it folded, not which registers had rows: the API fuzzer's control panel found that)
+    held = b.info("num_rows")
+    both("g", 0.25, inst=5)
+    step()
+    assert b.info("num_rows") == held + 1 and rows[-1] == 1
+    step(2, settle=True)
     both("damp", 0.2)                                      # a second slider: its value is folded into the lean code
     step()
     assert rows[-1] == 3
@@ -962,7 +971,7 @@ def test_controls_that_stay_put_go_back_into_the_code(gpu, n, monkeypatch):
     assert b.ood_flags() == 0 and b.tier_note().startswith("translated to gfx950 code")
     for i, o in oracles.items():
         assert b.instruction_counter_i(i) == o.instruction_counter()
-    assert b.info("xlate_builds") <= 3, b.info("xlate_builds")     # (the first code; the schedule's code; the long block's class of block lengths when staged)
+    assert b.info("xlate_builds") <= 4, b.info("xlate_builds")     # (the first code; `g`'s row; the schedule's code; the long block's class of block lengths when staged)
 
 
 def test_damaged_state_images_are_refused_before_any_address_is_computed(gpu):

@@ -343,6 +343,39 @@ def test_non_finite_values_follow_the_reference(gpu, k, case):
     if case in ("nan_input", "overflow_in_macw", "nan_state", "inf_uniform"):
         assert saw_nan  # the case does exercise NaN through saturating instructions
 
+def test_a_wavefront_that_changes_streams_finds_the_record_words_set(gpu, monkeypatch):
+    """The translated program has a fast stream and an exact one; a wavefront leaves the fast stream at the next sync point once a
+    lane has met a value outside the bounded class (here: 2.0 read back from the delay line) and continues in the exact stream at
+    the same point.  The two streams do not issue the same instructions - the fast one drops a dead INTERP - so nothing the exact
+    stream loaded into the record words (s16..s23: the fp64 (1 - X) of an INTERP with a constant X) before a sync point may be
+    taken for granted behind it.  Found by the API fuzzer's control panel (seed 2605911: an INTERP computed with (1 - X) = 0 in
+    the first sample of a launch).  Blocks of one sample (every launch starts with whatever the prologue left in s23), of two and
+    of five, a second constant X in the same program; against the oracle, /root/reference/source/FX8010.cpp:1180-1187."""
+    for k in ("FX_KERNEL", "FX_INST_PER_LANE", "FX_STAGES"):
+        monkeypatch.delenv(k, raising=False)
+    text = ("itramsize 3 \ninput in 0\noutput out 0\ncontrol k = 0.125\nstatic a\nstatic b\nstatic c\nstatic t\nstatic rd\n"
+            "interp a, in, k, a\nmacs a, in, 0, 0\nidelay read, rd, at, 0\ninterp b, rd, k, b\nandxor t, 2, 2, 0\nidelay write, t, at, 0\n"
+            "interp c, a, 0.5, c\nmacs out, b, c, 0.25\nend")
+    for N in (64, 300, 20000):
+        for cuts in ([1] * 8, [2, 2, 2, 2], [5, 5], [1, 2, 5, 1, 3]):
+            b = gpu.Batch(N, 1, 0)
+            assert b.load_text(text), b.errors()
+            x = (progs.stimulus(N, sum(cuts)) * 0.5).astype(np.float32)
+            ys, at = [], 0
+            for n in cuts:
+                ys.append(b.process_block(x[at:at + n]))
+                at += n
+            y = np.concatenate(ys, axis=0)
+            assert b.tier_note().startswith("translated to gfx950 code"), b.tier_note()
+            for inst in (0, 63, N - 1):
+                o = Oracle(1)
+                assert o.load_text(text)
+                ref = o.process_block(x[:, inst].copy())
+                assert o.ood_flags() == 0
+                assert np.array_equal(bits(ref), bits(y[:, inst])), (N, cuts, inst)
+                assert b.get_register_bits_i("b", inst) == o.get_register_bits("b") and b.instruction_counter_i(inst) == o.instruction_counter()
+
+
 
 def test_saturation_elision_is_sound(gpu, k):
     """The translator drops the saturation of an instruction whose result provably lies in [-1, 1] given that its

@@ -63,13 +63,16 @@ def value(rng):
 STATS = {"loaded": 0}   # sequences whose program loaded (a generator that produces text the front-end refuses tests nothing)
 
 
-def run(seed, verbose=False):
+def run(seed, verbose=False, edit=None):
+    """edit: a function text -> text applied to the generated program (tools/fuzz_api_reduce.py deletes instructions with it)"""
     rng = np.random.default_rng(880000 + seed)
     gen = stress_fuzz.random_program2 if seed % 2 else stress_fuzz.random_program
     n_regs = int(rng.integers(3, 30))
     text = gen(rng, int(rng.integers(6, 70)), n_regs)
     if PANEL:
         text = with_panel(rng, text)
+    if edit:
+        text = edit(text)
     N = int(rng.choice([1, 63, 64, 65, 130, 200]))
     check = sorted(set([0, N - 1, N // 2]))
     shards = int(os.environ.get("FX_FUZZ_SHARDS", "1"))   # > 1: the same call sequence through a multi-shard handle (all shards on device 0)
@@ -88,7 +91,7 @@ def run(seed, verbose=False):
     pin_out = A.HostBuffer((40, N)) if PINNED else None
 
     def process(handle, xs):
-        if PANEL and rng.integers(0, 2):
+        if PANEL and rng.integers(0, 2) and os.environ.get("FX_FUZZ_PANEL_PREPARE") != "0":
             handle.prepare(xs.shape[0], True)      # (what the builder thread was asked for is there: the block below may adopt it)
         if not PINNED:
             return handle.process_block(xs)
@@ -111,10 +114,31 @@ def run(seed, verbose=False):
         print("N", N, "check", check, "names", names)
     for step in range(30):
         op = rng.integers(0, 15)
+        if os.environ.get("FX_FUZZ_DUMP") == str(step):   # debugging: the oracle's registers before this step
+            every = [l.split()[1] for l in text.split("\n") if l.startswith(("static ", "control "))] + ["in", "out", "ccr"]
+            print("   oracle before step %d, instance %d:" % (step, check[0]), {r: "%08x" % oracles[check[0]].get_register_bits(r) for r in dict.fromkeys(every)},
+                  "cursors", oracles[check[0]].cursors(), "tram0", ["%08x" % v for v in np.asarray(oracles[check[0]].tram(0, 8)).view(np.uint32)])
         if verbose:
+            every = [l.split()[1] for l in text.split("\n") if l.startswith(("static ", "control "))] + ["out", "ccr"]
+            img = b.save_state()
+            hdr = np.frombuffer(img[:64].tobytes(), dtype=np.int32)
+            image_rows = img[64:64 + int(hdr[6]) * N * 4].view(np.uint32).reshape(int(hdr[6]), N)
             for n in check:
-                bad = [(r, "%08x" % b.get_register_bits_i(r, n), "%08x" % oracles[n].get_register_bits(r)) for r in names + ["ccr"]
+                bad = [(r, "%08x" % b.get_register_bits_i(r, n), "%08x" % oracles[n].get_register_bits(r)) for r in dict.fromkeys(names + every)
                        if b.get_register_bits_i(r, n) != oracles[n].get_register_bits(r)]
+                if b.get_cursors_i(n) != oracles[n].cursors():
+                    bad.append(("cursors", b.get_cursors_i(n), oracles[n].cursors()))
+                nregs = int(hdr[5])
+                lfsr = [int(v) for v in image_rows[nregs + 1 + 4: nregs + 1 + 6, n].view(np.int32)]
+                if lfsr != oracles[n].lfsr():
+                    bad.append(("lfsr", lfsr, oracles[n].lfsr()))
+                for which in (0, 1):
+                    try:
+                        dev, ora = b.get_tram_i(which, n, 64), oracles[n].tram(which, 64)
+                        if not np.array_equal(np.asarray(dev).view(np.uint32), np.asarray(ora).view(np.uint32)):
+                            bad.append(("tram%d" % which, ["%08x" % v for v in np.asarray(dev).view(np.uint32)[:12]], ["%08x" % v for v in np.asarray(ora).view(np.uint32)[:12]]))
+                    except Exception as e:
+                        bad.append(("tram%d" % which, str(e)[:80]))
                 if bad or b.instruction_counter_i(n) != oracles[n].instruction_counter():
                     print("  BEFORE step", step, "instance", n, "differs:", bad, "ctr", b.instruction_counter_i(n), oracles[n].instruction_counter())
             print("step", step, "op", int(op), "kernel", b.info("kernel"))
@@ -173,15 +197,42 @@ def run(seed, verbose=False):
                     return False
         elif op < 6:
             S = int(rng.choice([1, 3, 8, 16, 40]))
+            if os.environ.get("FX_FUZZ_FORCE_S", "").startswith("%d:" % step):   # debugging: "6:2" = step 6 with 2 samples
+                S = int(os.environ["FX_FUZZ_FORCE_S"].split(":")[1])
             xs = x[pos:pos + S]
             pos += S
-            y = process(b, xs)
+            if os.environ.get("FX_FUZZ_SPLIT") == str(step):   # debugging: the block as S blocks of one sample, the whole state compared after each
+                every = [l.split()[1] for l in text.split("\n") if l.startswith(("static ", "control "))] + ["out", "ccr"]
+                n = check[0]
+                for i in range(S):
+                    yi = b.process_block(xs[i:i + 1].copy())
+                    ri = oracles[n].process_block(xs[i:i + 1, n].copy())
+                    img = b.save_state()
+                    hdr = np.frombuffer(img[:64].tobytes(), dtype=np.int32)
+                    rows_ = img[64:64 + int(hdr[6]) * N * 4].view(np.uint32).reshape(int(hdr[6]), N)
+                    nregs = int(hdr[5])
+                    bad = [(r, "%08x" % b.get_register_bits_i(r, n), "%08x" % oracles[n].get_register_bits(r)) for r in dict.fromkeys(every) if b.get_register_bits_i(r, n) != oracles[n].get_register_bits(r)]
+                    print("   sample %d of step %d: out device %08x oracle %08x; cursors %s %s; lfsr %s %s; tram0 %s | %s; differing registers %s" % (
+                        i, step, int(yi.view(np.uint32)[0, n]), int(ri.view(np.uint32)[0]), b.get_cursors_i(n), oracles[n].cursors(),
+                        [int(v) for v in rows_[nregs + 1 + 4: nregs + 1 + 6, n].view(np.int32)], oracles[n].lfsr(),
+                        " ".join("%08x" % v for v in np.asarray(b.get_tram_i(0, n, 8)).view(np.uint32)), " ".join("%08x" % v for v in np.asarray(oracles[n].tram(0, 8)).view(np.uint32)), bad))
+                return False
+            else:
+                y = process(b, xs)
             for n in check:
                 ref = oracles[n].process_block(xs[:, n].copy())
                 if oracles[n].ood_flags():
                     return True  # left the parity domain: nothing to compare from here on
                 if not same(ref, y[:, n]):
                     print("MISMATCH seed %d step %d instance %d kernel %d" % (seed, step, n, b.info("kernel")))
+                    if verbose:
+                        rb, yb = np.asarray(ref, dtype=np.float32).view(np.uint32), np.ascontiguousarray(y[:, n]).view(np.uint32)
+                        first = int(np.nonzero(rb != yb)[0][0])
+                        print("  block of %d samples, first differing sample %d: oracle %08x device %08x; tier: %s" % (S, first, rb[first], yb[first], b.tier_note()))
+                        print("  oracle", " ".join("%08x" % v for v in rb[:8]), "\n  device", " ".join("%08x" % v for v in yb[:8]))
+                        every = [l.split()[1] for l in text.split("\n") if l.startswith(("static ", "control "))] + ["out", "ccr"]
+                        print("  registers after the block (device, oracle):", [(r, "%08x" % b.get_register_bits_i(r, n), "%08x" % oracles[n].get_register_bits(r))
+                                                                               for r in dict.fromkeys(every) if b.get_register_bits_i(r, n) != oracles[n].get_register_bits(r)])
                     return False
         elif op < 8:
             name, v = str(rng.choice(names)), value(rng)

@@ -181,8 +181,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--instances", default="4096,8192,16384,32768,65536,98304,131072,196608,262144")
-    ap.add_argument("--device-instances", default="", help="instance counts of the device-resident rows (default: the same, plus 393216 and 524288)")
+    ap.add_argument("--instances", default="4096,16384,65536,98304,131072,147456,163840,180224,196608")
+    ap.add_argument("--device-instances", default="", help="instance counts of the device-resident rows (default: 4096 ... 589824)")
     ap.add_argument("--shards", default="1", help="host-fed rows: shards on the one GPU, e.g. 1,4 (every value is a sweep of its own)")
     ap.add_argument("--no-device", action="store_true", help="skip the device-resident rows")
     ap.add_argument("--json", default="")
@@ -192,7 +192,7 @@ def main():
     import fx8010_amd as A
     import fx8010_programs as progs
     inst = [int(v) for v in args.instances.split(",") if v]
-    dev_inst = [int(v) for v in args.device_instances.split(",") if v] or inst + [393216, 524288]
+    dev_inst = [int(v) for v in args.device_instances.split(",") if v] or [4096, 65536, 131072, 262144, 393216, 458752, 524288, 557056, 589824]
     log = lambda s: print(s, flush=True)
     out = None
     for k in [int(v) for v in args.shards.split(",") if v]:
