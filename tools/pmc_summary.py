@@ -52,9 +52,13 @@ def main():
         print(json.dumps({"error": "no dispatches of %s* under %s" % (prefix, root)}))
         return
     avg = {k: sums[k] / counts[k] for k in sums}
-    waves = avg.get("SQ_WAVES") or meta["grid"] / 64.0
+    # wavefronts per launch: the grid's (one launch = grid / 64 wavefronts, exactly).  SQ_WAVES agrees most of the time; in some
+    # passes one dispatch's window also counts up to one chip-full (4096) of a neighbouring dispatch's wavefronts while every
+    # other counter of it is exact (seen in round 5: 36 864 for 32 768) - it is reported, not used.
+    waves = meta["grid"] / 64.0
     per_ws = {k: v / waves / samples for k, v in avg.items() if k != "SQ_WAVES"}
     out = {"workload": meta, "samples_per_launch": samples, "dispatches_averaged": min(counts.values()), "waves": waves,
+           "sq_waves_counter_mean": avg.get("SQ_WAVES"),
            "per_wave_sample": {k: round(v, 2) for k, v in sorted(per_ws.items())}}
     d = {}
     wc = per_ws.get("SQ_WAVE_CYCLES")
