@@ -65,4 +65,6 @@ run "stages, interpreter off" FX_STAGES=4 timeout -k 10 900 python3 tools/fuzz_s
 run "api pinned buffers"       FX_FUZZ_PINNED=1 timeout -k 10 900 python3 tools/fuzz_api.py 2500000 $((1500*K))
 run "api control panel"        FX_FUZZ_PANEL=1 timeout -k 10 900 python3 tools/fuzz_api.py 2600000 $((2000*K))
 run "api control panel, interpreter"  FX_FUZZ_PANEL=1 FX_KERNEL=asm timeout -k 10 900 python3 tools/fuzz_api.py 2700000 $((600*K))
+run "api control panel, wild registers"  FX_FUZZ_PANEL=1 FX_FUZZ_WILD=1 timeout -k 10 900 python3 tools/fuzz_api.py 2800000 $((2000*K))
+run "api control panel, two shards"      FX_FUZZ_PANEL=1 FX_FUZZ_SHARDS=2 timeout -k 10 900 python3 tools/fuzz_api.py 2900000 $((1000*K))
 echo done
