@@ -1242,7 +1242,6 @@ void Batch::leanStep() {
                 leanFolded_ = leanWant_;
                 leanActive_ = true;
                 lowDirty_ = true;
-                ++leanAdoptions_;
                 return;
             }
             if (buildPending(leanKey_)) return;
@@ -1265,7 +1264,6 @@ void Batch::leanStep() {
         leanFolded_ = want;
         leanActive_ = true;
         lowDirty_ = true;
-        ++leanAdoptions_;
         return;
     }
     if (builder_ && buildFailed(key)) return;

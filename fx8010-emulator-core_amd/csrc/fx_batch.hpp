@@ -242,7 +242,6 @@ private:
     std::vector<uint8_t> leanWant_;
     std::string leanKey_;
     bool leanStale_ = false;                     // the set of hot controls may differ from the rows of the code in force / on order
-    int leanAdoptions_ = 0;
     bool coldControl(int reg) const;
     void coldSetChanged();
     void controlWritten(int reg);

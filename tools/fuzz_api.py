@@ -1,6 +1,15 @@
 """Random programs x random host call sequences against the oracle (default tier; FX_KERNEL pins another).
 
     python tools/fuzz_api.py [first_seed] [count]
+    python tools/fuzz_api.py <seed> 1 verbose      one sequence, every step printed; before each step all registers, delay memory,
+                                                   positions and LFSR words of the checked instances against the oracle
+
+Modes (environment): FX_FUZZ_WILD=1 register values beyond [-1, 1]; FX_FUZZ_SHARDS=n a multi-shard handle; FX_FUZZ_PINNED=1 PCM in
+pinned buffers (in place, aliased, overlapping); FX_FUZZ_PANEL=1 four declared controls in operand positions and the builder
+thread waited for (control variants come and go); FX_FUZZ_NOCOMPARE=1 the calls only (the stand-in build under ASan).
+For a failing seed: tools/fuzz_api_reduce.py shrinks the program; FX_FUZZ_FORCE_S=<step>:<n> gives the plain block of that step n
+samples, FX_FUZZ_SPLIT=<step> runs it sample by sample with the whole state compared after each, FX_FUZZ_DUMP=<step> prints the
+oracle's registers before it (this is how seed 2605911 was taken apart: profiles/r05_fuzz_campaign_x3.txt).
 """
 import os
 import sys
