@@ -1733,6 +1733,7 @@ class Translator {
     void syncPoint(size_t index, uint32_t at) {
         returns_[index] = at;
         if (fast_) return;
+        e_.note("sync point");
         for (int k = 0; k < 8; ++k) known_[k] = false;
         if (omxHoisted_) {
             known_[6] = known_[7] = true;

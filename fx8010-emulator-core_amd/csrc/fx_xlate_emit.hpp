@@ -362,6 +362,14 @@ class Emitter {
     void line(const std::string& t) {
         if (text_) lines_.push_back(t);
     }
+
+public:
+    // a comment line of the listing (no code): the exact streams mark their sync points with it (tests/test_xlate.py walks them)
+    void note(const char* what) {
+        if (text_) lines_.push_back(std::string("; ") + what);
+    }
+
+private:
     bool listing() const { return text_ != nullptr; }
     std::vector<uint32_t>& w_;
     std::string* text_;

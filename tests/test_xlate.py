@@ -170,6 +170,9 @@ def branch_targets(listing):
     # overkill - every instruction here is 4 or 8 bytes, and a literal or a VOP3/DS/global encoding makes it 8
     sizes = []
     for l in lines:
+        if l.startswith(";"):   # (a comment of the listing - the exact streams' sync points - is no code)
+            sizes.append(0)
+            continue
         op = l.split()[0]
         eight = (op.endswith("_e64") or op in ("v_med3_f32", "v_med3_i32", "v_fma_f32", "v_fma_f64", "v_add_f64", "v_mul_f64") or op.startswith(("global_", "ds_", "s_memrealtime"))
                  or re.search(r"0x[0-9a-f]+", l) is not None)
@@ -372,3 +375,69 @@ def test_random_programs_all_translate():
                 failures.append((seed, stream, str(e)[:120]))
                 break
     assert not failures, failures[:5]
+
+
+def _record_word_faults(listing):
+    """walk an exact stream's listing: a vector instruction that reads one of the record words s16..s23 needs that word written
+    since the last sync point (`; sync point`: where a wavefront of the fast stream may arrive - with whatever THAT stream left
+    in the record words)"""
+    written, faults = set(), []
+    for k, l in enumerate(listing.split("\n")):
+        if l.startswith("; sync point"):
+            written = set()
+            continue
+        m = re.match(r"^s_mov_b32 s(\d+),", l)
+        if m and 16 <= int(m.group(1)) <= 23:
+            written.add(int(m.group(1)))
+            continue
+        m = re.match(r"^s_mov_b64 s\[(\d+):(\d+)\],", l)
+        if m and 16 <= int(m.group(1)) <= 23:
+            written.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            continue
+        if not l.startswith("v_"):
+            continue
+        operands = l.split(None, 1)[1] if " " in l else ""
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", operands):
+            for r in range(int(a), int(b) + 1):
+                if 16 <= r <= 23 and r not in written:
+                    faults.append((k, l, r))
+        for r in re.findall(r"\bs(\d+)\b", operands):
+            if 16 <= int(r) <= 23 and int(r) not in written:
+                faults.append((k, l, int(r)))
+    return faults
+
+
+def test_the_exact_stream_takes_no_record_word_for_granted_across_a_sync_point():
+    """A wavefront leaves the fast stream for the exact one at a sync point (a lane met a value outside the bounded class) and
+    continues there mid-sample: whatever the exact stream loaded into s16..s23 EARLIER in the sample - the fp64 (1 - X) of an
+    INTERP with a constant X in s[22:23] - that wavefront has not executed, and the fast stream does not load the same words (it
+    drops dead instructions).  The exact stream therefore forgets its record words at every sync point (fx_xlate.cpp syncPoint;
+    the API fuzzer's control panel found an INTERP running with (1 - X) = 0, seed 2605911; on the device:
+    tests/test_gpu_parity.py::test_a_wavefront_that_changes_streams_finds_the_record_words_set).  Here, without a GPU: every
+    listing of an exact stream - the benchmark programs, fuzzed programs, the fuzzer's control-panel programs, a program made for
+    it - is walked; no vector instruction may read a record word that has not been written since the last sync point."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import fuzz_api
+    made = ("itramsize 3 \ninput in 0\noutput out 0\ncontrol k = 0.125\nstatic a\nstatic b\nstatic c\nstatic t\nstatic rd\n"
+            "interp a, in, k, a\nmacs a, in, 0, 0\nidelay read, rd, at, 0\ninterp b, rd, k, b\nandxor t, 2, 2, 0\nidelay write, t, at, 0\n"
+            "interp c, a, 0.5, c\nmacs out, b, c, 0.25\nend")
+    texts = [("made for it", made)] + program_texts()
+    for s in range(40):
+        rng = np.random.default_rng(990000 + s)
+        texts.append(("panel%d" % s, fuzz_api.with_panel(rng, fuzz_text(7100 + s))))
+    walked = marks = reads = 0
+    for name, text in texts:
+        fe = A.FrontEnd(1)
+        assert fe.load_text(text), name
+        for stream in (1, 3):
+            code, listing = fe.translate(0, stream)
+            assert code, name
+            walked += 1
+            marks += listing.count("; sync point")
+            reads += len(re.findall(r"^v_\w+ .*\bs\[22:23\]", listing, flags=re.M))
+            faults = _record_word_faults(listing)
+            assert not faults, (name, stream, faults[:3])
+        assert "; sync point" not in fe.translate(0, 0)[1]          # (the fast streams leave, they are not arrived at)
+    assert walked >= 100 and marks > 500 and reads > 50, (walked, marks, reads)
