@@ -148,6 +148,8 @@ int Batch::afterLoad(bool ok) {
     }
     hotControl_.assign(prog_.regs.size(), 0);   // (nothing has moved since THIS load)
     lastControlWrite_.assign(prog_.regs.size(), 0);
+    coolAfter_.assign(prog_.regs.size(), kCoolSamples);
+    cooledOnce_.assign(prog_.regs.size(), 0);
     leanActive_ = leanPending_ = false;
     leanStale_ = controlMode_;
     leanKey_.clear();
@@ -1207,6 +1209,10 @@ void Batch::coldSetChanged() {
 void Batch::controlWritten(int reg) {
     const size_t r = (size_t)reg;
     if (!controlMode_ || r >= hotControl_.size()) return;
+    // a control that starts moving again after it had cooled down rests twice as long before it is folded in the next time (a
+    // slider that moves every few hundred milliseconds would otherwise have code built for it, in the background but beside a
+    // real-time stream, again and again: tools/realtime_capacity.py with FX_RT_SLIDER_EVERY=300, profiles/r05_rt_slow_slider.txt)
+    if (!hotControl_[r] && cooledOnce_[r]) coolAfter_[r] = std::min<int64_t>(coolAfter_[r] * 2, kCoolSamplesMost);
     hotControl_[r] = 1;
     lastControlWrite_[r] = sampleClock_;
     if (leanActive_ && r < leanFolded_.size() && leanFolded_[r]) coldSetChanged();
@@ -1223,8 +1229,9 @@ void Batch::leanStep() {
     if (sampleClock_ - lastCoolCheck_ >= kCoolSamples / 8) {
         lastCoolCheck_ = sampleClock_;
         for (size_t r = 0; r < hotControl_.size(); ++r)
-            if (hotControl_[r] && sampleClock_ - lastControlWrite_[r] >= kCoolSamples) {
+            if (hotControl_[r] && sampleClock_ - lastControlWrite_[r] >= coolAfter_[r]) {
                 hotControl_[r] = 0;
+                cooledOnce_[r] = 1;
                 leanStale_ = true;
             }
     }

@@ -235,7 +235,10 @@ private:
     std::vector<uint8_t> hotControl_;            // ... that the host has written lately
     std::vector<int64_t> lastControlWrite_;      // sampleClock_ of that write
     int64_t sampleClock_ = 0, lastCoolCheck_ = 0;   // sample periods processed by this handle
-    static constexpr int64_t kCoolSamples = 8192;   // 171 ms at 48 kHz
+    static constexpr int64_t kCoolSamples = 8192;   // 171 ms at 48 kHz: the first rest after which a control is folded in again
+    static constexpr int64_t kCoolSamplesMost = int64_t(1) << 24;   // ... doubled every time it moved again after cooling, up to 5.8 minutes
+    std::vector<int64_t> coolAfter_;             // per control: the rest it needs now
+    std::vector<uint8_t> cooledOnce_;            // ... it has cooled down before
     bool leanActive_ = false;                    // a lean variant is the code wanted now: laneForced() == forcedWithout(leanFolded_)
     std::vector<uint8_t> leanFolded_;            // the controls it has folded in
     bool leanPending_ = false;                   // a lean variant has been asked of the builder thread: leanWant_ folded, leanKey_

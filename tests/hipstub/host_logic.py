@@ -136,6 +136,15 @@ def scenario_lean_control_variant():
     b.process_block(x)
     assert b.info("control_rows") == 3
     assert b.info("xlate_builds") == 1, b.info("xlate_builds")
+    # a control that moved again after it had cooled down rests twice as long before it is folded in the next time (a slider
+    # that moves every few hundred milliseconds must not have code built for it again and again beside a real-time stream)
+    for _ in range(8192 // 32 + 40):
+        b.process_block(x)
+    settle(1)                                              # 8192 sample periods later: `decay` still has its row
+    for _ in range(8192 // 32 + 40):
+        b.process_block(x)
+    settle(0)                                              # ... 16384: folded in
+    assert b.info("xlate_builds") == 1, b.info("xlate_builds")
     # a state image into a fresh handle in control mode: whatever was lean is full again until the builder has caught up
     c = A.Batch(n, 1, 0)
     assert c.load_text(P.config5())

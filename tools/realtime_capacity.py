@@ -31,7 +31,8 @@ BLOCK = 32                      # AUDIOBLOCKSIZE, /root/reference/include/FX8010
 SAMPLERATE = 48000              # /root/reference/include/FX8010.h:37
 BUDGET_US = BLOCK / SAMPLERATE * 1e6   # 666.667 us: "Erlaubtes Zeitfenster ohne Dropouts", source/main.cpp:155
 SLIDER = (0.1, 0.25, 0.5, 1.0)  # source/main.cpp:80
-SLIDER_EVERY = 8                # a new value every 8th block
+SLIDER_EVERY = int(os.environ.get("FX_RT_SLIDER_EVERY", "8"))   # a new value every 8th block (the environment can slow the slider down: a slider that
+                                # rests longer than 8192 sample periods cools down and is folded into the code again, on the builder thread)
 RING = 8                        # distinct PCM blocks, fed in turn
 
 
